@@ -1,0 +1,184 @@
+/*
+ * mvsim.h -- C ABI of libmvsim.so: MI355X (gfx950) implementation of the per-view
+ * acquisition pipeline of net.preibisch.simulation.SimulateMultiViewDataset
+ *
+ *     rotate -> attenuate -> 3-D PSF convolve -> adjust -> axial slice extraction -> Poisson
+ *
+ * The reference is pure Java with NO foreign-function interface for this path; each entry
+ * point below names the Java static method (file:line in the reference tree) whose body it
+ * replaces.  The Java-side binding a maintainer would add (JNI shim + facade with the same
+ * signatures) is in java/ and described in INTEGRATION.md.
+ *
+ *   SMVD  = src/main/java/net/preibisch/simulation/SimulateMultiViewDataset.java
+ *   Tools = src/main/java/net/preibisch/simulation/Tools.java
+ *
+ * Conventions
+ *   - all images are IEEE float32, x fastest: index = x + Nx*(y + Ny*z)  (ArrayImg order)
+ *   - dim[3] = {Nx, Ny, Nz};  kdim[3] likewise for the PSF
+ *   - every function returns 0 (MVSIM_OK) or a negative status; mvsim_last_error() gives the
+ *     thread-local message of the last failure.  No C++ exception crosses this boundary.
+ *   - "host" entry points: caller owns every buffer, pre-sized; the call is synchronous and
+ *     keeps no reference to the pointers afterwards.
+ *   - "_dev" entry points: pointers are device (HBM) addresses valid on the context's GPU;
+ *     work is enqueued on the context's stream (mvsim_set_stream) and the call returns
+ *     without synchronising unless stated.
+ *   - a context is bound to one GPU and is NOT thread-safe; use one per host thread.
+ *   - there is no CPU fallback: without a usable gfx950 device mvsim_create fails.
+ */
+#ifndef MVSIM_H
+#define MVSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVSIM_OK       0
+#define MVSIM_EINVAL  (-1)   /* bad dims / axis / inc / null pointer              */
+#define MVSIM_ENOMEM  (-2)   /* device or host allocation failed                  */
+#define MVSIM_EHIP    (-3)   /* HIP runtime error                                 */
+#define MVSIM_EFFT    (-4)   /* rocFFT error                                      */
+#define MVSIM_ERCCL   (-5)   /* RCCL error                                        */
+#define MVSIM_ENODEV  (-6)   /* no usable GPU                                     */
+
+typedef struct mvsim_ctx mvsim_ctx;
+
+/* ---- library / context ------------------------------------------------------------ */
+const char* mvsim_version(void);
+const char* mvsim_last_error(void);
+int  mvsim_device_count(int* count);
+int  mvsim_create(int device, mvsim_ctx** ctx);
+int  mvsim_destroy(mvsim_ctx* ctx);
+/* Use a caller-owned hipStream_t (e.g. the host framework's current stream); NULL restores
+ * the context's own stream. */
+int  mvsim_set_stream(mvsim_ctx* ctx, void* hip_stream);
+int  mvsim_synchronize(mvsim_ctx* ctx);
+/* Release cached FFT plans / workspaces / PSF spectra held by the context. */
+int  mvsim_release_caches(mvsim_ctx* ctx);
+
+/* ---- device memory (for hosts that keep volumes resident between calls) ------------- */
+int  mvsim_dev_alloc(mvsim_ctx* ctx, size_t bytes, void** dptr);
+int  mvsim_dev_free(mvsim_ctx* ctx, void* dptr);
+int  mvsim_upload(mvsim_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int  mvsim_download(mvsim_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- pure host helpers --------------------------------------------------------------- */
+/* SMVD:80-102 axisRotation(Interval,int axis,int degrees): forward model T(+c) R T(-c) as a
+ * row-major 3x4 matrix (mpicbg AffineModel3D layout m00..m23).  Zero-min interval assumed. */
+int     mvsim_axis_rotation(const int64_t dim[3], int axis, int degrees, double m[12]);
+/* (Nz-1)/inc+1, SMVD:197 */
+int64_t mvsim_extract_nz(int64_t nz, int inc);
+/* (Nz_acq-1)*inc+1, SMVD:146 */
+int64_t mvsim_isotropic_nz(int64_t nz_acq, int inc);
+/* (SNR/sqrt(5))^2, Tools:76 */
+double  mvsim_poisson_mul(double snr);
+
+/* ---- stage operators, host buffers ----------------------------------------------------- */
+/* SMVD:104-135 rotateAroundAxis: out[l] = trilinear(in zero-extended, M^-1 l). */
+int mvsim_rotate_around_axis(mvsim_ctx* ctx, const float* in, const int64_t dim[3],
+                             int axis, int degrees, float* out);
+/* SMVD:318-364 attenuate3d: light enters at y = Ny-1; Nx > Ny is rejected (the reference
+ * walks dimension(0) steps along y and leaves the interval). */
+int mvsim_attenuate3d(mvsim_ctx* ctx, const float* in, const int64_t dim[3], double delta, float* out);
+/* Tools:112-118 normImage: img <- (float)(img / sum), in place. */
+int mvsim_norm_image(mvsim_ctx* ctx, float* img, int64_t n);
+/* SMVD:253-264 convolve(img, psf, service): normalises psf IN PLACE (sum -> 1), then exact
+ * linear convolution with mirror-single image boundary, kernel centre kdim/2, no flip.
+ * method: 0 = auto, 1 = FFT, 2 = direct LDS-tiled stencil. */
+int mvsim_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3],
+                   float* psf, const int64_t kdim[3], int method, float* out);
+/* Tools:143-159 adjustImage: in place; *correction = (target - min) / mean. */
+int mvsim_adjust_image(mvsim_ctx* ctx, float* img, int64_t n, float min_value, float target_average,
+                       double* correction);
+/* SMVD:181-231 extractSlices(img, inc, poissonSNR, rnd): out has mvsim_extract_nz(Nz,inc)
+ * planes.  snr < 0 => bit-exact strided copy.  Otherwise per-voxel Poisson(lambda = v * mul)
+ * from the counter-based generator keyed by (seed, stream) with counter = source voxel index;
+ * the Java facade takes seed = rnd.nextLong(). */
+int mvsim_extract_slices(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float snr,
+                         uint64_t seed, uint32_t stream, float* out);
+/* Tools:73-86 poissonProcess(img, SNR, rnd): in place over n values; counter = index_offset+i. */
+int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr,
+                          uint64_t seed, uint32_t stream, uint64_t index_offset);
+/* SMVD:144-171 makeIsotropic: out has mvsim_isotropic_nz(Nz,inc) planes. */
+int mvsim_make_isotropic(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float* out);
+/* SMVD:280-316 computeWeightImage (the reference ignores its delta argument). */
+int mvsim_compute_weight_image(mvsim_ctx* ctx, const int64_t dim[3], float* out);
+
+/* ---- stage operators, device-resident buffers (asynchronous on the context stream) ------ */
+int mvsim_rotate_around_axis_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3],
+                                 int axis, int degrees, float* out);
+int mvsim_attenuate3d_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], double delta, float* out);
+/* psf_host is normalised in place on the host (it is <= ~1 MB), then uploaded. */
+int mvsim_convolve_dev(mvsim_ctx* ctx, const float* img, const int64_t dim[3],
+                       float* psf_host, const int64_t kdim[3], int method, float* out);
+/* Synchronises (the correction is returned to the host). */
+int mvsim_adjust_image_dev(mvsim_ctx* ctx, float* img, int64_t n, float min_value, float target_average,
+                           double* correction);
+int mvsim_extract_slices_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float snr,
+                             uint64_t seed, uint32_t stream, float* out);
+int mvsim_make_isotropic_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float* out);
+int mvsim_compute_weight_image_dev(mvsim_ctx* ctx, const int64_t dim[3], float* out);
+
+/* ---- fused per-view pipeline: loop body SMVD:570-585 -------------------------------------- */
+typedef struct mvsim_view_params {
+    int32_t  axis;            /* 0 (SMVD:570)                                  */
+    int32_t  degrees;         /* angle + angleOffset                           */
+    double   delta;           /* attenuation, 0.01 (SMVD:533)                  */
+    float    min_value;       /* 1e-4f (SMVD:77)                               */
+    float    target_average;  /* 1     (SMVD:78)                               */
+    int32_t  inc;             /* lightsheetSpacing (SMVD:532)                  */
+    float    snr;             /* poissonSNR, 25 (SMVD:531); < 0 => no noise    */
+    uint64_t seed;            /* counter-RNG key; 464232194 (SMVD:76)          */
+    uint32_t stream;          /* view index                                    */
+    int32_t  conv_method;     /* 0 auto, 1 FFT, 2 direct stencil               */
+} mvsim_view_params;
+
+/* Optional intermediate outputs (NULL = not wanted).  acq is required. */
+typedef struct mvsim_view_outputs {
+    float* rot;   /* Nx*Ny*Nz               (SMVD:570) */
+    float* att;   /* Nx*Ny*Nz               (SMVD:573) */
+    float* con;   /* Nx*Ny*Nz, adjusted     (SMVD:580-582) */
+    float* acq;   /* Nx*Ny*extract_nz       (SMVD:585) */
+} mvsim_view_outputs;
+
+void mvsim_view_params_default(mvsim_view_params* p);
+
+/* Device-resident: gt and every non-NULL output are device pointers; psf_host is a host
+ * buffer, normalised in place.  Intermediates stay in HBM; nothing is copied to the host
+ * except the scalar correction when correction != NULL (which forces a synchronise). */
+int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3],
+                            float* psf_host, const int64_t kdim[3],
+                            const mvsim_view_params* params, const mvsim_view_outputs* out,
+                            double* correction);
+/* Host buffers in / out (what the JNI shim calls). */
+int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3],
+                        float* psf_host, const int64_t kdim[3],
+                        const mvsim_view_params* params, const mvsim_view_outputs* out,
+                        double* correction);
+
+/* ---- per-stage device timings of the last simulate_view / stage call (milliseconds) ------ */
+typedef struct mvsim_timings {
+    float rotate_ms, attenuate_ms, psf_ms, convolve_ms, adjust_ms, extract_ms, total_ms;
+} mvsim_timings;
+int mvsim_enable_timing(mvsim_ctx* ctx, int enable);
+int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t);
+
+/* ---- multi-GPU: one process per GPU, views shard across ranks (RCCL over xGMI) ------------ */
+#define MVSIM_UNIQUE_ID_BYTES 128
+/* rank 0 creates the id, the host passes the 128 bytes to every rank by any means. */
+int mvsim_comm_unique_id(unsigned char id[MVSIM_UNIQUE_ID_BYTES]);
+int mvsim_comm_init(mvsim_ctx* ctx, int nranks, int rank, const unsigned char id[MVSIM_UNIQUE_ID_BYTES]);
+/* Broadcast the ground-truth volume (device pointer, count floats) from root; enqueued on
+ * the context stream.  The only collective on the path (views are independent, SMVD:567). */
+int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, int root);
+int mvsim_comm_destroy(mvsim_ctx* ctx);
+/* view v of n_views belongs to rank v % nranks; returns how many views `rank` owns and writes
+ * their indices (capacity max_out). */
+int mvsim_shard_views(int n_views, int nranks, int rank, int* view_idx, int max_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVSIM_H */

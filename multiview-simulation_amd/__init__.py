@@ -1,0 +1,425 @@
+"""multiview-simulation_amd -- MI355X (gfx950) drop-in for the per-view acquisition path of
+``net.preibisch.simulation.SimulateMultiViewDataset``:
+
+    rotate -> attenuate -> 3-D PSF convolve -> adjust -> axial slice extraction -> Poisson
+
+The arithmetic lives in hand-written HIP kernels inside ``libmvsim.so`` (C ABI: ``include/mvsim.h``).
+This package is the host-side mirror of the reference's static-method interface, written in Python
+because the image has no JVM; the Java facade + JNI shim with identical signatures is under
+``java/``.  Images are numpy float32 arrays shaped ``(Nz, Ny, Nx)`` (x fastest),
+standing in for ImgLib2 ``RandomAccessibleInterval<FloatType>`` / ``Img<FloatType>``.
+
+The directory name carries a hyphen, so import it with::
+
+    import importlib; mvs = importlib.import_module("multiview-simulation_amd")
+
+There is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import MvsimError, MvsimNoDeviceError, Timings, ViewOutputs, ViewParams  # noqa: F401
+
+__all__ = ["Context", "JavaRandom", "SimulateMultiViewDataset", "Tools", "default_context", "MvsimError",
+           "MvsimNoDeviceError", "ViewParams", "shard_views", "version"]
+
+
+def version() -> str:
+    return _lib.load().mvsim_version().decode()
+
+
+# ------------------------------------------------------------------------------------------------
+# java.util.Random (JDK specification) -- host logic: the reference's entry points take a Random
+# (SimulateMultiViewDataset.java:195, Tools.java:73); the facade draws nextLong() from it as the
+# counter-RNG seed so that `new Random(seed0)` on the caller side stays reproducible.
+# ------------------------------------------------------------------------------------------------
+class JavaRandom:
+    _MULT = 0x5DEECE66D
+    _MASK = (1 << 48) - 1
+
+    def __init__(self, seed: int):
+        self.setSeed(seed)
+
+    def setSeed(self, seed: int) -> None:
+        self._s = (seed ^ self._MULT) & self._MASK
+
+    def next(self, bits: int) -> int:
+        self._s = (self._s * self._MULT + 0xB) & self._MASK
+        v = self._s >> (48 - bits)
+        v &= 0xFFFFFFFF
+        return v - (1 << 32) if v & 0x80000000 else v
+
+    def nextInt(self, bound: int | None = None) -> int:
+        if bound is None:
+            return self.next(32)
+        if bound <= 0:
+            raise ValueError("bound must be positive")
+        r = self.next(31)
+        m = bound - 1
+        if bound & m == 0:
+            return (bound * r) >> 31
+        u = r
+        while True:
+            r = u % bound
+            t = (u - r + m) & 0xFFFFFFFF
+            if not (t & 0x80000000):
+                return r
+            u = self.next(31)
+
+    def nextLong(self) -> int:
+        v = ((self.next(32) << 32) + self.next(32)) & 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v & (1 << 63) else v
+
+    def nextDouble(self) -> float:
+        return ((self.next(26) << 27) + self.next(27)) * (1.0 / (1 << 53))
+
+
+def _seed_from(rnd) -> int:
+    if rnd is None:
+        rnd = SimulateMultiViewDataset.rnd
+    if isinstance(rnd, int):
+        return rnd & 0xFFFFFFFFFFFFFFFF
+    return rnd.nextLong() & 0xFFFFFFFFFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------
+def _as_volume(a, name="image") -> np.ndarray:
+    """Any array-like / strided view -> contiguous float32 (Nz,Ny,Nx), as the Java facade copies an
+    arbitrary RandomAccessibleInterval view into a direct buffer."""
+    v = np.ascontiguousarray(a, dtype=np.float32)
+    if v.ndim != 3:
+        raise ValueError(f"{name}: expected 3 dimensions, got {v.ndim}")
+    if v.size == 0:
+        raise ValueError(f"{name}: empty interval")
+    return v
+
+
+def _dim(v: np.ndarray):
+    nz, ny, nx = v.shape
+    return (C.c_int64 * 3)(nx, ny, nz)
+
+
+def _ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One ``mvsim_ctx``: bound to one GPU, not thread-safe."""
+
+    def __init__(self, device: int | None = None):
+        self._h = C.c_void_p()
+        self._L = _lib.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        _lib.check(self._L.mvsim_create(device, C.byref(self._h)))
+        self.device = device
+
+    # -- lifecycle
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.mvsim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream: int | None) -> None:
+        _lib.check(self._L.mvsim_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self) -> None:
+        _lib.check(self._L.mvsim_synchronize(self._h))
+
+    def release_caches(self) -> None:
+        _lib.check(self._L.mvsim_release_caches(self._h))
+
+    # -- device memory
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        _lib.check(self._L.mvsim_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value or 0
+
+    def dev_free(self, dptr: int) -> None:
+        _lib.check(self._L.mvsim_dev_free(self._h, C.c_void_p(dptr)))
+
+    def upload(self, dptr: int, host: np.ndarray) -> None:
+        host = np.ascontiguousarray(host)
+        _lib.check(self._L.mvsim_upload(self._h, C.c_void_p(dptr), _ptr(host), host.nbytes))
+
+    def download(self, dptr: int, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        _lib.check(self._L.mvsim_download(self._h, _ptr(out), C.c_void_p(dptr), out.nbytes))
+        return out
+
+    # -- host-buffer stage operators
+    def rotate_around_axis(self, img, axis: int, degrees: int) -> np.ndarray:
+        v = _as_volume(img)
+        out = np.empty_like(v)
+        _lib.check(self._L.mvsim_rotate_around_axis(self._h, _ptr(v), _dim(v), axis, degrees, _ptr(out)))
+        return out
+
+    def attenuate3d(self, img, delta: float) -> np.ndarray:
+        v = _as_volume(img)
+        out = np.empty_like(v)
+        _lib.check(self._L.mvsim_attenuate3d(self._h, _ptr(v), _dim(v), float(delta), _ptr(out)))
+        return out
+
+    def norm_image(self, img: np.ndarray) -> None:
+        _check_inplace(img)
+        _lib.check(self._L.mvsim_norm_image(self._h, _ptr(img), img.size))
+
+    def convolve(self, img, psf: np.ndarray, method: int = 0) -> np.ndarray:
+        v = _as_volume(img)
+        _check_inplace(psf, "psf")
+        if psf.ndim != 3:
+            raise ValueError("psf: expected 3 dimensions")
+        out = np.empty_like(v)
+        _lib.check(self._L.mvsim_convolve(self._h, _ptr(v), _dim(v), _ptr(psf), _dim(psf), method, _ptr(out)))
+        return out
+
+    def adjust_image(self, img: np.ndarray, min_value: float, target_average: float) -> float:
+        _check_inplace(img)
+        corr = C.c_double()
+        _lib.check(self._L.mvsim_adjust_image(self._h, _ptr(img), img.size, min_value, target_average, C.byref(corr)))
+        return corr.value
+
+    def extract_slices(self, img, inc: int, snr: float, seed: int, stream: int = 0) -> np.ndarray:
+        v = _as_volume(img)
+        nz, ny, nx = v.shape
+        if inc < 1:
+            raise ValueError("inc must be >= 1")
+        out = np.empty((self._L.mvsim_extract_nz(nz, inc), ny, nx), dtype=np.float32)
+        _lib.check(self._L.mvsim_extract_slices(self._h, _ptr(v), _dim(v), inc, snr, seed & 0xFFFFFFFFFFFFFFFF,
+                                                stream, _ptr(out)))
+        return out
+
+    def poisson_process(self, img: np.ndarray, snr: float, seed: int, stream: int = 0, index_offset: int = 0) -> None:
+        _check_inplace(img)
+        _lib.check(self._L.mvsim_poisson_process(self._h, _ptr(img), img.size, float(snr),
+                                                 seed & 0xFFFFFFFFFFFFFFFF, stream, index_offset))
+
+    def make_isotropic(self, img, inc: int) -> np.ndarray:
+        v = _as_volume(img)
+        nz, ny, nx = v.shape
+        if inc < 1:
+            raise ValueError("inc must be >= 1")
+        out = np.empty((self._L.mvsim_isotropic_nz(nz, inc), ny, nx), dtype=np.float32)
+        _lib.check(self._L.mvsim_make_isotropic(self._h, _ptr(v), _dim(v), inc, _ptr(out)))
+        return out
+
+    def compute_weight_image(self, shape_zyx) -> np.ndarray:
+        nz, ny, nx = (int(s) for s in shape_zyx)
+        out = np.empty((nz, ny, nx), dtype=np.float32)
+        _lib.check(self._L.mvsim_compute_weight_image(self._h, (C.c_int64 * 3)(nx, ny, nz), _ptr(out)))
+        return out
+
+    # -- fused per-view pipeline
+    def view_params(self, **kw) -> ViewParams:
+        p = ViewParams()
+        self._L.mvsim_view_params_default(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown view parameter {k!r}")
+            setattr(p, k, v)
+        return p
+
+    def simulate_view(self, gt, psf: np.ndarray, params: ViewParams, want=("acq",)) -> dict:
+        """Host buffers in/out.  ``want`` is a subset of {'rot','att','con','acq'}; returns a dict with the
+        requested stages plus 'corr'.  ``psf`` is normalised in place (reference behaviour)."""
+        v = _as_volume(gt, "ground truth")
+        _check_inplace(psf, "psf")
+        nz, ny, nx = v.shape
+        res = {}
+        o = ViewOutputs()
+        for name in ("rot", "att", "con"):
+            if name in want:
+                res[name] = np.empty_like(v)
+                setattr(o, name, res[name].ctypes.data)
+        res["acq"] = np.empty((self._L.mvsim_extract_nz(nz, params.inc), ny, nx), dtype=np.float32)
+        o.acq = res["acq"].ctypes.data
+        corr = C.c_double()
+        _lib.check(self._L.mvsim_simulate_view(self._h, _ptr(v), _dim(v), _ptr(psf), _dim(psf), C.byref(params),
+                                               C.byref(o), C.byref(corr)))
+        res["corr"] = corr.value
+        return res
+
+    def simulate_view_dev(self, gt_dptr: int, dim_xyz, psf: np.ndarray, params: ViewParams, acq_dptr: int,
+                          rot_dptr: int = 0, att_dptr: int = 0, con_dptr: int = 0, want_corr: bool = False):
+        """Device-resident buffers (raw HBM addresses); asynchronous unless ``want_corr``."""
+        _check_inplace(psf, "psf")
+        o = ViewOutputs(rot_dptr or None, att_dptr or None, con_dptr or None, acq_dptr or None)
+        corr = C.c_double()
+        _lib.check(self._L.mvsim_simulate_view_dev(
+            self._h, C.c_void_p(gt_dptr), (C.c_int64 * 3)(*dim_xyz), _ptr(psf), _dim(psf), C.byref(params),
+            C.byref(o), C.byref(corr) if want_corr else None))
+        return corr.value if want_corr else None
+
+    # -- device-resident stage operators (raw addresses)
+    def rotate_around_axis_dev(self, in_dptr, dim_xyz, axis, degrees, out_dptr):
+        _lib.check(self._L.mvsim_rotate_around_axis_dev(self._h, C.c_void_p(in_dptr), (C.c_int64 * 3)(*dim_xyz), axis,
+                                                        degrees, C.c_void_p(out_dptr)))
+
+    def attenuate3d_dev(self, in_dptr, dim_xyz, delta, out_dptr):
+        _lib.check(self._L.mvsim_attenuate3d_dev(self._h, C.c_void_p(in_dptr), (C.c_int64 * 3)(*dim_xyz), float(delta),
+                                                 C.c_void_p(out_dptr)))
+
+    def convolve_dev(self, in_dptr, dim_xyz, psf: np.ndarray, out_dptr, method: int = 0):
+        _check_inplace(psf, "psf")
+        _lib.check(self._L.mvsim_convolve_dev(self._h, C.c_void_p(in_dptr), (C.c_int64 * 3)(*dim_xyz), _ptr(psf),
+                                              _dim(psf), method, C.c_void_p(out_dptr)))
+
+    def adjust_image_dev(self, dptr, n, min_value, target_average, want_corr=True):
+        corr = C.c_double()
+        _lib.check(self._L.mvsim_adjust_image_dev(self._h, C.c_void_p(dptr), n, min_value, target_average,
+                                                  C.byref(corr) if want_corr else None))
+        return corr.value if want_corr else None
+
+    def extract_slices_dev(self, in_dptr, dim_xyz, inc, snr, seed, stream, out_dptr):
+        _lib.check(self._L.mvsim_extract_slices_dev(self._h, C.c_void_p(in_dptr), (C.c_int64 * 3)(*dim_xyz), inc, snr,
+                                                    seed & 0xFFFFFFFFFFFFFFFF, stream, C.c_void_p(out_dptr)))
+
+    # -- timings
+    def enable_timing(self, enable: bool = True) -> None:
+        _lib.check(self._L.mvsim_enable_timing(self._h, 1 if enable else 0))
+
+    def timings(self) -> dict:
+        t = Timings()
+        _lib.check(self._L.mvsim_get_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
+    # -- multi-GPU
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_ubyte * _lib.UNIQUE_ID_BYTES)()
+        _lib.check(_lib.load().mvsim_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks: int, rank: int, uid: bytes) -> None:
+        if len(uid) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = (C.c_ubyte * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
+        _lib.check(self._L.mvsim_comm_init(self._h, nranks, rank, buf))
+
+    def comm_broadcast_volume(self, dptr: int, count: int, root: int = 0) -> None:
+        _lib.check(self._L.mvsim_comm_broadcast_volume(self._h, C.c_void_p(dptr), count, root))
+
+    def comm_destroy(self) -> None:
+        _lib.check(self._L.mvsim_comm_destroy(self._h))
+
+
+def _check_inplace(a, name="image") -> None:
+    if not isinstance(a, np.ndarray) or a.dtype != np.float32 or not a.flags.c_contiguous or not a.flags.writeable:
+        raise ValueError(f"{name}: in-place operators need a writable C-contiguous float32 numpy array")
+    if a.size == 0:
+        raise ValueError(f"{name}: empty image")
+
+
+def shard_views(n_views: int, nranks: int, rank: int) -> list[int]:
+    """view v -> rank v % nranks (host logic only; usable without a GPU)."""
+    L = _lib.load()
+    cap = max(n_views, 1)
+    buf = (C.c_int * cap)()
+    cnt = L.mvsim_shard_views(n_views, nranks, rank, buf, cap)
+    if cnt < 0:
+        _lib.check(cnt)
+    return [buf[i] for i in range(cnt)]
+
+
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+# ------------------------------------------------------------------------------------------------
+# Mirror of the reference's static-method interface (same names, argument meaning, in-place
+# behaviour).  File:line citations are into the reference tree.
+# ------------------------------------------------------------------------------------------------
+class Tools:
+    """net.preibisch.simulation.Tools (numeric helpers on the hot path)."""
+
+    @staticmethod
+    def poissonProcess(img: np.ndarray, SNR: float, rnd=None) -> None:
+        """Tools.java:73-86 -- in place; counts are not rescaled."""
+        default_context().poisson_process(img, SNR, _seed_from(rnd))
+
+    @staticmethod
+    def normImage(img: np.ndarray) -> None:
+        """Tools.java:112-118 -- in place, sum -> 1."""
+        default_context().norm_image(img)
+
+    @staticmethod
+    def adjustImage(image: np.ndarray, minValue: float, targetAverage: float) -> float:
+        """Tools.java:143-159 -- in place; returns the multiplicative correction."""
+        return default_context().adjust_image(image, minValue, targetAverage)
+
+
+class SimulateMultiViewDataset:
+    """net.preibisch.simulation.SimulateMultiViewDataset -- per-view operators."""
+
+    rnd = JavaRandom(464232194)        # SimulateMultiViewDataset.java:76
+    minValue = float(np.float32(0.0001))   # :77
+    avgIntensity = 1.0                 # :78
+
+    @staticmethod
+    def axisRotation(interval_dims_xyz, axis: int, degrees: int) -> np.ndarray:
+        """:80-102 -- forward model T(+c) R T(-c) as a 3x4 row-major matrix."""
+        L = _lib.load()
+        m = (C.c_double * 12)()
+        _lib.check(L.mvsim_axis_rotation((C.c_int64 * 3)(*interval_dims_xyz), axis, degrees, m))
+        return np.array(m, dtype=np.float64).reshape(3, 4)
+
+    @staticmethod
+    def rotateAroundAxis(img, axis: int, degrees: int) -> np.ndarray:
+        """:104-135"""
+        return default_context().rotate_around_axis(img, axis, degrees)
+
+    @staticmethod
+    def attenuate3d(img, delta: float) -> np.ndarray:
+        """:318-364"""
+        return default_context().attenuate3d(img, delta)
+
+    @staticmethod
+    def convolve(img, psf: np.ndarray, service=None) -> np.ndarray:
+        """:253-264 -- normalises ``psf`` in place; ``service`` (ExecutorService) accepted and ignored."""
+        return default_context().convolve(img, psf)
+
+    @staticmethod
+    def extractSlices(img, inc: int, poissonSNR: float, rnd=None) -> np.ndarray:
+        """:181-231 -- every inc-th slice; Poisson noise iff poissonSNR >= 0."""
+        seed = _seed_from(rnd) if poissonSNR >= 0.0 else 0
+        return default_context().extract_slices(img, inc, poissonSNR, seed)
+
+    @staticmethod
+    def poissonProcess(img, poissonSNR: float, rnd=None) -> np.ndarray:
+        """:233-251 -- copy, then Tools.poissonProcess on the copy."""
+        out = np.array(img, dtype=np.float32, order="C", copy=True)
+        Tools.poissonProcess(out, poissonSNR, rnd)
+        return out
+
+    @staticmethod
+    def makeIsotropic(img, inc: int) -> np.ndarray:
+        """:144-171"""
+        return default_context().make_isotropic(img, inc)
+
+    @staticmethod
+    def computeWeightImage(img, delta: float = 0.0) -> np.ndarray:
+        """:280-316 -- only the interval of ``img`` is used; ``delta`` is ignored as in the reference."""
+        return default_context().compute_weight_image(np.shape(img))

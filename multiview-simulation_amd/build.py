@@ -1,0 +1,79 @@
+"""Build recipe for libmvsim.so (hipcc, gfx950 only, in-tree so the .so travels with the repo)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmvsim.so")
+SOURCES = ["api.cpp", "comm.cpp", "kernels.hip", "fftconv.hip", "fft_kernels.hip", "stencil.hip"]
+HEADERS = ["common.h", "poisson_dev.h", "../../include/mvsim.h"]
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def _hipcc() -> str:
+    for cand in (os.path.join(ROCM, "bin", "hipcc"), shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libmvsim.so)")
+
+
+def sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def is_current() -> bool:
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    deps = sources() + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)]
+    return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every translation unit for gfx950 and link libmvsim.so.
+
+    -ffp-contract=off: the parity-relevant kernels state their rounding points explicitly
+    (fmaf() where a fused op is wanted); the compiler must not fuse behind our back.
+    """
+    if not force and is_current():
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    common = [
+        "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+        "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROCM, "include"),
+    ]
+    procs = []
+    for src in sources():
+        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        cmd = [hipcc, "-x", "hip", "-c", src, "-o", obj] + common
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- {src} ---\n{out}\n")
+        elif verbose and out.strip():
+            sys.stderr.write(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    link = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + [
+        "-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib"),
+    ]
+    if verbose:
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

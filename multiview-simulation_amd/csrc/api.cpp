@@ -1,0 +1,703 @@
+// C ABI of libmvsim (include/mvsim.h): context, memory, host-buffer and device-buffer stage
+// operators and the fused per-view pipeline.  Host orchestration only -- every voxel of
+// arithmetic happens in the HIP kernels (kernels.hip, fftconv.hip, stencil.hip).
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace mvsim {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int DevBuf::reserve(size_t need)
+{
+    if (need <= bytes) return MVSIM_OK;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e));
+        return MVSIM_ENOMEM;
+    }
+    bytes = need;
+    return MVSIM_OK;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+int PinnedRing::acquire(size_t need, int* slot)
+{
+    const int i = next;
+    next = (next + 1) % SLOTS;
+    if (busy[i]) { MVSIM_HIP(hipEventSynchronize(ev[i])); busy[i] = false; }
+    if (!ev[i]) MVSIM_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    if (bytes[i] < need) {
+        if (p[i]) { (void)hipHostFree(p[i]); p[i] = nullptr; bytes[i] = 0; }
+        MVSIM_HIP(hipHostMalloc(&p[i], need, hipHostMallocDefault));
+        bytes[i] = need;
+    }
+    *slot = i;
+    return MVSIM_OK;
+}
+
+void PinnedRing::release_all()
+{
+    for (int i = 0; i < SLOTS; ++i) {
+        if (busy[i]) (void)hipEventSynchronize(ev[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (p[i]) (void)hipHostFree(p[i]);
+        p[i] = nullptr; bytes[i] = 0; ev[i] = nullptr; busy[i] = false;
+    }
+}
+
+// ---- affine model (mpicbg AffineModel3D semantics; SimulateMultiViewDataset.java:80-102) -------
+static void ident(double m[12])
+{
+    for (int i = 0; i < 12; ++i) m[i] = 0.0;
+    m[0] = m[5] = m[10] = 1.0;
+}
+
+// a <- b o a
+static void pre_concat(double a[12], const double b[12])
+{
+    double r[12];
+    for (int i = 0; i < 3; ++i) {
+        const double* bi = b + 4 * i;
+        for (int j = 0; j < 3; ++j) r[4 * i + j] = bi[0] * a[j] + bi[1] * a[4 + j] + bi[2] * a[8 + j];
+        r[4 * i + 3] = bi[0] * a[3] + bi[1] * a[7] + bi[2] * a[11] + bi[3];
+    }
+    std::memcpy(a, r, sizeof(r));
+}
+
+void axis_rotation_host(const int64_t dim[3], int axis, int degrees, double m[12])
+{
+    // centre = (max - min) / 2 in integer arithmetic (SMVD:84-86)
+    double c[3];
+    for (int d = 0; d < 3; ++d) c[d] = (double)((dim[d] - 1) / 2);
+    // (float)Math.toRadians(degrees) (SMVD:90)
+    const double theta = (double)(float)((double)degrees * 0.017453292519943295);
+    const double co = std::cos(theta), si = std::sin(theta);
+    double t1[12], rot[12], t2[12];
+    ident(t1); ident(rot); ident(t2);
+    t1[3] = -c[0]; t1[7] = -c[1]; t1[11] = -c[2];
+    t2[3] = c[0];  t2[7] = c[1];  t2[11] = c[2];
+    switch (axis) {
+        case 0:  rot[5] = co; rot[6] = -si; rot[9] = si;  rot[10] = co; break;
+        case 1:  rot[0] = co; rot[2] = si;  rot[8] = -si; rot[10] = co; break;
+        default: rot[0] = co; rot[1] = -si; rot[4] = si;  rot[5] = co;  break;
+    }
+    pre_concat(t1, rot);   // SMVD:98
+    pre_concat(t1, t2);    // SMVD:99
+    std::memcpy(m, t1, 12 * sizeof(double));
+}
+
+void affine_invert_host(const double m[12], double v[12])
+{
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const double det = a * e * i + d * h * c + g * b * f - c * e * g - f * h * a - i * b * d;
+    v[0] = (e * i - f * h) / det;  v[1] = (c * h - b * i) / det;  v[2] = (b * f - c * e) / det;
+    v[4] = (f * g - d * i) / det;  v[5] = (a * i - c * g) / det;  v[6] = (c * d - a * f) / det;
+    v[8] = (d * h - e * g) / det;  v[9] = (b * g - a * h) / det;  v[10] = (a * e - b * d) / det;
+    v[3]  = -v[0] * m[3] - v[1] * m[7] - v[2] * m[11];
+    v[7]  = -v[4] * m[3] - v[5] * m[7] - v[6] * m[11];
+    v[11] = -v[8] * m[3] - v[9] * m[7] - v[10] * m[11];
+}
+
+static int check_dim(const int64_t dim[3])
+{
+    MVSIM_CHECK_ARG(dim != nullptr, "dim is null");
+    MVSIM_CHECK_ARG(dim[0] >= 1 && dim[1] >= 1 && dim[2] >= 1, "dimensions must be >= 1");
+    MVSIM_CHECK_ARG(dim[0] <= 65535 * 4 && dim[1] <= 65535 && dim[2] <= 65535, "dimension too large for one launch");
+    return MVSIM_OK;
+}
+
+static int64_t nvox(const int64_t dim[3]) { return dim[0] * dim[1] * dim[2]; }
+
+static void ev_begin(mvsim_ctx* ctx, int st)
+{
+    if (ctx->timing) (void)hipEventRecord(ctx->ev[st][0], ctx->stream);
+}
+static void ev_end(mvsim_ctx* ctx, int st)
+{
+    if (ctx->timing) { (void)hipEventRecord(ctx->ev[st][1], ctx->stream); ctx->ev_used[st] = true; }
+}
+static void ev_reset(mvsim_ctx* ctx)
+{
+    for (int s = 0; s < ST_COUNT; ++s) ctx->ev_used[s] = false;
+}
+
+static int set_device(mvsim_ctx* ctx)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
+    MVSIM_HIP(hipSetDevice(ctx->device));
+    return MVSIM_OK;
+}
+
+// Normalise the PSF on the host exactly as Tools.normImage does (double sum, (float)(v/sum)),
+// in place (Q5), then place it in device memory.
+static int psf_prepare(mvsim_ctx* ctx, float* psf_host, const int64_t kdim[3], const int64_t dim[3])
+{
+    MVSIM_CHECK_ARG(psf_host != nullptr && kdim != nullptr, "psf is null");
+    MVSIM_CHECK_ARG(kdim[0] >= 1 && kdim[1] >= 1 && kdim[2] >= 1, "psf dimensions must be >= 1");
+    (void)dim;
+    const int64_t n = kdim[0] * kdim[1] * kdim[2];
+    // pairwise (cascade) double summation: same order of magnitude of error as mpicbg RealSum
+    double lvl[64]; bool used[64] = {};
+    for (int64_t i = 0; i < n; ++i) {
+        double s = (double)psf_host[i];
+        int l = 0;
+        while (used[l]) { used[l] = false; s += lvl[l]; ++l; }
+        used[l] = true; lvl[l] = s;
+    }
+    double sum = 0.0;
+    for (int l = 0; l < 64; ++l) if (used[l]) sum += lvl[l];
+    for (int64_t i = 0; i < n; ++i) psf_host[i] = (float)((double)psf_host[i] / sum);
+    MVSIM_TRY(ctx->psf_dev.reserve((size_t)n * sizeof(float)));
+    int slot = 0;
+    MVSIM_TRY(ctx->pinned.acquire((size_t)n * sizeof(float), &slot));
+    std::memcpy(ctx->pinned.p[slot], psf_host, (size_t)n * sizeof(float));
+    MVSIM_HIP(hipMemcpyAsync(ctx->psf_dev.p, ctx->pinned.p[slot], (size_t)n * sizeof(float), hipMemcpyHostToDevice,
+                             ctx->stream));
+    MVSIM_HIP(hipEventRecord(ctx->pinned.ev[slot], ctx->stream));
+    ctx->pinned.busy[slot] = true;
+    return MVSIM_OK;
+}
+
+static int pick_method(int method, const int64_t kdim[3])
+{
+    if (method == 1 || method == 2) return method;
+    // direct stencil costs 2*K^3 flop/voxel; break-even with the FFT path is around K ~ 7
+    return (kdim[0] * kdim[1] * kdim[2] <= 7 * 7 * 7) ? 2 : 1;
+}
+
+static int convolve_dev_impl(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const int64_t kdim[3],
+                             int method, float* out)
+{
+    MVSIM_CHECK_ARG(img != out, "convolve cannot run in place");
+    if (pick_method(method, kdim) == 2) {
+        ev_begin(ctx, ST_CONVOLVE);
+        MVSIM_TRY(launch_stencil(ctx->stream, img, dim, ctx->psf_dev.as<float>(), kdim, out));
+        ev_end(ctx, ST_CONVOLVE);
+        return MVSIM_OK;
+    }
+    return fft_convolve(ctx, img, dim, ctx->psf_dev.as<float>(), kdim, out, true);
+}
+
+static int scal_ptr(mvsim_ctx* ctx, double** partial, double** scal)
+{
+    MVSIM_TRY(ctx->partials.reserve((SUM_BLOCKS + 8) * sizeof(double)));
+    *partial = ctx->partials.as<double>();
+    *scal = *partial + SUM_BLOCKS;
+    return MVSIM_OK;
+}
+
+}  // namespace mvsim
+
+using namespace mvsim;
+
+extern "C" {
+
+const char* mvsim_version(void) { return "mvsim 0.1.0 (gfx950)"; }
+const char* mvsim_last_error(void) { return g_err; }
+
+int mvsim_device_count(int* count)
+{
+    MVSIM_CHECK_ARG(count != nullptr, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return MVSIM_ENODEV; }
+    *count = n;
+    return MVSIM_OK;
+}
+
+int mvsim_create(int device, mvsim_ctx** out)
+{
+    MVSIM_CHECK_ARG(out != nullptr, "ctx out pointer is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device available (libmvsim has no CPU fallback)");
+        return MVSIM_ENODEV;
+    }
+    MVSIM_CHECK_ARG(device >= 0 && device < n, "device index out of range");
+    MVSIM_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MVSIM_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libmvsim is built for gfx950 only", device, prop.gcnArchName);
+        return MVSIM_ENODEV;
+    }
+    mvsim_ctx* ctx = new (std::nothrow) mvsim_ctx();
+    if (!ctx) { set_error("out of host memory"); return MVSIM_ENOMEM; }
+    ctx->device = device;
+    ctx->num_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return MVSIM_EHIP; }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return MVSIM_OK;
+}
+
+int mvsim_destroy(mvsim_ctx* ctx)
+{
+    if (!ctx) return MVSIM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    mvsim_comm_destroy(ctx);
+    fft_release(ctx);
+    ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
+    ctx->psf_dev.release(); ctx->partials.release();
+    ctx->pinned.release_all();
+    if (ctx->ev_created)
+        for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(ctx->ev[s][0]); (void)hipEventDestroy(ctx->ev[s][1]); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MVSIM_OK;
+}
+
+int mvsim_set_stream(mvsim_ctx* ctx, void* hip_stream)
+{
+    MVSIM_TRY(set_device(ctx));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return MVSIM_OK;
+}
+
+int mvsim_synchronize(mvsim_ctx* ctx)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    return MVSIM_OK;
+}
+
+int mvsim_release_caches(mvsim_ctx* ctx)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    fft_release(ctx);
+    ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
+    return MVSIM_OK;
+}
+
+int mvsim_dev_alloc(mvsim_ctx* ctx, size_t bytes, void** dptr)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(dptr != nullptr, "dptr is null");
+    *dptr = nullptr;
+    if (bytes == 0) return MVSIM_OK;
+    MVSIM_HIP(hipMalloc(dptr, bytes));
+    return MVSIM_OK;
+}
+
+int mvsim_dev_free(mvsim_ctx* ctx, void* dptr)
+{
+    MVSIM_TRY(set_device(ctx));
+    if (dptr) MVSIM_HIP(hipFree(dptr));
+    return MVSIM_OK;
+}
+
+int mvsim_upload(mvsim_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
+{
+    MVSIM_TRY(set_device(ctx));
+    if (bytes == 0) return MVSIM_OK;
+    MVSIM_CHECK_ARG(dst_dev && src_host, "null pointer");
+    MVSIM_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    return MVSIM_OK;
+}
+
+int mvsim_download(mvsim_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes)
+{
+    MVSIM_TRY(set_device(ctx));
+    if (bytes == 0) return MVSIM_OK;
+    MVSIM_CHECK_ARG(dst_host && src_dev, "null pointer");
+    MVSIM_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    return MVSIM_OK;
+}
+
+// ---- host helpers ---------------------------------------------------------------------------------
+int mvsim_axis_rotation(const int64_t dim[3], int axis, int degrees, double m[12])
+{
+    MVSIM_CHECK_ARG(dim && m, "null pointer");
+    MVSIM_CHECK_ARG(axis >= 0 && axis <= 2, "axis must be 0, 1 or 2");
+    axis_rotation_host(dim, axis, degrees, m);
+    return MVSIM_OK;
+}
+
+int64_t mvsim_extract_nz(int64_t nz, int inc) { return inc < 1 ? -1 : (nz - 1) / inc + 1; }
+int64_t mvsim_isotropic_nz(int64_t nz_acq, int inc) { return inc < 1 ? -1 : (nz_acq - 1) * inc + 1; }
+double  mvsim_poisson_mul(double snr) { return std::pow(snr / std::sqrt(5.0), 2.0); }
+
+void mvsim_view_params_default(mvsim_view_params* p)
+{
+    if (!p) return;
+    p->axis = 0; p->degrees = 15; p->delta = 0.01; p->min_value = 0.0001f; p->target_average = 1.0f;
+    p->inc = 3; p->snr = 25.0f; p->seed = 464232194ULL; p->stream = 0; p->conv_method = 0;
+}
+
+// ---- device-resident stage operators --------------------------------------------------------------
+int mvsim_rotate_around_axis_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int axis, int degrees,
+                                 float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out && in != out, "null or aliased buffers");
+    MVSIM_CHECK_ARG(axis >= 0 && axis <= 2, "axis must be 0, 1 or 2");
+    double m[12];
+    Affine inv;
+    axis_rotation_host(dim, axis, degrees, m);
+    affine_invert_host(m, inv.m);
+    ev_begin(ctx, ST_ROTATE);
+    MVSIM_TRY(launch_rotate(ctx->stream, in, out, dim, inv));
+    ev_end(ctx, ST_ROTATE);
+    return MVSIM_OK;
+}
+
+int mvsim_attenuate3d_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], double delta, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out && in != out, "null or aliased buffers");
+    MVSIM_CHECK_ARG(dim[0] <= dim[1], "attenuate3d: Nx > Ny walks outside the interval in the reference (steps = dimension(0))");
+    ev_begin(ctx, ST_ATTENUATE);
+    MVSIM_TRY(launch_attenuate(ctx->stream, in, out, dim, delta));
+    ev_end(ctx, ST_ATTENUATE);
+    return MVSIM_OK;
+}
+
+int mvsim_convolve_dev(mvsim_ctx* ctx, const float* img, const int64_t dim[3], float* psf_host,
+                       const int64_t kdim[3], int method, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(img && out, "null buffer");
+    MVSIM_CHECK_ARG(method >= 0 && method <= 2, "method must be 0, 1 or 2");
+    MVSIM_TRY(psf_prepare(ctx, psf_host, kdim, dim));
+    return convolve_dev_impl(ctx, img, dim, kdim, method, out);
+}
+
+int mvsim_adjust_image_dev(mvsim_ctx* ctx, float* img, int64_t n, float min_value, float target_average,
+                           double* correction)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(img && n >= 1, "null buffer or empty image");
+    double *partial, *scal;
+    MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
+    ev_begin(ctx, ST_ADJUST);
+    MVSIM_TRY(launch_sum(ctx->stream, img, n, partial, scal));
+    MVSIM_TRY(launch_adjust_corr(ctx->stream, scal, n, min_value, target_average));
+    MVSIM_TRY(launch_adjust_apply(ctx->stream, img, n, scal, min_value));
+    ev_end(ctx, ST_ADJUST);
+    if (correction) {
+        MVSIM_HIP(hipMemcpyAsync(correction, scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MVSIM_OK;
+}
+
+int mvsim_extract_slices_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float snr,
+                             uint64_t seed, uint32_t stream, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out, "null buffer");
+    MVSIM_CHECK_ARG(inc >= 1, "inc must be >= 1");
+    const bool noise = snr >= 0.0f;   // SMVD:211
+    ev_begin(ctx, ST_EXTRACT);
+    MVSIM_TRY(launch_extract(ctx->stream, in, out, dim, inc, false, nullptr, 0.0f, noise,
+                             mvsim_poisson_mul((double)snr), seed, stream, 0));
+    ev_end(ctx, ST_EXTRACT);
+    return MVSIM_OK;
+}
+
+int mvsim_make_isotropic_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out, "null buffer");
+    MVSIM_CHECK_ARG(inc >= 1, "inc must be >= 1");
+    return launch_make_isotropic(ctx->stream, in, out, dim, inc);
+}
+
+int mvsim_compute_weight_image_dev(mvsim_ctx* ctx, const int64_t dim[3], float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(out, "null buffer");
+    return launch_weight_image(ctx->stream, out, dim);
+}
+
+// ---- fused per-view pipeline ------------------------------------------------------------------------
+int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host,
+                            const int64_t kdim[3], const mvsim_view_params* p, const mvsim_view_outputs* o,
+                            double* correction)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(gt && p && o, "null pointer");
+    MVSIM_CHECK_ARG(o->acq != nullptr, "outputs.acq is required");
+    MVSIM_CHECK_ARG(p->axis >= 0 && p->axis <= 2, "axis must be 0, 1 or 2");
+    MVSIM_CHECK_ARG(p->inc >= 1, "inc must be >= 1");
+    MVSIM_CHECK_ARG(p->conv_method >= 0 && p->conv_method <= 2, "conv_method must be 0, 1 or 2");
+    MVSIM_CHECK_ARG(dim[0] <= dim[1], "attenuate3d: Nx > Ny walks outside the interval in the reference");
+    const int64_t n = nvox(dim);
+    const size_t vbytes = (size_t)n * sizeof(float);
+    ev_reset(ctx);
+
+    float* rot = o->rot;
+    float* att = o->att;
+    float* con = o->con;
+    if (!rot) { MVSIM_TRY(ctx->vol_a.reserve(vbytes)); rot = ctx->vol_a.as<float>(); }
+    if (!att) { MVSIM_TRY(ctx->vol_b.reserve(vbytes)); att = ctx->vol_b.as<float>(); }
+    if (!con) con = rot == ctx->vol_a.as<float>() ? rot : nullptr;   // reuse the rot scratch for con
+    if (!con) { MVSIM_TRY(ctx->vol_c.reserve(vbytes)); con = ctx->vol_c.as<float>(); }
+
+    MVSIM_TRY(psf_prepare(ctx, psf_host, kdim, dim));
+
+    double m[12];
+    Affine inv;
+    axis_rotation_host(dim, p->axis, p->degrees, m);
+    affine_invert_host(m, inv.m);
+    ev_begin(ctx, ST_ROTATE);
+    MVSIM_TRY(launch_rotate(ctx->stream, gt, rot, dim, inv));
+    ev_end(ctx, ST_ROTATE);
+
+    ev_begin(ctx, ST_ATTENUATE);
+    MVSIM_TRY(launch_attenuate(ctx->stream, rot, att, dim, p->delta));
+    ev_end(ctx, ST_ATTENUATE);
+
+    double *partial, *scal;
+    MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
+    const int method = pick_method(p->conv_method, kdim);
+    MVSIM_TRY(convolve_dev_impl(ctx, att, dim, kdim, method, con));
+
+    ev_begin(ctx, ST_ADJUST);
+    if (method == 2) MVSIM_TRY(launch_sum(ctx->stream, con, n, partial, scal));   // FFT path sums in its crop epilogue
+    MVSIM_TRY(launch_adjust_corr(ctx->stream, scal, n, p->min_value, p->target_average));
+    const bool materialise = o->con != nullptr;
+    if (materialise) MVSIM_TRY(launch_adjust_apply(ctx->stream, con, n, scal, p->min_value));
+    ev_end(ctx, ST_ADJUST);
+
+    ev_begin(ctx, ST_EXTRACT);
+    const bool noise = p->snr >= 0.0f;
+    MVSIM_TRY(launch_extract(ctx->stream, con, o->acq, dim, p->inc, !materialise, scal, p->min_value, noise,
+                             mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0));
+    ev_end(ctx, ST_EXTRACT);
+
+    if (correction) {
+        MVSIM_HIP(hipMemcpyAsync(correction, scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MVSIM_OK;
+}
+
+// ---- host-buffer entry points (JNI boundary) ---------------------------------------------------------
+static int up(mvsim_ctx* ctx, DevBuf& b, const float* h, size_t bytes)
+{
+    MVSIM_TRY(b.reserve(bytes));
+    MVSIM_HIP(hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MVSIM_OK;
+}
+static int down(mvsim_ctx* ctx, float* h, const void* d, size_t bytes)
+{
+    MVSIM_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    return MVSIM_OK;
+}
+
+int mvsim_rotate_around_axis(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int axis, int degrees, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out, "null buffer");
+    const size_t bytes = (size_t)nvox(dim) * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, in, bytes));
+    MVSIM_TRY(ctx->vol_b.reserve(bytes));
+    MVSIM_TRY(mvsim_rotate_around_axis_dev(ctx, ctx->vol_a.as<float>(), dim, axis, degrees, ctx->vol_b.as<float>()));
+    return down(ctx, out, ctx->vol_b.p, bytes);
+}
+
+int mvsim_attenuate3d(mvsim_ctx* ctx, const float* in, const int64_t dim[3], double delta, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out, "null buffer");
+    const size_t bytes = (size_t)nvox(dim) * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, in, bytes));
+    MVSIM_TRY(ctx->vol_b.reserve(bytes));
+    MVSIM_TRY(mvsim_attenuate3d_dev(ctx, ctx->vol_a.as<float>(), dim, delta, ctx->vol_b.as<float>()));
+    return down(ctx, out, ctx->vol_b.p, bytes);
+}
+
+int mvsim_norm_image(mvsim_ctx* ctx, float* img, int64_t n)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(img && n >= 1, "null buffer or empty image");
+    const size_t bytes = (size_t)n * sizeof(float);
+    double *partial, *scal;
+    MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
+    MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
+    MVSIM_TRY(launch_sum(ctx->stream, ctx->vol_a.as<float>(), n, partial, scal));
+    MVSIM_TRY(launch_norm_apply(ctx->stream, ctx->vol_a.as<float>(), n, scal));
+    return down(ctx, img, ctx->vol_a.p, bytes);
+}
+
+int mvsim_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], float* psf, const int64_t kdim[3],
+                   int method, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(img && out, "null buffer");
+    const size_t bytes = (size_t)nvox(dim) * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
+    MVSIM_TRY(ctx->vol_b.reserve(bytes));
+    MVSIM_TRY(mvsim_convolve_dev(ctx, ctx->vol_a.as<float>(), dim, psf, kdim, method, ctx->vol_b.as<float>()));
+    return down(ctx, out, ctx->vol_b.p, bytes);
+}
+
+int mvsim_adjust_image(mvsim_ctx* ctx, float* img, int64_t n, float min_value, float target_average, double* correction)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(img && n >= 1, "null buffer or empty image");
+    const size_t bytes = (size_t)n * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
+    MVSIM_TRY(mvsim_adjust_image_dev(ctx, ctx->vol_a.as<float>(), n, min_value, target_average, correction));
+    return down(ctx, img, ctx->vol_a.p, bytes);
+}
+
+int mvsim_extract_slices(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float snr, uint64_t seed,
+                         uint32_t stream, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out, "null buffer");
+    MVSIM_CHECK_ARG(inc >= 1, "inc must be >= 1");
+    const size_t bytes = (size_t)nvox(dim) * sizeof(float);
+    const size_t obytes = (size_t)(dim[0] * dim[1] * mvsim_extract_nz(dim[2], inc)) * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, in, bytes));
+    MVSIM_TRY(ctx->out_buf.reserve(obytes));
+    MVSIM_TRY(mvsim_extract_slices_dev(ctx, ctx->vol_a.as<float>(), dim, inc, snr, seed, stream, ctx->out_buf.as<float>()));
+    return down(ctx, out, ctx->out_buf.p, obytes);
+}
+
+int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr, uint64_t seed, uint32_t stream,
+                          uint64_t index_offset)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(img && n >= 1, "null buffer or empty image");
+    const size_t bytes = (size_t)n * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
+    MVSIM_TRY(ctx->out_buf.reserve(bytes));
+    const int64_t dim[3] = {n, 1, 1};
+    ev_begin(ctx, ST_EXTRACT);
+    MVSIM_TRY(launch_extract(ctx->stream, ctx->vol_a.as<float>(), ctx->out_buf.as<float>(), dim, 1, false, nullptr,
+                             0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset));
+    ev_end(ctx, ST_EXTRACT);
+    return down(ctx, img, ctx->out_buf.p, bytes);
+}
+
+int mvsim_make_isotropic(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out, "null buffer");
+    MVSIM_CHECK_ARG(inc >= 1, "inc must be >= 1");
+    const size_t bytes = (size_t)nvox(dim) * sizeof(float);
+    const size_t obytes = (size_t)(dim[0] * dim[1] * mvsim_isotropic_nz(dim[2], inc)) * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, in, bytes));
+    MVSIM_TRY(ctx->out_buf.reserve(obytes));
+    MVSIM_TRY(mvsim_make_isotropic_dev(ctx, ctx->vol_a.as<float>(), dim, inc, ctx->out_buf.as<float>()));
+    return down(ctx, out, ctx->out_buf.p, obytes);
+}
+
+int mvsim_compute_weight_image(mvsim_ctx* ctx, const int64_t dim[3], float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(out, "null buffer");
+    const size_t bytes = (size_t)nvox(dim) * sizeof(float);
+    MVSIM_TRY(ctx->vol_a.reserve(bytes));
+    MVSIM_TRY(mvsim_compute_weight_image_dev(ctx, dim, ctx->vol_a.as<float>()));
+    return down(ctx, out, ctx->vol_a.p, bytes);
+}
+
+int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host, const int64_t kdim[3],
+                        const mvsim_view_params* p, const mvsim_view_outputs* o, double* correction)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(gt && p && o && o->acq, "null pointer (outputs.acq is required)");
+    MVSIM_CHECK_ARG(p->inc >= 1, "inc must be >= 1");
+    const int64_t n = nvox(dim);
+    const size_t vbytes = (size_t)n * sizeof(float);
+    const size_t obytes = (size_t)(dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc)) * sizeof(float);
+    // ground truth goes to its own buffer; requested intermediates get device twins
+    DevBuf gt_d, rot_d, att_d, con_d;
+    int rc = up(ctx, gt_d, gt, vbytes);
+    mvsim_view_outputs dev = {nullptr, nullptr, nullptr, nullptr};
+    if (rc == MVSIM_OK && o->rot) { rc = rot_d.reserve(vbytes); dev.rot = rot_d.as<float>(); }
+    if (rc == MVSIM_OK && o->att) { rc = att_d.reserve(vbytes); dev.att = att_d.as<float>(); }
+    if (rc == MVSIM_OK && o->con) { rc = con_d.reserve(vbytes); dev.con = con_d.as<float>(); }
+    if (rc == MVSIM_OK) rc = ctx->out_buf.reserve(obytes);
+    dev.acq = ctx->out_buf.as<float>();
+    if (rc == MVSIM_OK) rc = mvsim_simulate_view_dev(ctx, gt_d.as<float>(), dim, psf_host, kdim, p, &dev, correction);
+    if (rc == MVSIM_OK && o->rot) rc = down(ctx, o->rot, dev.rot, vbytes);
+    if (rc == MVSIM_OK && o->att) rc = down(ctx, o->att, dev.att, vbytes);
+    if (rc == MVSIM_OK && o->con) rc = down(ctx, o->con, dev.con, vbytes);
+    if (rc == MVSIM_OK) rc = down(ctx, o->acq, dev.acq, obytes);
+    (void)hipStreamSynchronize(ctx->stream);
+    gt_d.release(); rot_d.release(); att_d.release(); con_d.release();
+    return rc;
+}
+
+// ---- timings ---------------------------------------------------------------------------------------
+int mvsim_enable_timing(mvsim_ctx* ctx, int enable)
+{
+    MVSIM_TRY(set_device(ctx));
+    if (enable && !ctx->ev_created) {
+        for (int s = 0; s < ST_COUNT; ++s) {
+            MVSIM_HIP(hipEventCreate(&ctx->ev[s][0]));
+            MVSIM_HIP(hipEventCreate(&ctx->ev[s][1]));
+        }
+        ctx->ev_created = true;
+    }
+    ctx->timing = enable != 0;
+    ev_reset(ctx);
+    return MVSIM_OK;
+}
+
+int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(t != nullptr, "timings pointer is null");
+    MVSIM_CHECK_ARG(ctx->ev_created, "timing was never enabled");
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    float ms[ST_COUNT] = {};
+    float total = 0.f;
+    for (int s = 0; s < ST_COUNT; ++s) {
+        if (!ctx->ev_used[s]) continue;
+        MVSIM_HIP(hipEventElapsedTime(&ms[s], ctx->ev[s][0], ctx->ev[s][1]));
+        total += ms[s];
+    }
+    t->rotate_ms = ms[ST_ROTATE]; t->attenuate_ms = ms[ST_ATTENUATE]; t->psf_ms = ms[ST_PSF];
+    t->convolve_ms = ms[ST_CONVOLVE]; t->adjust_ms = ms[ST_ADJUST]; t->extract_ms = ms[ST_EXTRACT];
+    t->total_ms = total;
+    ctx->last = *t;
+    return MVSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// Internal declarations shared by the libmvsim translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mvsim.h"
+
+namespace mvsim {
+
+void set_error(const char* fmt, ...);
+
+#define MVSIM_HIP(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            mvsim::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                             __LINE__);                                                         \
+            return (e_ == hipErrorOutOfMemory) ? MVSIM_ENOMEM : MVSIM_EHIP;                     \
+        }                                                                                       \
+    } while (0)
+
+#define MVSIM_FFT(expr)                                                                         \
+    do {                                                                                        \
+        rocfft_status s_ = (expr);                                                              \
+        if (s_ != rocfft_status_success) {                                                      \
+            mvsim::set_error("%s failed: rocfft status %d (%s:%d)", #expr, (int)s_, __FILE__,   \
+                             __LINE__);                                                         \
+            return MVSIM_EFFT;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+#define MVSIM_TRY(expr)                                                                         \
+    do {                                                                                        \
+        int rc_ = (expr);                                                                       \
+        if (rc_ != MVSIM_OK) return rc_;                                                        \
+    } while (0)
+
+#define MVSIM_CHECK_ARG(cond, msg)                                                              \
+    do {                                                                                        \
+        if (!(cond)) {                                                                          \
+            mvsim::set_error("invalid argument: %s", msg);                                      \
+            return MVSIM_EINVAL;                                                                \
+        }                                                                                       \
+    } while (0)
+
+// Grow-only device buffer (steady state: no hipMalloc on the hot path).
+struct DevBuf {
+    void*  p     = nullptr;
+    size_t bytes = 0;
+    int    reserve(size_t need);
+    void   release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Affine {
+    double m[12];
+};
+
+struct FftPlan {
+    int64_t      P[3]      = {0, 0, 0};
+    rocfft_plan  fwd       = nullptr;   // real P^3 -> complex (Px/2+1) Py Pz
+    rocfft_plan  inv       = nullptr;   // complex -> real
+    rocfft_execution_info info = nullptr;
+    size_t       work_bytes = 0;
+};
+
+// Small ring of pinned host buffers for asynchronous H2D copies of PSFs (the caller's buffer may be
+// pageable and may be reused as soon as the call returns).
+struct PinnedRing {
+    static constexpr int SLOTS = 4;
+    void*      p[SLOTS]     = {};
+    size_t     bytes[SLOTS] = {};
+    hipEvent_t ev[SLOTS]    = {};
+    bool       busy[SLOTS]  = {};
+    int        next         = 0;
+    int  acquire(size_t need, int* slot);   // waits for the slot's previous copy if still in flight
+    void release_all();
+};
+
+enum Stage { ST_ROTATE = 0, ST_ATTENUATE, ST_PSF, ST_CONVOLVE, ST_ADJUST, ST_EXTRACT, ST_COUNT };
+
+}  // namespace mvsim
+
+struct mvsim_ctx {
+    int         device     = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream     = nullptr;
+    int         num_cu     = 256;
+
+    // workspaces
+    mvsim::DevBuf vol_a, vol_b, vol_c;      // N-sized float staging for host entry points / fused path
+    mvsim::DevBuf out_buf;                  // extract output staging
+    mvsim::DevBuf psf_dev;                  // K^3 floats
+    mvsim::PinnedRing pinned;
+    mvsim::DevBuf fft_real;                 // P^3 floats
+    mvsim::DevBuf fft_spec_img, fft_spec_psf;
+    mvsim::DevBuf fft_work;
+    mvsim::DevBuf partials;                 // doubles: block partial sums + [sum, corr]
+    std::map<std::string, mvsim::FftPlan> plans;
+    bool   fft_ready = false;
+
+    // timing
+    bool       timing = false;
+    hipEvent_t ev[mvsim::ST_COUNT][2] = {};
+    bool       ev_used[mvsim::ST_COUNT] = {};
+    bool       ev_created = false;
+    mvsim_timings last = {};
+
+    // RCCL
+    void* comm = nullptr;
+    int   nranks = 1, rank = 0;
+};
+
+namespace mvsim {
+
+// ---- kernel launchers (each enqueues on `s`, returns MVSIM_* status) ----------------------------
+int launch_rotate(hipStream_t s, const float* in, float* out, const int64_t dim[3], const Affine& inv);
+int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta);
+// sum -> scal[0]; partial workspace must hold >= SUM_BLOCKS doubles
+constexpr int SUM_BLOCKS = 2048;
+int launch_sum(hipStream_t s, const float* in, int64_t n, double* partial, double* scal);
+// scal[1] = (double)(target - min) / (scal[0] / n)
+int launch_adjust_corr(hipStream_t s, double* scal, int64_t n, float min_value, float target);
+int launch_adjust_apply(hipStream_t s, float* img, int64_t n, const double* scal, float min_value);
+int launch_norm_apply(hipStream_t s, float* img, int64_t n, const double* scal);
+// extract (+ optional adjust using scal[1]) (+ optional Poisson).  in: Nx*Ny*Nz, out: Nx*Ny*nzo
+int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
+                   const double* scal, float min_value, bool noise, double mul, uint64_t seed,
+                   uint32_t stream, uint64_t index_offset);
+int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc);
+int launch_weight_image(hipStream_t s, float* out, const int64_t dim[3]);
+
+// FFT convolution pieces
+int launch_pad_mirror(hipStream_t s, const float* img, const int64_t dim[3], const int64_t kdim[3],
+                      float* padded, const int64_t P[3]);
+int launch_psf_embed(hipStream_t s, const float* psf, const int64_t kdim[3], float* padded, const int64_t P[3]);
+int launch_cmul(hipStream_t s, float2* f, const float2* g, int64_t n);
+// out = crop(real) * scale; also accumulates block partial sums -> partial (SUM_BLOCKS doubles) and scal[0]
+int launch_crop_scale_sum(hipStream_t s, const float* real, const int64_t P[3], float* out,
+                          const int64_t dim[3], float scale, double* partial, double* scal);
+int launch_stencil(hipStream_t s, const float* img, const int64_t dim[3], const float* psf,
+                   const int64_t kdim[3], float* out);
+
+int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,
+                 const int64_t kdim[3], float* out_dev, bool want_sum);
+void fft_release(mvsim_ctx* ctx);
+void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3]);
+
+void axis_rotation_host(const int64_t dim[3], int axis, int degrees, double m[12]);
+void affine_invert_host(const double m[12], double inv[12]);
+
+}  // namespace mvsim

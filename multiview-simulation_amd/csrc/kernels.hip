@@ -1,0 +1,411 @@
+// Streaming kernels of the per-view path (gfx950, wave64): rotate, attenuate, sum/adjust,
+// slice extraction + Poisson, makeIsotropic, weight image.  All are HBM-bound; design notes and
+// algorithmic bytes per voxel are in DESIGN.md.
+#include "common.h"
+#include "poisson_dev.h"
+
+namespace mvsim {
+
+// ------------------------------------------------------------------------------------------------
+// rotateAroundAxis (SimulateMultiViewDataset.java:104-135)
+// out[l] = trilinear(in zero-extended, Minv * l); ImgLib2 NLinearInterpolator arithmetic: weights
+// in double, each tap rounded (float)(v * w), float accumulation in Gray-code tap order.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tap0(const float* __restrict__ in, int nx, int ny, int nz, long long x,
+                                      long long y, long long z)
+{
+    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.0f;
+    return in[x + (long long)nx * (y + (long long)ny * z)];
+}
+
+__global__ __launch_bounds__(256) void k_rotate_generic(const float* __restrict__ in, float* __restrict__ out,
+                                                        int nx, int ny, int nz, Affine a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int z = blockIdx.z;
+    if (x >= nx) return;
+    const double l0 = (double)x, l1 = (double)y, l2 = (double)z;
+    const double px = l0 * a.m[0] + l1 * a.m[1] + l2 * a.m[2] + a.m[3];
+    const double py = l0 * a.m[4] + l1 * a.m[5] + l2 * a.m[6] + a.m[7];
+    const double pz = l0 * a.m[8] + l1 * a.m[9] + l2 * a.m[10] + a.m[11];
+    const double fx = floor(px), fy = floor(py), fz = floor(pz);
+    float acc = 0.0f;
+    // whole 2x2x2 support outside the volume -> exact zero (also keeps the long long casts safe)
+    if (fx >= -1.0 && fy >= -1.0 && fz >= -1.0 && fx < (double)nx && fy < (double)ny && fz < (double)nz) {
+        const long long sx = (long long)fx, sy = (long long)fy, sz = (long long)fz;
+        const double w0 = px - fx, w1 = py - fy, w2 = pz - fz;
+        const double w0n = 1.0 - w0, w1n = 1.0 - w1, w2n = 1.0 - w2;
+        acc = (float)((double)tap0(in, nx, ny, nz, sx, sy, sz) * (w0n * w1n * w2n));
+        acc += (float)((double)tap0(in, nx, ny, nz, sx + 1, sy, sz) * (w0 * w1n * w2n));
+        acc += (float)((double)tap0(in, nx, ny, nz, sx + 1, sy + 1, sz) * (w0 * w1 * w2n));
+        acc += (float)((double)tap0(in, nx, ny, nz, sx, sy + 1, sz) * (w0n * w1 * w2n));
+        acc += (float)((double)tap0(in, nx, ny, nz, sx, sy + 1, sz + 1) * (w0n * w1 * w2));
+        acc += (float)((double)tap0(in, nx, ny, nz, sx + 1, sy + 1, sz + 1) * (w0 * w1 * w2));
+        acc += (float)((double)tap0(in, nx, ny, nz, sx + 1, sy, sz + 1) * (w0 * w1n * w2));
+        acc += (float)((double)tap0(in, nx, ny, nz, sx, sy, sz + 1) * (w0n * w1n * w2));
+    }
+    out[x + (long long)nx * (y + (long long)ny * z)] = acc;
+}
+
+// Rotation about x (the only axis SimulateMultiViewDataset.main uses, :557,:570,:591): the inverse
+// model has row 0 = (1,0,0,0) exactly, so an output x-row reads 4 source rows at the same x with
+// wave-uniform weights.  4 voxels per lane, 16-B loads/stores.
+__global__ __launch_bounds__(128) void k_rotate_axis0_v4(const float* __restrict__ in, float* __restrict__ out,
+                                                         int nx, int ny, int nz, Affine a)
+{
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    const int z = blockIdx.z;
+    if (x4 >= nx) return;
+    const double l1 = (double)y, l2 = (double)z;
+    // l0 * m4 with m4 == 0 contributes +0 exactly; keep the reference's evaluation order
+    const double py = 0.0 * a.m[4] + l1 * a.m[5] + l2 * a.m[6] + a.m[7];
+    const double pz = 0.0 * a.m[8] + l1 * a.m[9] + l2 * a.m[10] + a.m[11];
+    const double fy = floor(py), fz = floor(pz);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fy >= -1.0 && fz >= -1.0 && fy < (double)ny && fz < (double)nz) {
+        const int sy = (int)fy, sz = (int)fz;
+        const double w1 = py - fy, w2 = pz - fz;
+        const double w1n = 1.0 - w1, w2n = 1.0 - w2;
+        const double w00 = 1.0 * w1n * w2n, w10 = 1.0 * w1 * w2n, w11 = 1.0 * w1 * w2, w01 = 1.0 * w1n * w2;
+        const bool y0 = sy >= 0, y1 = sy + 1 < ny, z0 = sz >= 0, z1 = sz + 1 < nz;
+        const long long row = (long long)nx;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v00 = (y0 && z0) ? *reinterpret_cast<const float4*>(in + x4 + row * (sy + (long long)ny * sz)) : zero;
+        const float4 v10 = (y1 && z0) ? *reinterpret_cast<const float4*>(in + x4 + row * (sy + 1 + (long long)ny * sz)) : zero;
+        const float4 v11 = (y1 && z1) ? *reinterpret_cast<const float4*>(in + x4 + row * (sy + 1 + (long long)ny * (sz + 1))) : zero;
+        const float4 v01 = (y0 && z1) ? *reinterpret_cast<const float4*>(in + x4 + row * (sy + (long long)ny * (sz + 1))) : zero;
+#define MVSIM_BLEND(c)                                   \
+        r.c = (float)((double)v00.c * w00);              \
+        r.c += (float)((double)v10.c * w10);             \
+        r.c += (float)((double)v11.c * w11);             \
+        r.c += (float)((double)v01.c * w01);
+        MVSIM_BLEND(x) MVSIM_BLEND(y) MVSIM_BLEND(z) MVSIM_BLEND(w)
+#undef MVSIM_BLEND
+    }
+    *reinterpret_cast<float4*>(out + x4 + (long long)nx * (y + (long long)ny * z)) = r;
+}
+
+int launch_rotate(hipStream_t s, const float* in, float* out, const int64_t dim[3], const Affine& inv)
+{
+    const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
+    const bool x_identity = inv.m[0] == 1.0 && inv.m[1] == 0.0 && inv.m[2] == 0.0 && inv.m[3] == 0.0 &&
+                            inv.m[4] == 0.0 && inv.m[8] == 0.0;
+    const bool aligned = (nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    if (x_identity && aligned) {
+        const int threads = 128;
+        dim3 grid((nx / 4 + threads - 1) / threads, ny, nz);
+        hipLaunchKernelGGL(k_rotate_axis0_v4, grid, dim3(threads), 0, s, in, out, nx, ny, nz, inv);
+    } else {
+        const int threads = 256;
+        dim3 grid((nx + threads - 1) / threads, ny, nz);
+        hipLaunchKernelGGL(k_rotate_generic, grid, dim3(threads), 0, s, in, out, nx, ny, nz, inv);
+    }
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// attenuate3d (SimulateMultiViewDataset.java:318-364).  One (x,z) column per lane, lanes along x
+// (coalesced 256-B rows per wave per y step), serial fp64 recurrence from y = Ny-1 downwards:
+//   phi = v*delta*n ; n = max(n - phi, 0) ; out = (float)(v*n)
+// `steps` = Nx (the reference loops dimension(0) times, Q1); rows below stay zero.
+// ------------------------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(64) void k_attenuate(const float* __restrict__ in, float* __restrict__ out, int nx,
+                                                  int ny, int steps, double delta)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int z = blockIdx.y;
+    if (x >= nx) return;
+    const long long plane = (long long)nx * ny;
+    const float* __restrict__ pin = in + plane * z + x;
+    float* __restrict__ pout = out + plane * z + x;
+    double n = 1.0;
+    int y = ny - 1;
+    int left = steps;
+    while (left >= U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = pin[(long long)(y - u) * nx];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double dv = (double)v[u];
+            const double phi = dv * delta * n;
+            n = fmax(n - phi, 0.0);
+            pout[(long long)(y - u) * nx] = (float)(dv * n);
+        }
+        y -= U;
+        left -= U;
+    }
+    for (; left > 0; --left, --y) {
+        const double dv = (double)pin[(long long)y * nx];
+        const double phi = dv * delta * n;
+        n = fmax(n - phi, 0.0);
+        pout[(long long)y * nx] = (float)(dv * n);
+    }
+    for (; y >= 0; --y) pout[(long long)y * nx] = 0.0f;
+}
+
+int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta)
+{
+    const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
+    dim3 grid((nx + 63) / 64, nz);
+    hipLaunchKernelGGL(k_attenuate<16>, grid, dim3(64), 0, s, in, out, nx, ny, nx, delta);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sum (Tools.sumImage, Tools.java:124-132; mpicbg RealSum ~ exact-to-double): per-thread double
+// accumulation, wave shuffle + LDS block tree, fixed-order final pass => deterministic.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum_256(double v)
+{
+    __shared__ double sh[4];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) sh[wid] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    __syncthreads();
+    return r;  // valid in thread 0
+}
+
+__global__ __launch_bounds__(256) void k_sum_partial(const float* __restrict__ in, long long n,
+                                                     double* __restrict__ partial)
+{
+    double acc = 0.0;
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * 256;
+    const long long n4 = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) ? (n >> 2) : 0;
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    for (long long i = tid; i < n4; i += nthreads) {
+        const float4 v = in4[i];
+        acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
+    for (long long i = (n4 << 2) + tid; i < n; i += nthreads) acc += (double)in[i];
+    const double b = block_sum_256(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = b;
+}
+
+__global__ __launch_bounds__(256) void k_sum_final(const double* __restrict__ partial, int count,
+                                                   double* __restrict__ scal)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) acc += partial[i];
+    const double b = block_sum_256(acc);
+    if (threadIdx.x == 0) scal[0] = b;
+}
+
+int launch_sum(hipStream_t s, const float* in, int64_t n, double* partial, double* scal)
+{
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > SUM_BLOCKS) blocks = SUM_BLOCKS;
+    hipLaunchKernelGGL(k_sum_partial, dim3(blocks), dim3(256), 0, s, in, (long long)n, partial);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, partial, blocks, scal);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// adjustImage (Tools.java:143-159): corr = (double)(target - min) / (sum / n)
+__global__ void k_adjust_corr(double* scal, long long n, float min_value, float target)
+{
+    const double avg = scal[0] / (double)n;
+    scal[1] = (double)(target - min_value) / avg;
+}
+
+int launch_adjust_corr(hipStream_t s, double* scal, int64_t n, float min_value, float target)
+{
+    hipLaunchKernelGGL(k_adjust_corr, dim3(1), dim3(1), 0, s, scal, (long long)n, min_value, target);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+__device__ __forceinline__ float adjust_one(float v, double corr, float min_value)
+{
+    const float t = (float)((double)v * corr);  // pass 1, Tools.java:150-151
+    return t + min_value;                       // pass 2, Tools.java:154-155 (second rounding, Q6)
+}
+
+__global__ __launch_bounds__(256) void k_adjust_apply(float* __restrict__ img, long long n,
+                                                      const double* __restrict__ scal, float min_value)
+{
+    const double corr = scal[1];
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * 256;
+    const long long n4 = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) ? (n >> 2) : 0;
+    float4* img4 = reinterpret_cast<float4*>(img);
+    for (long long i = tid; i < n4; i += nthreads) {
+        float4 v = img4[i];
+        v.x = adjust_one(v.x, corr, min_value);
+        v.y = adjust_one(v.y, corr, min_value);
+        v.z = adjust_one(v.z, corr, min_value);
+        v.w = adjust_one(v.w, corr, min_value);
+        img4[i] = v;
+    }
+    for (long long i = (n4 << 2) + tid; i < n; i += nthreads) img[i] = adjust_one(img[i], corr, min_value);
+}
+
+int launch_adjust_apply(hipStream_t s, float* img, int64_t n, const double* scal, float min_value)
+{
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_adjust_apply, dim3(blocks), dim3(256), 0, s, img, (long long)n, scal, min_value);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// normImage (Tools.java:112-118): img <- (float)((double)img / sum)
+__global__ __launch_bounds__(256) void k_norm_apply(float* __restrict__ img, long long n,
+                                                    const double* __restrict__ scal)
+{
+    const double sum = scal[0];
+    const long long nthreads = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += nthreads)
+        img[i] = (float)((double)img[i] / sum);
+}
+
+int launch_norm_apply(hipStream_t s, float* img, int64_t n, const double* scal)
+{
+    int blocks = (int)((n + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_norm_apply, dim3(blocks), dim3(256), 0, s, img, (long long)n, scal);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// extractSlices + adjust + Poisson (SimulateMultiViewDataset.java:195-251, Tools.java:73-86):
+// out[x,y,k] = f(in[x,y,k*inc]);  ADJUST applies the two adjustImage passes on the fly (fused
+// path: the scaled volume is never materialised); NOISE draws Poisson((double)v * mul).
+// ------------------------------------------------------------------------------------------------
+template <bool ADJUST, bool NOISE>
+__global__ __launch_bounds__(256) void k_extract(const float* __restrict__ in, float* __restrict__ out,
+                                                 long long plane, long long nzo, int inc,
+                                                 const double* __restrict__ scal, float min_value, double mul,
+                                                 uint32_t k0, uint32_t k1, uint32_t stream,
+                                                 unsigned long long index_offset)
+{
+    double corr = 1.0;
+    if (ADJUST) corr = scal[1];
+    const long long total = plane * nzo;
+    const long long nthreads = (long long)gridDim.x * 256;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += nthreads) {
+        const long long k = o / plane;
+        const long long i = o - k * plane;
+        const long long src = k * inc * plane + i;
+        float v = in[src];
+        if (ADJUST) v = adjust_one(v, corr, min_value);
+        if (NOISE) v = poisson_counter((double)v * mul, k0, k1, stream, index_offset + (unsigned long long)src);
+        out[o] = v;
+    }
+}
+
+int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
+                   const double* scal, float min_value, bool noise, double mul, uint64_t seed,
+                   uint32_t stream, uint64_t index_offset)
+{
+    const long long plane = (long long)dim[0] * dim[1];
+    const long long nzo = (dim[2] - 1) / inc + 1;
+    const long long total = plane * nzo;
+    long long want = (total + 255) / 256;
+    int blocks = (int)(want < 1 ? 1 : (want > 256 * 32 ? 256 * 32 : want));
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#define MVSIM_LAUNCH_EX(A, N)                                                                             \
+    hipLaunchKernelGGL((k_extract<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane, nzo, inc, scal, \
+                       min_value, mul, k0, k1, stream, (unsigned long long)index_offset)
+    if (adjust && noise) MVSIM_LAUNCH_EX(true, true);
+    else if (adjust) MVSIM_LAUNCH_EX(true, false);
+    else if (noise) MVSIM_LAUNCH_EX(false, true);
+    else MVSIM_LAUNCH_EX(false, false);
+#undef MVSIM_LAUNCH_EX
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// makeIsotropic (SimulateMultiViewDataset.java:144-171): z = (float)l / (float)inc (Q4), x and y
+// integral => the 8-tap interpolator degenerates to two planes (weights of the x+1 / y+1 taps
+// are exactly 0); mirror-single extension along z.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long mirror1(long long i, long long n)
+{
+    if (n == 1) return 0;
+    const long long p = 2 * n - 2;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - i;
+}
+
+__global__ __launch_bounds__(256) void k_make_isotropic(const float* __restrict__ in, float* __restrict__ out,
+                                                        long long plane, long long nz, long long onz, int inc)
+{
+    const long long total = plane * onz;
+    const long long nthreads = (long long)gridDim.x * 256;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += nthreads) {
+        const long long z = o / plane;
+        const long long i = o - z * plane;
+        const double pz = (double)((float)z / (float)inc);
+        const double fz = floor(pz);
+        const double w2 = pz - fz, w2n = 1.0 - w2;
+        const long long z0 = mirror1((long long)fz, nz), z1 = mirror1((long long)fz + 1, nz);
+        // tap order 000 ... 001: only 000 (w = 1*1*w2n) and 001 (w = 1*1*w2) carry weight
+        float acc = (float)((double)in[z0 * plane + i] * (1.0 * 1.0 * w2n));
+        acc += (float)((double)in[z1 * plane + i] * (1.0 * 1.0 * w2));
+        out[o] = acc;
+    }
+}
+
+int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc)
+{
+    const long long plane = (long long)dim[0] * dim[1];
+    const long long onz = (dim[2] - 1) * inc + 1;
+    long long want = (plane * onz + 255) / 256;
+    int blocks = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+    hipLaunchKernelGGL(k_make_isotropic, dim3(blocks), dim3(256), 0, s, in, out, plane, (long long)dim[2], onz, inc);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// computeWeightImage (SimulateMultiViewDataset.java:280-316): cosine ramp along y.
+__global__ __launch_bounds__(256) void k_weight_image(float* __restrict__ out, int nx, int ny, long long total)
+{
+    const long long nthreads = (long long)gridDim.x * 256;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += nthreads) {
+        const int y = (int)((o / nx) % ny);
+        const int l = ny - y - 1;
+        float value;
+        if (l < ny / 2) value = 1.0f;
+        else if (l > ny / 2 + 40) value = 0.0f;
+        else {
+            const double pos = ((double)(l - ny / 2) / 40.0) * 3.141592653589793;
+            value = (float)((cos(pos) + 1.0) / 2.0);
+        }
+        out[o] = value;
+    }
+}
+
+int launch_weight_image(hipStream_t s, float* out, const int64_t dim[3])
+{
+    const long long total = (long long)dim[0] * dim[1] * dim[2];
+    long long want = (total + 255) / 256;
+    int blocks = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+    hipLaunchKernelGGL(k_weight_image, dim3(blocks), dim3(256), 0, s, out, (int)dim[0], (int)dim[1], total);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+}  // namespace mvsim
