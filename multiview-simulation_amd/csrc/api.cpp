@@ -260,7 +260,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     mvsim_comm_destroy(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->psf_dev.release(); ctx->partials.release();
+    ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
         for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(ctx->ev[s][0]); (void)hipEventDestroy(ctx->ev[s][1]); }

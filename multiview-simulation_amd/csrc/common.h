@@ -104,6 +104,10 @@ struct mvsim_ctx {
     mvsim::DevBuf fft_spec_img, fft_spec_psf;
     mvsim::DevBuf fft_work;
     mvsim::DevBuf partials;                 // doubles: block partial sums + [sum, corr]
+    mvsim::DevBuf partials_e;               // per-block sums of the c2r/crop pass
+    mvsim::DevBuf cfft_f, cfft_g;           // custom FFT: image / PSF half spectra [Pz][Py][Hxp]
+    mvsim::DevBuf cfft_g1, cfft_g2;         // compact PSF intermediates [Kz][Ky][Hxp], [Kz][Py][Hxp]
+    std::map<int, void*> twiddles;          // length -> device table exp(-2 pi i k / L), k = 0..L
     std::map<std::string, mvsim::FftPlan> plans;
     bool   fft_ready = false;
 
@@ -153,6 +157,11 @@ int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], con
                  const int64_t kdim[3], float* out_dev, bool want_sum);
 void fft_release(mvsim_ctx* ctx);
 void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3]);
+// hand-written LDS FFT path (fft_kernels.hip)
+bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3]);
+int  custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
+                         const int64_t kdim[3], const int64_t P[3], float* out);
+void custom_fft_release(mvsim_ctx* ctx);
 
 void axis_rotation_host(const int64_t dim[3], int axis, int degrees, double m[12]);
 void affine_invert_host(const double m[12], double inv[12]);

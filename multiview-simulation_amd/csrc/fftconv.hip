@@ -248,6 +248,7 @@ void fft_release(mvsim_ctx* ctx)
     ctx->fft_spec_img.release();
     ctx->fft_spec_psf.release();
     ctx->fft_work.release();
+    custom_fft_release(ctx);
 }
 
 static void ev_begin(mvsim_ctx* ctx, int st)
@@ -263,6 +264,7 @@ int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], con
                  const int64_t kdim[3], float* out_dev, bool want_sum)
 {
     int64_t P[3];
+    if (custom_fft_sizes(dim, kdim, P)) return custom_fft_convolve(ctx, img_dev, dim, psf_dev, kdim, P, out_dev);
     choose_padded(dim, kdim, P);
     FftPlan* pl = nullptr;
     MVSIM_TRY(get_plan(ctx, P, &pl));

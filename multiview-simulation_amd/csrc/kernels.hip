@@ -50,41 +50,57 @@ __global__ __launch_bounds__(256) void k_rotate_generic(const float* __restrict_
 
 // Rotation about x (the only axis SimulateMultiViewDataset.main uses, :557,:570,:591): the inverse
 // model has row 0 = (1,0,0,0) exactly, so an output x-row reads 4 source rows at the same x with
-// wave-uniform weights.  4 voxels per lane, 16-B loads/stores.
+// wave-uniform weights.  4 voxels per lane (16-B loads/stores), ROT_ROWS consecutive output rows per
+// block with all 4*ROT_ROWS row loads issued before the first blend.
+constexpr int ROT_ROWS = 4;
+
 __global__ __launch_bounds__(128) void k_rotate_axis0_v4(const float* __restrict__ in, float* __restrict__ out,
                                                          int nx, int ny, int nz, Affine a)
 {
     const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int y = blockIdx.y;
+    const int y0 = blockIdx.y * ROT_ROWS;
     const int z = blockIdx.z;
     if (x4 >= nx) return;
-    const double l1 = (double)y, l2 = (double)z;
-    // l0 * m4 with m4 == 0 contributes +0 exactly; keep the reference's evaluation order
-    const double py = 0.0 * a.m[4] + l1 * a.m[5] + l2 * a.m[6] + a.m[7];
-    const double pz = 0.0 * a.m[8] + l1 * a.m[9] + l2 * a.m[10] + a.m[11];
-    const double fy = floor(py), fz = floor(pz);
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (fy >= -1.0 && fz >= -1.0 && fy < (double)ny && fz < (double)nz) {
-        const int sy = (int)fy, sz = (int)fz;
-        const double w1 = py - fy, w2 = pz - fz;
-        const double w1n = 1.0 - w1, w2n = 1.0 - w2;
-        const double w00 = 1.0 * w1n * w2n, w10 = 1.0 * w1 * w2n, w11 = 1.0 * w1 * w2, w01 = 1.0 * w1n * w2;
-        const bool y0 = sy >= 0, y1 = sy + 1 < ny, z0 = sz >= 0, z1 = sz + 1 < nz;
-        const long long row = (long long)nx;
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 v00 = (y0 && z0) ? *reinterpret_cast<const float4*>(in + x4 + row * (sy + (long long)ny * sz)) : zero;
-        const float4 v10 = (y1 && z0) ? *reinterpret_cast<const float4*>(in + x4 + row * (sy + 1 + (long long)ny * sz)) : zero;
-        const float4 v11 = (y1 && z1) ? *reinterpret_cast<const float4*>(in + x4 + row * (sy + 1 + (long long)ny * (sz + 1))) : zero;
-        const float4 v01 = (y0 && z1) ? *reinterpret_cast<const float4*>(in + x4 + row * (sy + (long long)ny * (sz + 1))) : zero;
-#define MVSIM_BLEND(c)                                   \
-        r.c = (float)((double)v00.c * w00);              \
-        r.c += (float)((double)v10.c * w10);             \
-        r.c += (float)((double)v11.c * w11);             \
-        r.c += (float)((double)v01.c * w01);
+    const long long row = (long long)nx;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v00[ROT_ROWS], v10[ROT_ROWS], v11[ROT_ROWS], v01[ROT_ROWS];
+    double w00[ROT_ROWS], w10[ROT_ROWS], w11[ROT_ROWS], w01[ROT_ROWS];
+#pragma unroll
+    for (int r = 0; r < ROT_ROWS; ++r) {
+        const int y = y0 + r;
+        const double l1 = (double)y, l2 = (double)z;
+        // l0 * m4 with m4 == 0 contributes +0 exactly; keep the reference's evaluation order
+        const double py = 0.0 * a.m[4] + l1 * a.m[5] + l2 * a.m[6] + a.m[7];
+        const double pz = 0.0 * a.m[8] + l1 * a.m[9] + l2 * a.m[10] + a.m[11];
+        const double fy = floor(py), fz = floor(pz);
+        v00[r] = v10[r] = v11[r] = v01[r] = zero;
+        w00[r] = w10[r] = w11[r] = w01[r] = 0.0;
+        if (y < ny && fy >= -1.0 && fz >= -1.0 && fy < (double)ny && fz < (double)nz) {
+            const int sy = (int)fy, sz = (int)fz;
+            const double w1 = py - fy, w2 = pz - fz;
+            const double w1n = 1.0 - w1, w2n = 1.0 - w2;
+            w00[r] = 1.0 * w1n * w2n; w10[r] = 1.0 * w1 * w2n; w11[r] = 1.0 * w1 * w2; w01[r] = 1.0 * w1n * w2;
+            const bool ya = sy >= 0, yb = sy + 1 < ny, za = sz >= 0, zb = sz + 1 < nz;
+            if (ya && za) v00[r] = *reinterpret_cast<const float4*>(in + x4 + row * (sy + (long long)ny * sz));
+            if (yb && za) v10[r] = *reinterpret_cast<const float4*>(in + x4 + row * (sy + 1 + (long long)ny * sz));
+            if (yb && zb) v11[r] = *reinterpret_cast<const float4*>(in + x4 + row * (sy + 1 + (long long)ny * (sz + 1)));
+            if (ya && zb) v01[r] = *reinterpret_cast<const float4*>(in + x4 + row * (sy + (long long)ny * (sz + 1)));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROT_ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= ny) break;
+        float4 o;
+#define MVSIM_BLEND(c)                                         \
+        o.c = (float)((double)v00[r].c * w00[r]);              \
+        o.c += (float)((double)v10[r].c * w10[r]);             \
+        o.c += (float)((double)v11[r].c * w11[r]);             \
+        o.c += (float)((double)v01[r].c * w01[r]);
         MVSIM_BLEND(x) MVSIM_BLEND(y) MVSIM_BLEND(z) MVSIM_BLEND(w)
 #undef MVSIM_BLEND
+        *reinterpret_cast<float4*>(out + x4 + (long long)nx * (y + (long long)ny * z)) = o;
     }
-    *reinterpret_cast<float4*>(out + x4 + (long long)nx * (y + (long long)ny * z)) = r;
 }
 
 int launch_rotate(hipStream_t s, const float* in, float* out, const int64_t dim[3], const Affine& inv)
@@ -95,7 +111,7 @@ int launch_rotate(hipStream_t s, const float* in, float* out, const int64_t dim[
     const bool aligned = (nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
     if (x_identity && aligned) {
         const int threads = 128;
-        dim3 grid((nx / 4 + threads - 1) / threads, ny, nz);
+        dim3 grid((nx / 4 + threads - 1) / threads, (ny + ROT_ROWS - 1) / ROT_ROWS, nz);
         hipLaunchKernelGGL(k_rotate_axis0_v4, grid, dim3(threads), 0, s, in, out, nx, ny, nz, inv);
     } else {
         const int threads = 256;
@@ -314,6 +330,39 @@ __global__ __launch_bounds__(256) void k_extract(const float* __restrict__ in, f
     }
 }
 
+// Vector form: 4 consecutive voxels per lane (16-B loads/stores); the lane's 4 voxels are exactly one
+// Philox group.  Requires plane % 4 == 0, index_offset % 4 == 0 and 16-B aligned buffers.
+template <bool ADJUST, bool NOISE>
+__global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, float* __restrict__ out,
+                                                  long long plane4, long long nzo, int inc,
+                                                  const double* __restrict__ scal, float min_value, double mul,
+                                                  uint32_t k0, uint32_t k1, uint32_t stream,
+                                                  unsigned long long index_offset)
+{
+    double corr = 1.0;
+    if (ADJUST) corr = scal[1];
+    const long long total4 = plane4 * nzo;
+    const long long nthreads = (long long)gridDim.x * 256;
+    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total4; o += nthreads) {
+        const long long k = o / plane4;
+        const long long i = o - k * plane4;
+        const long long src4 = k * inc * plane4 + i;
+        float4 v = in4[src4];
+        if (ADJUST) {
+            v.x = adjust_one(v.x, corr, min_value);
+            v.y = adjust_one(v.y, corr, min_value);
+            v.z = adjust_one(v.z, corr, min_value);
+            v.w = adjust_one(v.w, corr, min_value);
+        }
+        if (NOISE)
+            v = poisson_counter4((double)v.x * mul, (double)v.y * mul, (double)v.z * mul, (double)v.w * mul, k0, k1,
+                                 stream, index_offset + 4ull * (unsigned long long)src4);
+        out4[o] = v;
+    }
+}
+
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
                    uint32_t stream, uint64_t index_offset)
@@ -321,9 +370,25 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
     const long long plane = (long long)dim[0] * dim[1];
     const long long nzo = (dim[2] - 1) / inc + 1;
     const long long total = plane * nzo;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const bool vec = (plane % 4 == 0) && (index_offset % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    if (vec) {
+        long long want = (total / 4 + 255) / 256;
+        int blocks = (int)(want < 1 ? 1 : (want > 256 * 64 ? 256 * 64 : want));
+#define MVSIM_LAUNCH_EX4(A, N)                                                                               \
+    hipLaunchKernelGGL((k_extract4<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, scal, \
+                       min_value, mul, k0, k1, stream, (unsigned long long)index_offset)
+        if (adjust && noise) MVSIM_LAUNCH_EX4(true, true);
+        else if (adjust) MVSIM_LAUNCH_EX4(true, false);
+        else if (noise) MVSIM_LAUNCH_EX4(false, true);
+        else MVSIM_LAUNCH_EX4(false, false);
+#undef MVSIM_LAUNCH_EX4
+        MVSIM_HIP(hipGetLastError());
+        return MVSIM_OK;
+    }
     long long want = (total + 255) / 256;
     int blocks = (int)(want < 1 ? 1 : (want > 256 * 32 ? 256 * 32 : want));
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #define MVSIM_LAUNCH_EX(A, N)                                                                             \
     hipLaunchKernelGGL((k_extract<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane, nzo, inc, scal, \
                        min_value, mul, k0, k1, stream, (unsigned long long)index_offset)

@@ -2,10 +2,12 @@
 // (replaces uncommons/PoissonGenerator.java:95-109 + java.util.Random, which cost ~lambda+1
 // Math.log calls per voxel on one strictly sequential stream).
 //
-// Generator : Philox4x32-10, key = 64-bit seed, counter = (voxel index lo, hi, stream, attempt)
-// Sampler   : lambda < 10  -> inversion by sequential search on one 53-bit uniform
-//             lambda >= 10 -> Hoermann's PTRS transformed rejection (one Philox block per attempt)
-// All accept/reject arithmetic is IEEE +,-,*,/,sqrt on doubles plus the bit-defined log/exp
+// Generator : Philox4x32-10, key = 64-bit seed
+// Sampler   : lambda < 10  -> inversion by sequential search on a 32-bit uniform; the 4 voxels of
+//                             group index>>2 share ONE Philox block, ctr = (index>>2, stream, 0)
+//             lambda >= 10 -> Hoermann's PTRS transformed rejection, one Philox block per attempt,
+//                             ctr = (index, stream, attempt+1)
+// All accept/reject arithmetic is IEEE +,-,*,/,sqrt,fma on doubles plus the bit-defined log/exp
 // below (built with -ffp-contract=off), so a CPU implementation of the same recipe gives
 // identical counts.
 #pragma once
@@ -65,22 +67,27 @@ __device__ __forceinline__ double det_log(double x)
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
-// exp(x) for the range the sampler needs (x in (-10, 0]); general clamp kept for safety.
-__device__ __forceinline__ double det_exp(double x)
+// exp(-lambda), 0 < lambda < 10, division free: 2^k * sum_{n<=13} r^n / n!  (Horner, explicit FMAs)
+__device__ __forceinline__ double det_exp_neg(double lambda)
 {
-    if (x < -745.0) return 0.0;
-    if (x > 709.0) return 1.0e308;
+    const double x = -lambda;
     const double kf = floor(x * 1.44269504088896338700e+00 + 0.5);
-    const double hi = x - kf * 6.93147180369123816490e-01;
-    const double lo = kf * 1.90821492927058770002e-10;
-    const double r = hi - lo;
-    const double t = r * r;
-    const double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 + t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
-    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
-    const int k = (int)kf;
-    if (k < -1000)
-        return (y * __longlong_as_double((long long)((uint64_t)(k + 1000 + 1023) << 52))) * 0x1.0p-1000;
-    return y * __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
+    const double r = (x - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return p * __longlong_as_double((long long)((uint64_t)((int)kf + 1023) << 52));
 }
 
 // log(k!) : table to 16, Stirling series beyond.
@@ -113,46 +120,97 @@ __device__ __forceinline__ double det_lgamma_int(long long k)
     return ((x - 0.5) * det_log(x) - x) + 0.9189385332046727 + ser;
 }
 
-// Poisson(lambda) for voxel `index` of stream `stream`.  lambda <= 0 or NaN -> 0 (the
-// reference's loop does not terminate there; documented deviation Q9).
-__device__ __forceinline__ float poisson_counter(double lambda, uint32_t k0, uint32_t k1, uint32_t stream,
-                                                 uint64_t index)
+// 1/k, k = 0..63 (k = 0 unused), correctly rounded at compile time
+__device__ const double kInvK[64] = {
+    0.0,       1.0 / 1,  1.0 / 2,  1.0 / 3,  1.0 / 4,  1.0 / 5,  1.0 / 6,  1.0 / 7,  1.0 / 8,  1.0 / 9,  1.0 / 10,
+    1.0 / 11,  1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18, 1.0 / 19, 1.0 / 20, 1.0 / 21,
+    1.0 / 22,  1.0 / 23, 1.0 / 24, 1.0 / 25, 1.0 / 26, 1.0 / 27, 1.0 / 28, 1.0 / 29, 1.0 / 30, 1.0 / 31, 1.0 / 32,
+    1.0 / 33,  1.0 / 34, 1.0 / 35, 1.0 / 36, 1.0 / 37, 1.0 / 38, 1.0 / 39, 1.0 / 40, 1.0 / 41, 1.0 / 42, 1.0 / 43,
+    1.0 / 44,  1.0 / 45, 1.0 / 46, 1.0 / 47, 1.0 / 48, 1.0 / 49, 1.0 / 50, 1.0 / 51, 1.0 / 52, 1.0 / 53, 1.0 / 54,
+    1.0 / 55,  1.0 / 56, 1.0 / 57, 1.0 / 58, 1.0 / 59, 1.0 / 60, 1.0 / 61, 1.0 / 62, 1.0 / 63};
+
+// Inversion by sequential search for 0 < lambda < 10 on the 32-bit word `w` of the group block.
+__device__ __forceinline__ float poisson_small(double lambda, uint32_t w)
 {
-    if (!(lambda > 0.0)) return 0.0f;
-    const uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32);
-    if (lambda < 10.0) {
-        const Philox4 r = philox4x32_10(c0, c1, stream, 0u, k0, k1);
-        const double u = u53(r.x, r.y);
-        double p = det_exp(-lambda);
-        double F = p;
-        int k = 0;
-        while (u >= F && k < 1000) {
-            k += 1;
-            p = (p * lambda) / (double)k;
-            F = F + p;
-        }
-        return (float)k;
+    const double u = ((double)w + 0.5) * 0x1.0p-32;
+    double p = det_exp_neg(lambda);
+    double F = p;
+    int k = 0;
+    while (u >= F && k < 63) {
+        k += 1;
+        p = (p * lambda) * kInvK[k];
+        F = F + p;
     }
+    return (float)k;
+}
+
+// Hoermann PTRS for lambda >= 10; one Philox block per attempt, ctr = (index, stream, attempt + 1).
+__device__ __forceinline__ float poisson_ptrs(double lambda, uint32_t k0, uint32_t k1, uint32_t stream, uint64_t index)
+{
+    const uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32);
     const double slam = sqrt(lambda);
-    const double loglam = det_log(lambda);
     const double b = 0.931 + 2.53 * slam;
     const double a = -0.059 + 0.02483 * b;
-    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
-    const double vr = 0.9277 - 3.6224 / (b - 2.0);
-    for (uint32_t attempt = 0; attempt < 0xFFFFFFFFu; ++attempt) {
-        const Philox4 r = philox4x32_10(c0, c1, stream, attempt, k0, k1);
+    const double bm2 = b - 2.0;
+    const double vrq = 0.9277 * bm2 - 3.6224;       // V <= vr  <=>  V*(b-2) <= 0.9277*(b-2) - 3.6224
+    const double bm34 = b - 3.4;
+    const double ianum = 1.1239 * bm34 + 1.1328;     // invalpha = ianum / bm34
+    double loglam = 0.0;
+    bool have_loglam = false;
+    for (uint32_t attempt = 0; attempt < 0xFFFFFFFEu; ++attempt) {
+        const Philox4 r = philox4x32_10(c0, c1, stream, attempt + 1u, k0, k1);
         const double U = u53(r.x, r.y) - 0.5;
         const double V = u53(r.z, r.w);
         const double us = 0.5 - fabs(U);
         const double kd = floor((2.0 * a / us + b) * U + lambda + 0.43);
-        if (us >= 0.07 && V <= vr) return (float)(long long)kd;
+        if (us >= 0.07 && V * bm2 <= vrq) return (float)(long long)kd;
         if (kd < 0.0 || (us < 0.013 && V > us)) continue;
         const long long k = (long long)kd;
-        const double lhs = det_log(V) + det_log(invalpha) - det_log(a / (us * us) + b);
+        const double us2 = us * us;
+        const double lhs = det_log((V * us2 * ianum) / (bm34 * (a + b * us2)));
+        if (!have_loglam) { loglam = det_log(lambda); have_loglam = true; }
         const double rhs = (-lambda + kd * loglam) - det_lgamma_int(k);
         if (lhs <= rhs) return (float)k;
     }
     return (float)lambda;
+}
+
+// Counter sampler v2 for one voxel (generic path: recomputes the group block of index >> 2).
+// lambda <= 0 or NaN -> 0 (the reference's loop does not terminate there; documented deviation Q9).
+__device__ __forceinline__ float poisson_counter(double lambda, uint32_t k0, uint32_t k1, uint32_t stream,
+                                                 uint64_t index)
+{
+    if (!(lambda > 0.0)) return 0.0f;
+    if (lambda < 10.0) {
+        const uint64_t g = index >> 2;
+        const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream, 0u, k0, k1);
+        const uint32_t lane = (uint32_t)index & 3u;
+        const uint32_t w = lane == 0 ? r.x : (lane == 1 ? r.y : (lane == 2 ? r.z : r.w));
+        return poisson_small(lambda, w);
+    }
+    return poisson_ptrs(lambda, k0, k1, stream, index);
+}
+
+// Four voxels index4 .. index4+3 (index4 % 4 == 0) sharing their group block.
+__device__ __forceinline__ float4 poisson_counter4(double l0, double l1, double l2, double l3, uint32_t k0,
+                                                   uint32_t k1, uint32_t stream, uint64_t index4)
+{
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool s0 = l0 > 0.0 && l0 < 10.0, s1 = l1 > 0.0 && l1 < 10.0, s2 = l2 > 0.0 && l2 < 10.0,
+               s3 = l3 > 0.0 && l3 < 10.0;
+    if (s0 || s1 || s2 || s3) {
+        const uint64_t g = index4 >> 2;
+        const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream, 0u, k0, k1);
+        if (s0) out.x = poisson_small(l0, r.x);
+        if (s1) out.y = poisson_small(l1, r.y);
+        if (s2) out.z = poisson_small(l2, r.z);
+        if (s3) out.w = poisson_small(l3, r.w);
+    }
+    if (l0 >= 10.0) out.x = poisson_ptrs(l0, k0, k1, stream, index4);
+    if (l1 >= 10.0) out.y = poisson_ptrs(l1, k0, k1, stream, index4 + 1);
+    if (l2 >= 10.0) out.z = poisson_ptrs(l2, k0, k1, stream, index4 + 2);
+    if (l3 >= 10.0) out.w = poisson_ptrs(l3, k0, k1, stream, index4 + 3);
+    return out;
 }
 
 }  // namespace mvsim

@@ -75,6 +75,8 @@ def lib():
         L.orc_det_log.restype = C.c_double
         L.orc_det_exp.argtypes = [C.c_double]
         L.orc_det_exp.restype = C.c_double
+        L.orc_det_exp_neg.argtypes = [C.c_double]
+        L.orc_det_exp_neg.restype = C.c_double
         L.orc_det_lgamma_int.argtypes = [C.c_int64]
         L.orc_det_lgamma_int.restype = C.c_double
         L.orc_poisson_counter.argtypes = [C.c_double, C.c_uint64, C.c_uint32, C.c_uint64]
@@ -166,6 +168,10 @@ def det_log(x: float) -> float:
 
 def det_exp(x: float) -> float:
     return lib().orc_det_exp(x)
+
+
+def det_exp_neg(lam: float) -> float:
+    return lib().orc_det_exp_neg(lam)
 
 
 def det_lgamma_int(k: int) -> float:

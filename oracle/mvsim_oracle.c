@@ -162,45 +162,81 @@ static double u53(uint32_t a, uint32_t b)
     return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * 0x1.0p-53;
 }
 
-/* O(1) Poisson sampler keyed by (seed, stream, index): inversion by sequential
- * search for lambda < 10, Hoermann's PTRS transformed rejection otherwise.
- * Q9: lambda <= 0 or NaN -> 0 (the reference loops forever there). */
+/* exp(-lambda) for 0 < lambda < 10, division free: 2^k * sum_{n<=13} r^n/n! by Horner with
+ * explicit fused multiply-adds (correctly rounded on every platform). */
+double orc_det_exp_neg(double lambda)
+{
+    const double x = -lambda;
+    const double kf = floor(x * 1.44269504088896338700e+00 + 0.5);
+    const double r = (x - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return p * bits2d((uint64_t)((int)kf + 1023) << 52);
+}
+
+/* O(1) Poisson sampler keyed by (seed, stream, index)  -- "counter sampler v2".
+ *   lambda <= 0 or NaN : 0 (Q9: the reference loops forever there)
+ *   lambda < 10        : inversion by sequential search on a 32-bit uniform; the four voxels
+ *                        index>>2 share one Philox block (ctr = (index>>2, stream, 0)), voxel
+ *                        index&3 takes word index&3; p_{k} = p_{k-1} * lambda * (1/k)
+ *   lambda >= 10       : Hoermann's PTRS transformed rejection, one Philox block per attempt
+ *                        (ctr = (index, stream, attempt+1)); divisions folded out of the
+ *                        squeeze, logs merged in the exact test. */
 int64_t orc_poisson_counter(double lambda, uint64_t seed, uint32_t stream, uint64_t index)
 {
     if (!(lambda > 0.0)) return 0;
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
-    uint32_t ctr[4] = { (uint32_t)index, (uint32_t)(index >> 32), stream, 0u };
     uint32_t r[4];
     if (lambda < 10.0) {
+        const uint64_t g = index >> 2;
+        uint32_t ctr[4] = { (uint32_t)g, (uint32_t)(g >> 32), stream, 0u };
         orc_philox4x32_10(ctr, key, r);
-        const double u = u53(r[0], r[1]);
-        double p = orc_det_exp(-lambda);
+        const double u = ((double)r[index & 3] + 0.5) * 0x1.0p-32;
+        double p = orc_det_exp_neg(lambda);
         double F = p;
         int64_t k = 0;
-        while (u >= F && k < 1000) {
+        while (u >= F && k < 63) {
             k += 1;
-            p = (p * lambda) / (double)k;
+            p = (p * lambda) * (1.0 / (double)k);
             F = F + p;
         }
         return k;
     }
+    uint32_t ctr[4] = { (uint32_t)index, (uint32_t)(index >> 32), stream, 1u };
     const double slam = sqrt(lambda);
-    const double loglam = orc_det_log(lambda);
     const double b = 0.931 + 2.53 * slam;
     const double a = -0.059 + 0.02483 * b;
-    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
-    const double vr = 0.9277 - 3.6224 / (b - 2.0);
-    for (uint32_t attempt = 0; attempt < 0xFFFFFFFFu; ++attempt) {
-        ctr[3] = attempt;
+    const double bm2 = b - 2.0;
+    const double vrq = 0.9277 * bm2 - 3.6224;           /* V <= vr  <=>  V*(b-2) <= 0.9277*(b-2) - 3.6224 */
+    const double bm34 = b - 3.4;
+    const double ianum = 1.1239 * bm34 + 1.1328;         /* invalpha = ianum / bm34 */
+    double loglam = 0.0;
+    int have_loglam = 0;
+    for (uint32_t attempt = 0; attempt < 0xFFFFFFFEu; ++attempt) {
+        ctr[3] = attempt + 1u;
         orc_philox4x32_10(ctr, key, r);
         const double U = u53(r[0], r[1]) - 0.5;
         const double V = u53(r[2], r[3]);
         const double us = 0.5 - fabs(U);
         const double kd = floor((2.0 * a / us + b) * U + lambda + 0.43);
-        if (us >= 0.07 && V <= vr) return (int64_t)kd;
+        if (us >= 0.07 && V * bm2 <= vrq) return (int64_t)kd;
         if (kd < 0.0 || (us < 0.013 && V > us)) continue;
         const int64_t k = (int64_t)kd;
-        const double lhs = orc_det_log(V) + orc_det_log(invalpha) - orc_det_log(a / (us * us) + b);
+        const double us2 = us * us;
+        const double lhs = orc_det_log((V * us2 * ianum) / (bm34 * (a + b * us2)));
+        if (!have_loglam) { loglam = orc_det_log(lambda); have_loglam = 1; }
         const double rhs = (-lambda + kd * loglam) - orc_det_lgamma_int(k);
         if (lhs <= rhs) return k;
     }

@@ -48,6 +48,7 @@ int32_t  orc_poisson_interarrival(orc_jrandom* r, double mean);
 void     orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double   orc_det_log(double x);
 double   orc_det_exp(double x);
+double   orc_det_exp_neg(double lambda);        /* exp(-lambda), 0 < lambda < 10 */
 double   orc_det_lgamma_int(int64_t k);            /* log(k!) */
 int64_t  orc_poisson_counter(double lambda, uint64_t seed, uint32_t stream, uint64_t index);
 

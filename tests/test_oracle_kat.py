@@ -51,6 +51,7 @@ def test_det_functions_close_to_libm(orc):
         assert abs(orc.det_log(x) - math.log(x)) <= 4e-16 * max(1.0, abs(math.log(x)))
     for x in -rng.random(2000) * 10:
         assert abs(orc.det_exp(x) - math.exp(x)) <= 4e-16 * math.exp(x)
+        assert abs(orc.det_exp_neg(-x) - math.exp(x)) <= 6e-16 * math.exp(x)
     for k in list(range(0, 300)) + [1000, 10 ** 5, 10 ** 7]:
         assert abs(orc.det_lgamma_int(k) - math.lgamma(k + 1)) <= 1e-13 * max(1.0, math.lgamma(k + 1))
 
