@@ -46,6 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     common = [
         "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+        *os.environ.get("MVSIM_EXTRA_CFLAGS", "").split(),
         "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROCM, "include"),
     ]
     procs = []

@@ -9,9 +9,12 @@
 //   D  y: inverse FFT along y, in place                               read C       write C
 //   E  x: complex->real FFT along x + crop + 1/P^3 + block sums       read C       write 4N
 // Each pass stages a tile of NL lines in LDS (line = the FFT axis, contiguous in LDS; NL adjacent
-// kx columns = 128 B contiguous in HBM), runs a mixed-radix Stockham FFT with one register
-// butterfly per lane per radix pass, and writes the tile back.  Twiddles come from a host-computed
-// (double precision, rounded once) table staged in LDS.  Inverse transforms use conj(FFT(conj(.))).
+// kx columns = 128 B contiguous in HBM).  Every wave then OWNS whole lines of the tile and runs the
+// mixed-radix Stockham passes on them with register butterflies; because LDS operations of one wave
+// execute in issue order, the passes need no workgroup barrier at all -- the waves of a block run
+// decoupled and hide each other's LDS latency.  Block barriers remain only around the transposed
+// staging (and around the spectrum product of pass C).  Twiddles come from a host-computed (double
+// precision, rounded once) table staged in LDS.  Inverse transforms use conj(FFT(conj(.))).
 #include "common.h"
 
 #include <cmath>
@@ -111,33 +114,42 @@ template <> __device__ __forceinline__ void dft<9>(float2* u)
 }
 
 // ---------------------------------------------------------------------------------- Stockham passes in LDS
-// buf: NL lines of length L, line pitch LP (complex elements); tw: L twiddles exp(-2 pi i k / L).
-// One register butterfly per lane-iteration; read phase, barrier, write phase, barrier.
-template <int L, int LP, int NL, int T, int P>
-__device__ __forceinline__ void passes(float2*, const float2*, int) {}
+// Compiler-level ordering point for LDS traffic of ONE wave (the hardware executes a wave's DS
+// operations in issue order, so no s_barrier is needed between a wave's own writes and reads).
+__device__ __forceinline__ void wave_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-template <int L, int LP, int NL, int T, int P, int R, int... Rest>
-__device__ __forceinline__ void passes(float2* __restrict__ buf, const float2* __restrict__ tw, int tid)
+// wbuf: the LW lines owned by this wave (length L, pitch LP complex elements); tw: L twiddles
+// exp(-2 pi i k / L) in LDS.  Per radix pass: read all butterflies of the wave into registers, then
+// twiddle + DFT + write back in Stockham order.
+template <int L, int LP, int LW, int P>
+__device__ __forceinline__ void wpasses(float2*, const float2*, int) {}
+
+template <int L, int LP, int LW, int P, int R, int... Rest>
+__device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2* __restrict__ tw, int lane)
 {
     constexpr int STR = L / R;
-    constexpr int NB = NL * STR;
-    constexpr int IT = (NB + T - 1) / T;
+    constexpr int NB = LW * STR;               // butterflies of this wave in this pass
+    constexpr int IT = (NB + 63) / 64;
     float2 u[IT][R];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int b = tid + it * T;
-        if ((NB % T == 0) || b < NB) {
+        const int b = lane + it * 64;
+        if ((NB % 64 == 0) || b < NB) {
             const int line = b / STR, i = b - line * STR;
-            const float2* src = buf + line * LP + i;
+            const float2* src = wbuf + line * LP + i;
 #pragma unroll
             for (int r = 0; r < R; ++r) u[it][r] = src[r * STR];
         }
     }
-    __syncthreads();
+    wave_order();
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int b = tid + it * T;
-        if ((NB % T == 0) || b < NB) {
+        const int b = lane + it * 64;
+        if ((NB % 64 == 0) || b < NB) {
             const int line = b / STR, i = b - line * STR;
             const int k = i % P;
             const int j = (i - k) * R + k;
@@ -147,32 +159,50 @@ __device__ __forceinline__ void passes(float2* __restrict__ buf, const float2* _
                 for (int r = 1; r < R; ++r) u[it][r] = cmul(u[it][r], tw[r * idx]);
             }
             dft<R>(u[it]);
-            float2* dst = buf + line * LP + j;
+            float2* dst = wbuf + line * LP + j;
 #pragma unroll
             for (int r = 0; r < R; ++r) dst[r * P] = u[it][r];
         }
     }
-    __syncthreads();
-    passes<L, LP, NL, T, P * R, Rest...>(buf, tw, tid);
+    wave_order();
+    wpasses<L, LP, LW, P * R, Rest...>(wbuf, tw, lane);
 }
 
+#ifndef MVSIM_NL_BIG
+#define MVSIM_NL_BIG ((L <= 576) ? 16 : 8)
+#endif
 // size traits ---------------------------------------------------------------------------------------
-constexpr int round64(int v) { return ((v + 63) / 64) * 64; }
+constexpr int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+constexpr int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// y / z passes: NL lines per tile (NL adjacent kx columns); NW waves, each owning LW = NL / NW lines
+// (~1024 complex elements per wave).
 template <int L> struct Cfg {
-    static constexpr int NL = (L <= 576) ? 16 : 8;           // lines per tile (16 complex = 128 B in HBM)
-    static constexpr int LP = L + 1;                         // odd pitch: conflict-free transposed staging
-    static constexpr int T0 = round64(NL * L / 16);
-    static constexpr int T = T0 < 64 ? 64 : (T0 > 1024 ? 1024 : T0);
-    // tile + twiddles + 256 B of small per-block tables (row offsets, wave partial sums)
+    static constexpr int NL = MVSIM_NL_BIG;
+    static constexpr int LP = L + 1;                          // odd pitch: conflict-free transposed staging
+    static constexpr int NW = clampi(pow2_floor((NL * L) / 1024 > 0 ? (NL * L) / 1024 : 1), 1, NL);
+    static constexpr int LW = NL / NW;
+    static constexpr int T = 64 * NW;
     static constexpr size_t LDS = (size_t)(NL * LP + L) * sizeof(float2) + 32 * sizeof(double);
+};
+
+// x passes: rows are contiguous in HBM; 4 waves per block, each owning LW rows (~1152 complex per wave).
+template <int M> struct CfgX {
+    static constexpr int LW = clampi(1152 / M, 1, 8);
+    static constexpr int NW = 4;
+    static constexpr int NL = NW * LW;
+    static constexpr int LP = M + 1;
+    static constexpr int T = 64 * NW;
+    static constexpr size_t LDS = (size_t)(NL * LP + M) * sizeof(float2) + 32 * sizeof(double);
 };
 
 template <int L, int... Rs> struct Plan {
     static constexpr int len = L;
-    template <int NL, int T>
-    static __device__ __forceinline__ void run(float2* buf, const float2* tw, int tid)
+    // transform the LW lines starting at wbuf (owned by the calling wave)
+    template <int LW>
+    static __device__ __forceinline__ void run(float2* wbuf, const float2* tw, int lane)
     {
-        passes<L, L + 1, NL, T, 1, Rs...>(buf, tw, tid);
+        wpasses<L, L + 1, LW, 1, Rs...>(wbuf, tw, lane);
     }
 };
 
@@ -192,9 +222,11 @@ __device__ __forceinline__ int map_src(const DimMap& m, int j)
         if (j < m.a) i = j;
         else if (j >= m.P - m.b) i = j - m.P;
         else return -1;
+        if (i < 0) i = -i;                           // one reflection covers any halo shorter than the image
+        if (i >= m.n) i = 2 * m.n - 2 - i;
         if (i >= 0 && i < m.n) return i;
         if (m.n == 1) return 0;
-        const int p = 2 * m.n - 2;
+        const int p = 2 * m.n - 2;                   // general case: halo longer than the image
         i %= p;
         if (i < 0) i += p;
         return i < m.n ? i : p - i;
@@ -220,23 +252,25 @@ struct LinesArgs {
     DimMap        lmap;     // SPARSE: position n reads source position map_src(lmap, n) (or zero)
 };
 
+// second launch bound: two blocks per CU must stay resident (w = 2*T/256 waves per SIMD, rounded up)
 template <class PLAN, int MODE, bool SPARSE>
-__global__ __launch_bounds__(Cfg<PLAN::len>::T) void k_fft_lines(LinesArgs p)
+__global__ __launch_bounds__(Cfg<PLAN::len>::T, (2 * Cfg<PLAN::len>::T + 255) / 256) void k_fft_lines(LinesArgs p)
 {
     constexpr int L = PLAN::len;
     using C = Cfg<L>;
-    constexpr int NL = C::NL, LP = C::LP, T = C::T;
+    constexpr int NL = C::NL, LP = C::LP, T = C::T, LW = C::LW;
     constexpr int LPR = NL / 2;             // lanes per position: one float4 = two adjacent columns
     constexpr int ROWS = T / LPR;
     constexpr int NIT = (L + ROWS - 1) / ROWS;
     extern __shared__ __align__(16) float2 lds[];
     float2* buf = lds;
     float2* tw = lds + NL * LP;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c2 = (tid % LPR) * 2;
     const int r0 = tid / LPR;
+    float2* wbuf = buf + wave * LW * LP;    // the lines this wave transforms
 
-    // all global loads of the tile (and of the spectrum tile) are issued before anything waits
+    // all global loads of the tile are issued before anything waits
     const float2* sbase = p.src + (long long)blockIdx.y * p.src_outer + (long long)blockIdx.x * NL + c2;
     float4 v[NIT];
 #pragma unroll
@@ -252,15 +286,6 @@ __global__ __launch_bounds__(Cfg<PLAN::len>::T) void k_fft_lines(LinesArgs p)
             }
         }
     }
-    float4 g[MODE == CONV ? NIT : 1];
-    if (MODE == CONV) {
-        const float2* gbase = p.spec + (long long)blockIdx.y * p.spec_outer + (long long)blockIdx.x * NL + c2;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int n = r0 + it * ROWS;
-            if ((L % ROWS == 0) || n < L) g[it] = *reinterpret_cast<const float4*>(gbase + n * p.spec_es);
-        }
-    }
     for (int i = tid; i < L; i += T) tw[i] = p.tw[i];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -273,22 +298,37 @@ __global__ __launch_bounds__(Cfg<PLAN::len>::T) void k_fft_lines(LinesArgs p)
         }
     }
     __syncthreads();
-    PLAN::template run<NL, T>(buf, tw, tid);
+    PLAN::template run<LW>(wbuf, tw, lane);
     if (MODE == CONV) {
-        // multiply by the PSF spectrum, conjugate, transform again (inverse = conj FFT conj)
+        // multiply by the PSF spectrum, conjugate, transform again (inverse = conj FFT conj).
+        // The spectrum tile is fetched here in two batches rather than prefetched: holding it across the
+        // first transform would push the kernel past 96 VGPRs and evict the second resident block.
+        __syncthreads();
+        const float2* gbase = p.spec + (long long)blockIdx.y * p.spec_outer + (long long)blockIdx.x * NL + c2;
+        constexpr int HB = (NIT + 1) / 2;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int n = r0 + it * ROWS;
-            if ((L % ROWS == 0) || n < L) {
-                const float2 a = cmul(buf[c2 * LP + n], make_float2(g[it].x, g[it].y));
-                const float2 b = cmul(buf[(c2 + 1) * LP + n], make_float2(g[it].z, g[it].w));
-                buf[c2 * LP + n] = cconj(a);
-                buf[(c2 + 1) * LP + n] = cconj(b);
+        for (int h0 = 0; h0 < NIT; h0 += HB) {
+            float4 g[HB];
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                const int n = r0 + (h0 + q) * ROWS;
+                if (h0 + q < NIT && ((L % ROWS == 0) || n < L)) g[q] = *reinterpret_cast<const float4*>(gbase + n * p.spec_es);
+            }
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                const int n = r0 + (h0 + q) * ROWS;
+                if (h0 + q < NIT && ((L % ROWS == 0) || n < L)) {
+                    const float2 a = cmul(buf[c2 * LP + n], make_float2(g[q].x, g[q].y));
+                    const float2 b = cmul(buf[(c2 + 1) * LP + n], make_float2(g[q].z, g[q].w));
+                    buf[c2 * LP + n] = cconj(a);
+                    buf[(c2 + 1) * LP + n] = cconj(b);
+                }
             }
         }
         __syncthreads();
-        PLAN::template run<NL, T>(buf, tw, tid);
+        PLAN::template run<LW>(wbuf, tw, lane);
     }
+    __syncthreads();
     float2* dbase = p.dst + (long long)blockIdx.y * p.dst_outer + (long long)blockIdx.x * NL + c2;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -303,164 +343,267 @@ __global__ __launch_bounds__(Cfg<PLAN::len>::T) void k_fft_lines(LinesArgs p)
 
 // ---------------------------------------------------------------------------------- x passes
 // A: rows of the (virtually) padded real volume -> half spectrum along x.  M = Px/2.
-// NR rows per block; dst row pitch hxp (complex).
+// Each wave owns LW rows end to end (load, transform, post-process, store): no block barrier after the
+// twiddle table is staged.  Lanes run along x with 16-B loads / stores; dst row pitch hxp (complex).
 template <class PLAN>
-__global__ __launch_bounds__(Cfg<PLAN::len>::T) void k_fft_x_r2c(const float* __restrict__ src, SrcMap map,
-                                                                float2* __restrict__ dst,
-                                                                const float2* __restrict__ twg,
-                                                                const float2* __restrict__ twx, int hxp,
-                                                                long long rows)
+__global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* __restrict__ src, SrcMap map,
+                                                                 float2* __restrict__ dst,
+                                                                 const float2* __restrict__ twg,
+                                                                 const float2* __restrict__ twx, int hxp,
+                                                                 long long rows)
 {
     constexpr int M = PLAN::len;
-    using C = Cfg<M>;
-    constexpr int NR = C::NL, LP = C::LP, T = C::T;
+    using C = CfgX<M>;
+    constexpr int NR = C::NL, LP = C::LP, T = C::T, LW = C::LW;
+    constexpr int PAIRS = (M + 1) / 2;               // lanes needed for one row (2 complex = 4 floats per lane)
+    constexpr int PIT = (PAIRS + 63) / 64;
     extern __shared__ __align__(16) float2 lds[];
-    float2* buf = lds;
     float2* tw = lds + NR * LP;
-    long long* rowoff = reinterpret_cast<long long*>(lds + NR * LP + M);   // NR entries (<= 16)
-    const int tid = threadIdx.x;
-    const long long row0 = (long long)blockIdx.x * NR;
-    if (tid < NR) {
-        const long long row = row0 + tid;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2* wbuf = lds + wave * LW * LP;
+    const long long row0 = (long long)blockIdx.x * NR + wave * LW;
+
+    const int nxs = map.x.n;
+    const bool fast_x = (nxs & 3) == 0 && map.x.mode == 0;     // 16-B aligned interior loads
+    float4 v[LW][PIT];
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        const long long row = row0 + j;
         long long off = -1;
         if (row < rows) {
-            const int py = map.y.P;
-            const int y = (int)(row % py), z = (int)(row / py);
+            const unsigned py = (unsigned)map.y.P;
+            const unsigned urow = (unsigned)row;      // rows = Py*Pz < 2^31
+            const int z = (int)(urow / py), y = (int)(urow - (unsigned)z * py);
             const int sy = map_src(map.y, y), sz = map_src(map.z, z);
-            if (sy >= 0 && sz >= 0) off = (long long)map.x.n * (sy + (long long)map.y.n * sz);
+            if (sy >= 0 && sz >= 0) off = (long long)nxs * (sy + (long long)map.y.n * sz);
         }
-        rowoff[tid] = off;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int q = lane + it * 64;             // floats 4q .. 4q+3 of the padded row
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (off >= 0 && q < PAIRS) {
+                const float* __restrict__ srow = src + off;
+                if (fast_x && 4 * q + 3 < nxs) {
+                    t = *reinterpret_cast<const float4*>(srow + 4 * q);
+                } else {
+                    const int s0 = map_src(map.x, 4 * q), s1 = map_src(map.x, 4 * q + 1);
+                    const int s2 = map_src(map.x, 4 * q + 2), s3 = map_src(map.x, 4 * q + 3);
+                    t.x = s0 >= 0 ? srow[s0] : 0.f;
+                    t.y = s1 >= 0 ? srow[s1] : 0.f;
+                    t.z = s2 >= 0 ? srow[s2] : 0.f;
+                    t.w = s3 >= 0 ? srow[s3] : 0.f;
+                }
+            }
+            v[j][it] = t;
+        }
     }
     for (int i = tid; i < M; i += T) tw[i] = twg[i];
-    __syncthreads();
-    const bool even_rows = (map.x.n & 1) == 0 && map.x.mode == 0;
-    for (int e = tid; e < NR * M; e += T) {
-        const int r = e / M, n = e - r * M;
-        const long long off = rowoff[r];
-        float2 v = make_float2(0.f, 0.f);
-        if (off >= 0) {
-            const float* __restrict__ srow = src + off;
-            if (even_rows && 2 * n + 1 < map.x.n) {
-                v = *reinterpret_cast<const float2*>(srow + 2 * n);      // interior: identity map, 8-B aligned
-            } else {
-                const int s0 = map_src(map.x, 2 * n), s1 = map_src(map.x, 2 * n + 1);
-                v.x = s0 >= 0 ? srow[s0] : 0.f;
-                v.y = s1 >= 0 ? srow[s1] : 0.f;
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int q = lane + it * 64;
+            if (q < PAIRS) {
+                wbuf[j * LP + 2 * q] = make_float2(v[j][it].x, v[j][it].y);
+                if (2 * q + 1 < M) wbuf[j * LP + 2 * q + 1] = make_float2(v[j][it].z, v[j][it].w);
             }
         }
-        buf[r * LP + n] = v;
     }
-    __syncthreads();
-    PLAN::template run<NR, T>(buf, tw, tid);
-    // X[k] = (Z[k] + conj Z[M-k])/2 - i/2 * w_P^k * (Z[k] - conj Z[M-k]),  k = 0..M  (twx[k] = w_P^k)
-    for (int e = tid; e < NR * hxp; e += T) {
-        const int r = e / hxp, k = e - r * hxp;
-        const long long row = row0 + r;
-        if (row >= rows) continue;
-        float2 out = make_float2(0.f, 0.f);
-        if (k <= M) {
-            const float2 zk = buf[r * LP + (k == M ? 0 : k)];
-            const float2 zm = cconj(buf[r * LP + (k == 0 ? 0 : M - k)]);
-            const float2 sm = cadd(zk, zm), d = csub(zk, zm);
-            const float2 t = cmul(twx[k], d);            // w^k * d
-            out = make_float2(0.5f * (sm.x + t.y), 0.5f * (sm.y - t.x));   // sm/2 - (i/2) t
+    __syncthreads();                                  // twiddle table complete (rows are wave-private)
+    PLAN::template run<LW>(wbuf, tw, lane);
+    // Post-process to the half spectrum, in symmetric pairs.  With s = Z[k] + conj Z[M-k], d = Z[k] - conj Z[M-k],
+    // t = -i w_P^k d:   2 X[k] = s + t,   2 X[M-k] = conj(s - t).   The factor 2 is NOT divided out here: image and
+    // PSF spectra both carry it and pass E folds the exact power of two into its final scale.
+    // Lane q owns k = 2q, 2q+1 (one 16-B store) and the mirrored M-2q, M-2q-1 (two 8-B stores).
+    constexpr int HQ = M / 4;                         // pairs k = 0 .. M/2-1 in lanes of two; k = M/2, pads: tail lanes
+    for (int j = 0; j < LW; ++j) {
+        const long long row = row0 + j;
+        if (row >= rows) break;
+        float2* __restrict__ drow = dst + row * hxp;
+        const float2* __restrict__ zrow = wbuf + j * LP;
+        for (int q = lane; q < HQ; q += 64) {
+            float2 lo[2], hi[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * q + h;
+                const float2 zk = zrow[k];
+                const float2 zm = cconj(zrow[k == 0 ? 0 : M - k]);
+                const float2 sm = cadd(zk, zm), d = csub(zk, zm);
+                const float2 wd = cmul(twx[k], d);
+                const float2 t = make_float2(wd.y, -wd.x);                 // -i * w^k * d
+                lo[h] = cadd(sm, t);
+                hi[h] = cconj(csub(sm, t));                                 // element M-k (k = 0: element M)
+            }
+            *reinterpret_cast<float4*>(drow + 2 * q) = make_float4(lo[0].x, lo[0].y, lo[1].x, lo[1].y);
+            drow[M - 2 * q] = hi[0];
+            drow[M - 2 * q - 1] = hi[1];
         }
-        dst[row * hxp + k] = out;
+        // k = M/2 is its own mirror (needs M % 4 == 0, true for every table size >= 16 that is even twice);
+        // generic tail: elements not covered above + zero padding up to hxp
+        for (int k = 2 * HQ + lane; k <= M - 2 * HQ; k += 64) {
+            const float2 zk = zrow[k == M ? 0 : k];
+            const float2 zm = cconj(zrow[k == 0 ? 0 : M - k]);
+            const float2 sm = cadd(zk, zm), d = csub(zk, zm);
+            const float2 wd = cmul(twx[k], d);
+            drow[k] = cadd(sm, make_float2(wd.y, -wd.x));
+        }
+        for (int k = M + 1 + lane; k < hxp; k += 64) drow[k] = make_float2(0.f, 0.f);
     }
 }
 
 // E: half spectrum rows -> real rows, cropped to nx, scaled; one partial sum (double) per block.
-// Persistent blocks: each walks row groups blockIdx.x, blockIdx.x + gridDim.x, ...
+// Wave-private rows as in pass A; rows are processed in batches of RB to bound register use.
 template <class PLAN>
-__global__ __launch_bounds__(Cfg<PLAN::len>::T) void k_fft_x_c2r(const float2* __restrict__ srcc,
-                                                                float* __restrict__ out,
-                                                                const float2* __restrict__ twg,
-                                                                const float2* __restrict__ twx, int hxp, int py,
-                                                                int nx, int ny, long long rows, float scale,
-                                                                double* __restrict__ partial)
+__global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* __restrict__ srcc,
+                                                                 float* __restrict__ out,
+                                                                 const float2* __restrict__ twg,
+                                                                 const float2* __restrict__ twx, int hxp, int py,
+                                                                 int nx, int ny, long long rows, float scale,
+                                                                 double* __restrict__ partial)
 {
     constexpr int M = PLAN::len;
-    using C = Cfg<M>;
-    constexpr int NR = C::NL, LP = C::LP, T = C::T;
+    using C = CfgX<M>;
+    constexpr int NR = C::NL, LP = C::LP, T = C::T, LW = C::LW, NW = C::NW;
+    constexpr int RB = LW >= 2 ? 2 : 1;                                       // rows per load batch
     extern __shared__ __align__(16) float2 lds[];
-    float2* buf = lds;
     float2* tw = lds + NR * LP;
-    double* red = reinterpret_cast<double*>(lds + NR * LP + M);              // T/64 <= 16 doubles
-    long long* rowoff = reinterpret_cast<long long*>(red + 16);              // NR entries
-    const int tid = threadIdx.x;
+    double* red = reinterpret_cast<double*>(lds + NR * LP + M);              // NW doubles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2* wbuf = lds + wave * LW * LP;
     for (int i = tid; i < M; i += T) tw[i] = twg[i];
-    const long long ngroups = (rows + NR - 1) / NR;
-    double acc = 0.0;
-    for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const long long row0 = grp * NR;                   // output rows (y < ny, z < nz)
-        __syncthreads();                                   // previous group's buf / rowoff fully consumed
-        if (tid < NR) {
-            const long long row = row0 + tid;
+    const long long row0 = (long long)blockIdx.x * NR + wave * LW;           // output rows (y < ny, z < nz)
+
+    // Pre-process in symmetric pairs.  With A = X[k], B = conj X[M-k], s = A + B, d = A - B, t = i w_P^{-k} d:
+    //   Z[k] = s + t,  Z[M-k] = conj(s - t);  the inverse FFT runs as conj(FFT(conj Z)), so conj(Z) is staged:
+    //   buf[k] = conj(s + t),  buf[M-k] = s - t.
+    // Lane q owns k = 2q, 2q+1 (one 16-B load) and the mirrored M-2q, M-2q-1 (two 8-B loads), q < M/4.
+    constexpr int HQ = M / 4;
+    constexpr int HIT = (HQ + 63) / 64;
+#pragma unroll
+    for (int j0 = 0; j0 < LW; j0 += RB) {
+        float4 xa[RB][HIT];
+        float2 xb0[RB][HIT], xb1[RB][HIT];
+        bool live[RB];
+        long long offs[RB];
+#pragma unroll
+        for (int jj = 0; jj < RB; ++jj) {
+            const long long row = row0 + j0 + jj;
             long long off = -1;
-            if (row < rows) {
-                const int y = (int)(row % ny), z = (int)(row / ny);
+            if (j0 + jj < LW && row < rows) {
+                const unsigned urow = (unsigned)row;  // rows = Ny*Nz < 2^31
+                const int z = (int)(urow / (unsigned)ny), y = (int)(urow - (unsigned)z * (unsigned)ny);
                 off = ((long long)z * py + y) * hxp;
             }
-            rowoff[tid] = off;
-        }
-        __syncthreads();
-        // Z[k] = (X[k] + conj X[M-k]) + i w_P^{-k} (X[k] - conj X[M-k]); inverse FFT via conj trick: stage conj(Z)
-        for (int e = tid; e < NR * M; e += T) {
-            const int r = e / M, k = e - r * M;
-            const long long off = rowoff[r];
-            float2 v = make_float2(0.f, 0.f);
-            if (off >= 0) {
-                const float2* __restrict__ sp = srcc + off;
-                const float2 a = sp[k], b = cconj(sp[M - k]);
-                const float2 sm = cadd(a, b), d = csub(a, b);
-                const float2 t = cmul(cconj(twx[k]), d);      // w^{-k} d
-                v = make_float2(sm.x - t.y, -(sm.y + t.x));    // conj(sm + i t)
+            live[jj] = off >= 0;
+            offs[jj] = off;
+#pragma unroll
+            for (int it = 0; it < HIT; ++it) {
+                const int q = lane + it * 64;
+                xa[jj][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                xb0[jj][it] = xb1[jj][it] = make_float2(0.f, 0.f);
+                if (off >= 0 && q < HQ) {
+                    const float2* __restrict__ sp = srcc + off;
+                    xa[jj][it] = *reinterpret_cast<const float4*>(sp + 2 * q);   // X[2q], X[2q+1]
+                    xb0[jj][it] = sp[M - 2 * q];                                   // X[M-2q]
+                    xb1[jj][it] = sp[M - 2 * q - 1];                               // X[M-2q-1]
+                }
             }
-            buf[r * LP + k] = v;
         }
-        __syncthreads();
-        PLAN::template run<NR, T>(buf, tw, tid);
-        // z[n] = conj(buf[n]) = x[2n] + i x[2n+1]
-        for (int e = tid; e < NR * M; e += T) {
-            const int r = e / M, n = e - r * M;
-            const long long row = row0 + r;
-            if (row >= rows || 2 * n >= nx) continue;
-            const float2 vv = buf[r * LP + n];
-            const float x0 = vv.x * scale, x1 = -vv.y * scale;
-            float* __restrict__ o = out + row * nx + 2 * n;
-            if (2 * n + 1 < nx) {
-                if ((nx & 1) == 0) *reinterpret_cast<float2*>(o) = make_float2(x0, x1);
-                else { o[0] = x0; o[1] = x1; }
-                acc += (double)x0 + (double)x1;
+#pragma unroll
+        for (int jj = 0; jj < RB; ++jj) {
+            if (j0 + jj >= LW) break;
+            float2* zrow = wbuf + (j0 + jj) * LP;
+#pragma unroll
+            for (int it = 0; it < HIT; ++it) {
+                const int q = lane + it * 64;
+                if (q < HQ) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = 2 * q + h;
+                        const float2 a = h == 0 ? make_float2(xa[jj][it].x, xa[jj][it].y) : make_float2(xa[jj][it].z, xa[jj][it].w);
+                        const float2 b = cconj(h == 0 ? xb0[jj][it] : xb1[jj][it]);
+                        const float2 sm = cadd(a, b), d = csub(a, b);
+                        const float2 wd = cmul(cconj(twx[k]), d);                  // w^{-k} d
+                        const float2 t = make_float2(-wd.y, wd.x);                  // i w^{-k} d
+                        const float2 zk = cconj(cadd(sm, t));
+                        zrow[k] = live[jj] ? zk : make_float2(0.f, 0.f);
+                        if (k > 0) zrow[M - k] = live[jj] ? csub(sm, t) : make_float2(0.f, 0.f);
+                    }
+                }
+            }
+            // middle elements not covered by the pairs (k = M/2 when M % 4 == 0): generic, straight from HBM
+            for (int k = 2 * HQ + lane; k <= M - 2 * HQ && k < M; k += 64) {
+                float2 zk = make_float2(0.f, 0.f);
+                if (live[jj]) {
+                    const float2* __restrict__ sp = srcc + offs[jj];
+                    const float2 a = sp[k], b = cconj(sp[M - k]);
+                    const float2 sm = cadd(a, b), d = csub(a, b);
+                    const float2 wd = cmul(cconj(twx[k]), d);
+                    zk = cconj(cadd(sm, make_float2(-wd.y, wd.x)));
+                }
+                zrow[k] = zk;
+            }
+        }
+    }
+    __syncthreads();                                  // twiddle table complete (rows are wave-private)
+    PLAN::template run<LW>(wbuf, tw, lane);
+    // z[n] = conj(buf[n]) = x[2n] + i x[2n+1]; lane q writes x[4q..4q+3]
+    double acc = 0.0;
+    const bool vec_out = (nx & 3) == 0;
+    for (int j = 0; j < LW; ++j) {
+        const long long row = row0 + j;
+        if (row >= rows) break;
+        float* __restrict__ o = out + row * nx;
+        const float2* __restrict__ zrow = wbuf + j * LP;
+        for (int q = lane; 4 * q < nx; q += 64) {
+            const float2 z0 = zrow[2 * q];
+            const float2 z1 = (2 * q + 1 < M) ? zrow[2 * q + 1] : make_float2(0.f, 0.f);
+            const float x0 = z0.x * scale, x1 = -z0.y * scale, x2 = z1.x * scale, x3 = -z1.y * scale;
+            if (vec_out) {
+                *reinterpret_cast<float4*>(o + 4 * q) = make_float4(x0, x1, x2, x3);
+                acc += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
             } else {
-                o[0] = x0;
-                acc += (double)x0;
+                o[4 * q] = x0; acc += (double)x0;
+                if (4 * q + 1 < nx) { o[4 * q + 1] = x1; acc += (double)x1; }
+                if (4 * q + 2 < nx) { o[4 * q + 2] = x2; acc += (double)x2; }
+                if (4 * q + 3 < nx) { o[4 * q + 3] = x3; acc += (double)x3; }
             }
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    if (lane == 0) red[wave] = acc;
     __syncthreads();
     if (tid == 0) {
         double sum = 0.0;
-        for (int w = 0; w < T / 64; ++w) sum += red[w];
+        for (int w = 0; w < NW; ++w) sum += red[w];
         partial[blockIdx.x] = sum;
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, long long count,
-                                                         double* __restrict__ scal)
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partial, long long count,
+                                                          double* __restrict__ scal)
 {
-    __shared__ double sh[4];
-    double acc = 0.0;
-    for (long long i = threadIdx.x; i < count; i += 256) acc += partial[i];
+    __shared__ double sh[16];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    long long i = threadIdx.x;
+    for (; i + 3 * 1024 < count; i += 4 * 1024) {
+        a0 += partial[i];
+        a1 += partial[i + 1024];
+        a2 += partial[i + 2 * 1024];
+        a3 += partial[i + 3 * 1024];
+    }
+    for (; i < count; i += 1024) a0 += partial[i];
+    double acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) scal[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        scal[0] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------- size table
@@ -523,7 +666,7 @@ template <class PLAN>
 static int launch_r2c_t(hipStream_t s, const float* src, const SrcMap& map, float2* dst, const float2* tw,
                         const float2* twx, int hxp, long long rows)
 {
-    using C = Cfg<PLAN::len>;
+    using C = CfgX<PLAN::len>;
     const long long blocks = (rows + C::NL - 1) / C::NL;
     MVSIM_TRY(set_lds(k_fft_x_r2c<PLAN>, C::LDS));
     hipLaunchKernelGGL((k_fft_x_r2c<PLAN>), dim3((unsigned)blocks), dim3(C::T), C::LDS, s, src, map, dst, tw, twx, hxp, rows);
@@ -531,15 +674,13 @@ static int launch_r2c_t(hipStream_t s, const float* src, const SrcMap& map, floa
     return MVSIM_OK;
 }
 
-constexpr int C2R_MAX_BLOCKS = 2048;
-
 template <class PLAN>
 static int launch_c2r_t(hipStream_t s, const float2* srcc, float* out, const float2* tw, const float2* twx, int hxp,
                         int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks)
 {
-    using C = Cfg<PLAN::len>;
+    using C = CfgX<PLAN::len>;
     const long long groups = (rows + C::NL - 1) / C::NL;
-    const int blocks = (int)(groups < C2R_MAX_BLOCKS ? groups : C2R_MAX_BLOCKS);
+    const int blocks = (int)groups;
     *nblocks = blocks;
     MVSIM_TRY(set_lds(k_fft_x_c2r<PLAN>, C::LDS));
     hipLaunchKernelGGL((k_fft_x_c2r<PLAN>), dim3((unsigned)blocks), dim3(C::T), C::LDS, s, srcc, out, tw, twx, hxp, py, nx, ny,
@@ -586,7 +727,16 @@ static int launch_c2r(hipStream_t s, int M, const float2* srcc, float* out, cons
     return MVSIM_EINVAL;
 }
 
-static int lines_per_tile(int L) { return L <= 576 ? 16 : 8; }
+template <int L> static constexpr int nl_of() { return Cfg<L>::NL; }
+static int lines_per_tile(int L)
+{
+    switch (L) {
+#define X(LL, ...) case LL: return nl_of<LL>();
+        MVSIM_FFT_SIZES(X)
+#undef X
+    }
+    return 16;
+}
 
 static int pick_size(int64_t need)
 {
@@ -666,13 +816,14 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
     const int tw_max = tile_y > tile_z ? tile_y : tile_z;
     const int hxp = ((M + 1 + tw_max - 1) / tw_max) * tw_max;
     const size_t cbytes = (size_t)hxp * py * pz * sizeof(float2);
+    const long long rows_out_early = (long long)dim[1] * dim[2];
     MVSIM_TRY(ctx->cfft_f.reserve(cbytes));
     MVSIM_TRY(ctx->cfft_g.reserve(cbytes));
     // compact PSF intermediates: G1 [kz][ky][hxp] (x transformed), G2 [kz][py][hxp] (x,y transformed)
     MVSIM_TRY(ctx->cfft_g1.reserve((size_t)hxp * ky * kz * sizeof(float2)));
     MVSIM_TRY(ctx->cfft_g2.reserve((size_t)hxp * py * kz * sizeof(float2)));
     MVSIM_TRY(ctx->partials.reserve((size_t)(SUM_BLOCKS + 8) * sizeof(double)));
-    MVSIM_TRY(ctx->partials_e.reserve((size_t)C2R_MAX_BLOCKS * sizeof(double)));
+    MVSIM_TRY(ctx->partials_e.reserve((size_t)((rows_out_early + 3) / 4 + 16) * sizeof(double)));
     double* scal = ctx->partials.as<double>() + SUM_BLOCKS;
 
     const float2 *tw_m, *tw_px, *tw_py, *tw_pz;
@@ -740,11 +891,12 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
         MVSIM_TRY(launch_lines(s, pz, CONV, false, c, hxp / tile_z, py));
         b.tw = tw_py;
         MVSIM_TRY(launch_lines(s, py, INV, false, b, hxp / tile_y, (int)dim[2]));   // planes z >= Nz are never read
-        const float scale = (float)(1.0 / ((double)px * (double)py * (double)pz));
+        // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
+        const float scale = (float)(0.25 / ((double)px * (double)py * (double)pz));
         int nblk = 0;
         MVSIM_TRY(launch_c2r(s, M, F, out, tw_m, tw_px, hxp, py, (int)dim[0], (int)dim[1], rows_out, scale,
                              ctx->partials_e.as<double>(), &nblk));
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal);
         MVSIM_HIP(hipGetLastError());
     }
     ev_end(ctx, ST_CONVOLVE);
