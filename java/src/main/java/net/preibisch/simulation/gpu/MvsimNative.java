@@ -1,0 +1,38 @@
+package net.preibisch.simulation.gpu;
+
+import java.nio.FloatBuffer;
+
+/**
+ * JNI binding of libmvsim.so (C ABI in include/mvsim.h).  One native context per GPU; the context is
+ * not thread-safe, so {@link GpuContextPool} hands one to each calling thread.
+ *
+ * SOURCE ONLY in this repository: the build image has no JDK (no javac, no jni.h).  Compile on a host
+ * with a JDK: see INTEGRATION.md.
+ */
+final class MvsimNative
+{
+	static { System.loadLibrary( "mvsim_jni" ); }
+
+	private MvsimNative() {}
+
+	static native long create( int device );                          // mvsim_create
+	static native void destroy( long ctx );                           // mvsim_destroy
+	static native int deviceCount();                                  // mvsim_device_count
+
+	// all buffers are DIRECT FloatBuffers (x fastest); dim = {nx, ny, nz}
+	static native void rotateAroundAxis( long ctx, FloatBuffer in, long[] dim, int axis, int degrees, FloatBuffer out );
+	static native void attenuate3d( long ctx, FloatBuffer in, long[] dim, double delta, FloatBuffer out );
+	static native void normImage( long ctx, FloatBuffer img, long n );
+	static native void convolve( long ctx, FloatBuffer img, long[] dim, FloatBuffer psf, long[] kdim, int method, FloatBuffer out );
+	static native double adjustImage( long ctx, FloatBuffer img, long n, float minValue, float targetAverage );
+	static native void extractSlices( long ctx, FloatBuffer in, long[] dim, int inc, float snr, long seed, int stream, FloatBuffer out );
+	static native void poissonProcess( long ctx, FloatBuffer img, long n, double snr, long seed, int stream, long indexOffset );
+	static native void makeIsotropic( long ctx, FloatBuffer in, long[] dim, int inc, FloatBuffer out );
+	static native void computeWeightImage( long ctx, long[] dim, FloatBuffer out );
+	static native void axisRotation( long[] dim, int axis, int degrees, double[] m12 );
+
+	/** Fused loop body of SimulateMultiViewDataset.main (:570-585); rot/att/con may be null. */
+	static native double simulateView( long ctx, FloatBuffer gt, long[] dim, FloatBuffer psf, long[] kdim,
+			int axis, int degrees, double delta, float minValue, float targetAverage, int inc, float snr, long seed, int stream,
+			FloatBuffer rot, FloatBuffer att, FloatBuffer con, FloatBuffer acq );
+}

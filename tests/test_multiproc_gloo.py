@@ -1,0 +1,31 @@
+"""World-size-2 CPU rehearsal (gloo) of the multi-GPU path: view sharding, ground-truth broadcast,
+communicator-id distribution and max-over-ranks timing.  The RCCL broadcast itself needs GPUs and is
+exercised by bench.py --gpus N on the driver's 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_sharding_and_broadcast(tmp_path):
+    out = tmp_path / "result.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "tests", "_gloo_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.load(open(out))
+    g = sorted(res["gathered"], key=lambda d: d["rank"])
+    assert [d["rank"] for d in g] == [0, 1]
+    views = sorted(v for d in g for v in d["views"])
+    assert views == list(range(res["n_views"]))                    # a partition: nothing lost, nothing doubled
+    assert g[0]["views"] == list(range(0, 16, 2)) and g[1]["views"] == list(range(1, 16, 2))
+    assert len(g[0]["views"]) == len(g[1]["views"]) == 8           # weak scaling: 8 views per rank
+    assert g[0]["gt_sum"] == g[1]["gt_sum"] and g[0]["gt_sum"] > 0  # broadcast delivered the same volume
+    assert g[0]["uid_len"] == g[1]["uid_len"] == 128
+    assert res["tmax"] == 2.0
+    angs = sorted(a for d in g for a in d["angles"])
+    assert angs == [15 + (360 * v) // 16 for v in range(16)]
