@@ -5,8 +5,9 @@
 // Generator : Philox4x32-10, key = 64-bit seed
 // Sampler   : lambda < 10  -> inversion by sequential search on a 32-bit uniform; the 4 voxels of
 //                             group index>>2 share ONE Philox block, ctr = (index>>2, stream, 0)
-//             lambda >= 10 -> Hoermann's PTRS transformed rejection, one Philox block per attempt,
-//                             ctr = (index, stream, attempt+1)
+//             lambda >= 10 -> Hoermann's PTRS transformed rejection on 32-bit uniforms; attempt 0 of the
+//                             voxel pair index>>1 shares one block, ctr = (index>>1, stream, 1); retries
+//                             take two attempts per block, ctr = (index, stream, 2 + (a-1)/2)
 // All accept/reject arithmetic is IEEE +,-,*,/,sqrt,fma on doubles plus the bit-defined log/exp
 // below (built with -ffp-contract=off), so a CPU implementation of the same recipe gives
 // identical counts.
@@ -26,8 +27,11 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32 -> 64 multiply per product (v_mad_u64_u32) instead of separate mul_hi / mul_lo
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -91,28 +95,14 @@ __device__ __forceinline__ double det_exp_neg(double lambda)
 }
 
 // log(k!) : table to 16, Stirling series beyond.
+__device__ const double kLogFact[17] = {
+    0.0, 0.0, 0.6931471805599453, 1.791759469228055, 3.1780538303479458, 4.787491742782046, 6.579251212010101,
+    8.525161361065415, 10.60460290274525, 12.801827480081469, 15.104412573075516, 17.502307845873887,
+    19.987214495661885, 22.552163853123425, 25.19122118273868, 27.89927138384089, 30.671860106080672};
+
 __device__ __forceinline__ double det_lgamma_int(long long k)
 {
-    switch (k) {
-        case 0: case 1: return 0.0;
-        case 2: return 0.6931471805599453;
-        case 3: return 1.791759469228055;
-        case 4: return 3.1780538303479458;
-        case 5: return 4.787491742782046;
-        case 6: return 6.579251212010101;
-        case 7: return 8.525161361065415;
-        case 8: return 10.60460290274525;
-        case 9: return 12.801827480081469;
-        case 10: return 15.104412573075516;
-        case 11: return 17.502307845873887;
-        case 12: return 19.987214495661885;
-        case 13: return 22.552163853123425;
-        case 14: return 25.19122118273868;
-        case 15: return 27.89927138384089;
-        case 16: return 30.671860106080672;
-        default: break;
-    }
-    if (k < 0) return 0.0;
+    if (k <= 16) return kLogFact[k < 0 ? 0 : k];
     const double x = (double)k + 1.0;
     const double ix = 1.0 / x;
     const double ix2 = ix * ix;
@@ -144,8 +134,13 @@ __device__ __forceinline__ float poisson_small(double lambda, uint32_t w)
     return (float)k;
 }
 
-// Hoermann PTRS for lambda >= 10; one Philox block per attempt, ctr = (index, stream, attempt + 1).
-__device__ __forceinline__ float poisson_ptrs(double lambda, uint32_t k0, uint32_t k1, uint32_t stream, uint64_t index)
+__device__ __forceinline__ double u32_open(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
+
+// Hoermann PTRS for lambda >= 10 on 32-bit uniforms.  (w0, w1) are the attempt-0 words, taken by the caller
+// from the block shared by the voxel pair index>>1; retries draw ctr = (index, stream, 2 + (a-1)/2), two
+// attempts per block.
+__device__ __forceinline__ float poisson_ptrs(double lambda, uint32_t w0, uint32_t w1, uint32_t k0, uint32_t k1,
+                                              uint32_t stream, uint64_t index)
 {
     const uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32);
     const double slam = sqrt(lambda);
@@ -157,10 +152,18 @@ __device__ __forceinline__ float poisson_ptrs(double lambda, uint32_t k0, uint32
     const double ianum = 1.1239 * bm34 + 1.1328;     // invalpha = ianum / bm34
     double loglam = 0.0;
     bool have_loglam = false;
-    for (uint32_t attempt = 0; attempt < 0xFFFFFFFEu; ++attempt) {
-        const Philox4 r = philox4x32_10(c0, c1, stream, attempt + 1u, k0, k1);
-        const double U = u53(r.x, r.y) - 0.5;
-        const double V = u53(r.z, r.w);
+    Philox4 r = Philox4{0u, 0u, 0u, 0u};
+    for (uint32_t attempt = 0; attempt < 0xFFFFFFF0u; ++attempt) {
+        if (attempt > 0) {
+            if (((attempt - 1u) & 1u) == 0u) {
+                r = philox4x32_10(c0, c1, stream, 2u + (attempt - 1u) / 2u, k0, k1);
+                w0 = r.x; w1 = r.y;
+            } else {
+                w0 = r.z; w1 = r.w;
+            }
+        }
+        const double U = u32_open(w0) - 0.5;
+        const double V = u32_open(w1);
         const double us = 0.5 - fabs(U);
         const double kd = floor((2.0 * a / us + b) * U + lambda + 0.43);
         if (us >= 0.07 && V * bm2 <= vrq) return (float)(long long)kd;
@@ -175,7 +178,7 @@ __device__ __forceinline__ float poisson_ptrs(double lambda, uint32_t k0, uint32
     return (float)lambda;
 }
 
-// Counter sampler v2 for one voxel (generic path: recomputes the group block of index >> 2).
+// Counter sampler v3 for one voxel (generic path: recomputes the shared blocks of index>>2 / index>>1).
 // lambda <= 0 or NaN -> 0 (the reference's loop does not terminate there; documented deviation Q9).
 __device__ __forceinline__ float poisson_counter(double lambda, uint32_t k0, uint32_t k1, uint32_t stream,
                                                  uint64_t index)
@@ -188,10 +191,13 @@ __device__ __forceinline__ float poisson_counter(double lambda, uint32_t k0, uin
         const uint32_t w = lane == 0 ? r.x : (lane == 1 ? r.y : (lane == 2 ? r.z : r.w));
         return poisson_small(lambda, w);
     }
-    return poisson_ptrs(lambda, k0, k1, stream, index);
+    const uint64_t pr = index >> 1;
+    const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
+    const bool odd = (index & 1) != 0;
+    return poisson_ptrs(lambda, odd ? r.z : r.x, odd ? r.w : r.y, k0, k1, stream, index);
 }
 
-// Four voxels index4 .. index4+3 (index4 % 4 == 0) sharing their group block.
+// Four voxels index4 .. index4+3 (index4 % 4 == 0) sharing their group / pair blocks.
 __device__ __forceinline__ float4 poisson_counter4(double l0, double l1, double l2, double l3, uint32_t k0,
                                                    uint32_t k1, uint32_t stream, uint64_t index4)
 {
@@ -206,10 +212,19 @@ __device__ __forceinline__ float4 poisson_counter4(double l0, double l1, double 
         if (s2) out.z = poisson_small(l2, r.z);
         if (s3) out.w = poisson_small(l3, r.w);
     }
-    if (l0 >= 10.0) out.x = poisson_ptrs(l0, k0, k1, stream, index4);
-    if (l1 >= 10.0) out.y = poisson_ptrs(l1, k0, k1, stream, index4 + 1);
-    if (l2 >= 10.0) out.z = poisson_ptrs(l2, k0, k1, stream, index4 + 2);
-    if (l3 >= 10.0) out.w = poisson_ptrs(l3, k0, k1, stream, index4 + 3);
+    const bool b0 = l0 >= 10.0, b1 = l1 >= 10.0, b2 = l2 >= 10.0, b3 = l3 >= 10.0;
+    if (b0 || b1) {
+        const uint64_t pr = index4 >> 1;
+        const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
+        if (b0) out.x = poisson_ptrs(l0, r.x, r.y, k0, k1, stream, index4);
+        if (b1) out.y = poisson_ptrs(l1, r.z, r.w, k0, k1, stream, index4 + 1);
+    }
+    if (b2 || b3) {
+        const uint64_t pr = (index4 >> 1) + 1;
+        const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
+        if (b2) out.z = poisson_ptrs(l2, r.x, r.y, k0, k1, stream, index4 + 2);
+        if (b3) out.w = poisson_ptrs(l3, r.z, r.w, k0, k1, stream, index4 + 3);
+    }
     return out;
 }
 

@@ -157,11 +157,6 @@ double orc_det_lgamma_int(int64_t k)
     return ((x - 0.5) * orc_det_log(x) - x) + 0.9189385332046727 + ser;
 }
 
-static double u53(uint32_t a, uint32_t b)
-{
-    return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * 0x1.0p-53;
-}
-
 /* exp(-lambda) for 0 < lambda < 10, division free: 2^k * sum_{n<=13} r^n/n! by Horner with
  * explicit fused multiply-adds (correctly rounded on every platform). */
 double orc_det_exp_neg(double lambda)
@@ -186,14 +181,17 @@ double orc_det_exp_neg(double lambda)
     return p * bits2d((uint64_t)((int)kf + 1023) << 52);
 }
 
-/* O(1) Poisson sampler keyed by (seed, stream, index)  -- "counter sampler v2".
+/* O(1) Poisson sampler keyed by (seed, stream, index)  -- "counter sampler v3".
  *   lambda <= 0 or NaN : 0 (Q9: the reference loops forever there)
  *   lambda < 10        : inversion by sequential search on a 32-bit uniform; the four voxels
- *                        index>>2 share one Philox block (ctr = (index>>2, stream, 0)), voxel
- *                        index&3 takes word index&3; p_{k} = p_{k-1} * lambda * (1/k)
- *   lambda >= 10       : Hoermann's PTRS transformed rejection, one Philox block per attempt
- *                        (ctr = (index, stream, attempt+1)); divisions folded out of the
- *                        squeeze, logs merged in the exact test. */
+ *                        index>>2 share one Philox block, ctr = (index>>2, stream, 0), voxel
+ *                        index&3 takes word index&3; p_k = p_{k-1} * lambda * (1/k)
+ *   lambda >= 10       : Hoermann's PTRS transformed rejection on 32-bit uniforms (U, V):
+ *                        attempt 0 : block ctr = (index>>1, stream, 1), words 2*(index&1), +1
+ *                        attempt a>=1 : block ctr = (index, stream, 2 + (a-1)/2), words 2*((a-1)&1), +1
+ *                        divisions folded out of the squeeze, logs merged in the exact test. */
+static double u32_open(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
+
 int64_t orc_poisson_counter(double lambda, uint64_t seed, uint32_t stream, uint64_t index)
 {
     if (!(lambda > 0.0)) return 0;
@@ -203,7 +201,7 @@ int64_t orc_poisson_counter(double lambda, uint64_t seed, uint32_t stream, uint6
         const uint64_t g = index >> 2;
         uint32_t ctr[4] = { (uint32_t)g, (uint32_t)(g >> 32), stream, 0u };
         orc_philox4x32_10(ctr, key, r);
-        const double u = ((double)r[index & 3] + 0.5) * 0x1.0p-32;
+        const double u = u32_open(r[index & 3]);
         double p = orc_det_exp_neg(lambda);
         double F = p;
         int64_t k = 0;
@@ -214,7 +212,6 @@ int64_t orc_poisson_counter(double lambda, uint64_t seed, uint32_t stream, uint6
         }
         return k;
     }
-    uint32_t ctr[4] = { (uint32_t)index, (uint32_t)(index >> 32), stream, 1u };
     const double slam = sqrt(lambda);
     const double b = 0.931 + 2.53 * slam;
     const double a = -0.059 + 0.02483 * b;
@@ -224,11 +221,22 @@ int64_t orc_poisson_counter(double lambda, uint64_t seed, uint32_t stream, uint6
     const double ianum = 1.1239 * bm34 + 1.1328;         /* invalpha = ianum / bm34 */
     double loglam = 0.0;
     int have_loglam = 0;
-    for (uint32_t attempt = 0; attempt < 0xFFFFFFFEu; ++attempt) {
-        ctr[3] = attempt + 1u;
-        orc_philox4x32_10(ctr, key, r);
-        const double U = u53(r[0], r[1]) - 0.5;
-        const double V = u53(r[2], r[3]);
+    for (uint32_t attempt = 0; attempt < 0xFFFFFFF0u; ++attempt) {
+        uint32_t w0, w1;
+        if (attempt == 0) {
+            const uint64_t pr = index >> 1;
+            uint32_t ctr[4] = { (uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u };
+            orc_philox4x32_10(ctr, key, r);
+            w0 = r[2 * (index & 1)]; w1 = r[2 * (index & 1) + 1];
+        } else {
+            if ((attempt - 1) % 2 == 0) {
+                uint32_t ctr[4] = { (uint32_t)index, (uint32_t)(index >> 32), stream, 2u + (attempt - 1) / 2 };
+                orc_philox4x32_10(ctr, key, r);
+            }
+            w0 = r[2 * ((attempt - 1) & 1)]; w1 = r[2 * ((attempt - 1) & 1) + 1];
+        }
+        const double U = u32_open(w0) - 0.5;
+        const double V = u32_open(w1);
         const double us = 0.5 - fabs(U);
         const double kd = floor((2.0 * a / us + b) * U + lambda + 0.43);
         if (us >= 0.07 && V * bm2 <= vrq) return (int64_t)kd;

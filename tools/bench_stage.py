@@ -36,6 +36,11 @@ def main():
         ctx.upload(d_in, mix)
         ms = timeit(ctx, lambda: ctx.extract_slices_dev(d_in, dims, 1, 25.0, 1234, 0, d_out), "extract_ms")
         print(f"random 20% bright mix  : {ms:8.3f} ms")
+    elif which == "poisson1":
+        val = float(sys.argv[3])
+        ctx.upload(d_in, np.full(n ** 3, val, np.float32))
+        ms = timeit(ctx, lambda: ctx.extract_slices_dev(d_in, dims, 1, 25.0, 1234, 0, d_out), "extract_ms", reps=2)
+        print(f"poisson value {val}: {ms:8.3f} ms")
     elif which == "rotate":
         ctx.upload(d_in, synth.sphere_phantom(n))
         for deg in (0, 15, 60, 90):
