@@ -4,6 +4,8 @@
 #include "common.h"
 #include "poisson_dev.h"
 
+#include <cstdlib>
+
 namespace mvsim {
 
 // ------------------------------------------------------------------------------------------------
@@ -363,6 +365,133 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
     }
 }
 
+// Noise form for production sizes.  Phase 1 (every lane busy): adjust, the low-lambda inversion and the
+// attempt-0 squeeze of PTRS for the lane's 4 voxels.  The ~14 % of bright voxels that need the exact test or a
+// retry go into a block-level work queue in LDS and are processed COMPACTED, one attempt per pass, so the
+// divergent fp64 code (logs, divisions) runs with full waves instead of once per voxel slot with 1-in-7 lanes
+// active.  Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.
+struct PItem {
+    unsigned long long index;
+    float v;
+    unsigned short slot, attempt;
+};
+
+template <bool ADJUST>
+__global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict__ in, float* __restrict__ out,
+                                                        long long plane4, long long nzo, int inc,
+                                                        const double* __restrict__ scal, float min_value, double mul,
+                                                        uint32_t k0, uint32_t k1, uint32_t stream,
+                                                        unsigned long long index_offset)
+{
+    __shared__ PItem q[2][1024];
+    __shared__ float res[1024];
+    __shared__ int qn[2];
+    double corr = 1.0;
+    if (ADJUST) corr = scal[1];
+    const int tid = threadIdx.x;
+    const long long total4 = plane4 * nzo;
+    const long long stride = (long long)gridDim.x * 256;
+    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+    for (long long base = (long long)blockIdx.x * 256; base < total4; base += stride) {
+        const long long o = base + tid;
+        const bool active = o < total4;
+        if (tid == 0) { qn[0] = 0; qn[1] = 0; }
+        __syncthreads();
+        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t pend = 0u;
+        if (active) {
+            const long long k = o / plane4;
+            const long long i = o - k * plane4;
+            const long long src4 = k * inc * plane4 + i;
+            float4 v = in4[src4];
+            if (ADJUST) {
+                v.x = adjust_one(v.x, corr, min_value);
+                v.y = adjust_one(v.y, corr, min_value);
+                v.z = adjust_one(v.z, corr, min_value);
+                v.w = adjust_one(v.w, corr, min_value);
+            }
+            const unsigned long long index4 = index_offset + 4ull * (unsigned long long)src4;
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            double lam[4];
+            bool small_any = false, bright01 = false, bright23 = false;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                lam[c] = (double)vv[c] * mul;
+                small_any |= lam[c] > 0.0 && lam[c] < 10.0;
+            }
+            bright01 = lam[0] >= 10.0 || lam[1] >= 10.0;
+            bright23 = lam[2] >= 10.0 || lam[3] >= 10.0;
+            float ov[4] = {0.f, 0.f, 0.f, 0.f};
+            if (small_any) {
+                const unsigned long long g = index4 >> 2;
+                const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream, 0u, k0, k1);
+                const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (lam[c] > 0.0 && lam[c] < 10.0) ov[c] = poisson_small(lam[c], w[c]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 0 ? bright01 : bright23) {
+                    const unsigned long long pr = (index4 >> 1) + (unsigned long long)h;
+                    const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
+                    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int c = 2 * h + e;
+                        if (lam[c] >= 10.0) {
+                            double us, V, kd;
+                            const int st = ptrs_fast(ptrs_setup(lam[c]), lam[c], w[2 * e], w[2 * e + 1], us, V, kd);
+                            if (st == 0) {
+                                ov[c] = (float)(long long)kd;
+                            } else {
+                                const int pos = atomicAdd(&qn[0], 1);
+                                PItem it;
+                                it.index = index4 + (unsigned long long)c;
+                                it.v = vv[c];
+                                it.slot = (unsigned short)(tid * 4 + c);
+                                it.attempt = (unsigned short)(st == 2 ? 0 : 1);   // exact test of attempt 0, or straight to a retry
+                                q[0][pos] = it;
+                                pend |= 1u << c;
+                            }
+                        }
+                    }
+                }
+            }
+            r4 = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        }
+        int cur = 0;
+        for (;;) {
+            __syncthreads();                       // pushes into q[cur] are complete
+            const int n = qn[cur];
+            if (n == 0) break;
+            for (int i = tid; i < n; i += 256) {
+                const PItem it = q[cur][i];
+                float val;
+                if (ptrs_step((double)it.v * mul, it.index, (uint32_t)it.attempt, k0, k1, stream, val)) {
+                    res[it.slot] = val;
+                } else {
+                    const int pos = atomicAdd(&qn[cur ^ 1], 1);
+                    PItem nx = it;
+                    nx.attempt = (unsigned short)(it.attempt + 1);
+                    q[cur ^ 1][pos] = nx;
+                }
+            }
+            __syncthreads();                       // q[cur] / qn[cur] fully consumed
+            if (tid == 0) qn[cur] = 0;
+            cur ^= 1;
+        }
+        if (active) {
+            if (pend & 1u) r4.x = res[tid * 4 + 0];
+            if (pend & 2u) r4.y = res[tid * 4 + 1];
+            if (pend & 4u) r4.z = res[tid * 4 + 2];
+            if (pend & 8u) r4.w = res[tid * 4 + 3];
+            out4[o] = r4;
+        }
+    }
+}
+
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
                    uint32_t stream, uint64_t index_offset)
@@ -379,7 +508,15 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
 #define MVSIM_LAUNCH_EX4(A, N)                                                                               \
     hipLaunchKernelGGL((k_extract4<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, scal, \
                        min_value, mul, k0, k1, stream, (unsigned long long)index_offset)
-        if (adjust && noise) MVSIM_LAUNCH_EX4(true, true);
+        if (noise && !getenv("MVSIM_POISSON_NOQUEUE")) {
+            if (adjust)
+                hipLaunchKernelGGL((k_extract4_noise<true>), dim3(blocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
+                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset);
+            else
+                hipLaunchKernelGGL((k_extract4_noise<false>), dim3(blocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
+                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset);
+        }
+        else if (adjust && noise) MVSIM_LAUNCH_EX4(true, true);
         else if (adjust) MVSIM_LAUNCH_EX4(true, false);
         else if (noise) MVSIM_LAUNCH_EX4(false, true);
         else MVSIM_LAUNCH_EX4(false, false);

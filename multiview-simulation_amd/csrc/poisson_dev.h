@@ -136,46 +136,115 @@ __device__ __forceinline__ float poisson_small(double lambda, uint32_t w)
 
 __device__ __forceinline__ double u32_open(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
 
-// Hoermann PTRS for lambda >= 10 on 32-bit uniforms.  (w0, w1) are the attempt-0 words, taken by the caller
-// from the block shared by the voxel pair index>>1; retries draw ctr = (index, stream, 2 + (a-1)/2), two
-// attempts per block.
+constexpr uint32_t kPtrsMaxAttempts = 60000u;   // cap (never reached in practice: p ~ 0.1^k); then floor(lambda)
+
+// ---- Hoermann PTRS for lambda >= 10 on 32-bit uniforms, split into pieces so that the one-voxel and the
+// four-voxel drivers execute exactly the same arithmetic.
+struct PtrsSetup {
+    double b, a, bm2, vrq, bm34, ianum;
+};
+
+__device__ __forceinline__ PtrsSetup ptrs_setup(double lambda)
+{
+    PtrsSetup s;
+    const double slam = sqrt(lambda);
+    s.b = 0.931 + 2.53 * slam;
+    s.a = -0.059 + 0.02483 * s.b;
+    s.bm2 = s.b - 2.0;
+    s.vrq = 0.9277 * s.bm2 - 3.6224;        // V <= vr  <=>  V*(b-2) <= 0.9277*(b-2) - 3.6224
+    s.bm34 = s.b - 3.4;
+    s.ianum = 1.1239 * s.bm34 + 1.1328;      // invalpha = ianum / bm34
+    return s;
+}
+
+// One attempt's squeeze.  Returns 0: accepted (kd is the sample), 1: rejected, 2: needs the exact test.
+__device__ __forceinline__ int ptrs_fast(const PtrsSetup& s, double lambda, uint32_t w0, uint32_t w1, double& us,
+                                         double& V, double& kd)
+{
+    const double U = u32_open(w0) - 0.5;
+    V = u32_open(w1);
+    us = 0.5 - fabs(U);
+    kd = floor((2.0 * s.a / us + s.b) * U + lambda + 0.43);
+    if (us >= 0.07 && V * s.bm2 <= s.vrq) return 0;
+    if (kd < 0.0 || (us < 0.013 && V > us)) return 1;
+    return 2;
+}
+
+// The exact acceptance test of one attempt.
+__device__ __forceinline__ bool ptrs_exact(const PtrsSetup& s, double lambda, double us, double V, double kd,
+                                           double& loglam, bool& have_loglam)
+{
+    const double us2 = us * us;
+    const double lhs = det_log((V * us2 * s.ianum) / (s.bm34 * (s.a + s.b * us2)));
+    if (!have_loglam) { loglam = det_log(lambda); have_loglam = true; }
+    const double rhs = (-lambda + kd * loglam) - det_lgamma_int((long long)kd);
+    return lhs <= rhs;
+}
+
+// Retry attempts a >= 1 until accepted: ctr = (index, stream, 2 + (a-1)/2), two attempts per block.
+__device__ __forceinline__ double ptrs_retry(const PtrsSetup& s, double lambda, double& loglam, bool& have_loglam,
+                                             uint32_t k0, uint32_t k1, uint32_t stream, uint64_t index)
+{
+    const uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32);
+    Philox4 r = Philox4{0u, 0u, 0u, 0u};
+    for (uint32_t attempt = 1; attempt < kPtrsMaxAttempts; ++attempt) {
+        uint32_t w0, w1;
+        if (((attempt - 1u) & 1u) == 0u) {
+            r = philox4x32_10(c0, c1, stream, 2u + (attempt - 1u) / 2u, k0, k1);
+            w0 = r.x; w1 = r.y;
+        } else {
+            w0 = r.z; w1 = r.w;
+        }
+        double us, V, kd;
+        const int st = ptrs_fast(s, lambda, w0, w1, us, V, kd);
+        if (st == 0) return kd;
+        if (st == 2 && ptrs_exact(s, lambda, us, V, kd, loglam, have_loglam)) return kd;
+    }
+    return lambda;
+}
+
+// One attempt of one voxel, self-contained (used by the block-level work queue of k_extract4_noise): returns
+// true when the voxel is resolved.  attempt == kPtrsMaxAttempts resolves to floor(lambda).
+__device__ __forceinline__ bool ptrs_step(double lambda, uint64_t index, uint32_t attempt, uint32_t k0, uint32_t k1,
+                                          uint32_t stream, float& res)
+{
+    if (attempt >= kPtrsMaxAttempts) { res = (float)(long long)lambda; return true; }
+    const PtrsSetup s = ptrs_setup(lambda);
+    uint32_t w0, w1;
+    if (attempt == 0u) {
+        const uint64_t pr = index >> 1;
+        const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
+        const bool odd = (index & 1) != 0;
+        w0 = odd ? r.z : r.x; w1 = odd ? r.w : r.y;
+    } else {
+        const Philox4 r = philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), stream, 2u + (attempt - 1u) / 2u, k0, k1);
+        const bool second = ((attempt - 1u) & 1u) != 0u;
+        w0 = second ? r.z : r.x; w1 = second ? r.w : r.y;
+    }
+    double us, V, kd;
+    const int st = ptrs_fast(s, lambda, w0, w1, us, V, kd);
+    if (st == 1) return false;
+    if (st == 2) {
+        double loglam = 0.0;
+        bool have = false;
+        if (!ptrs_exact(s, lambda, us, V, kd, loglam, have)) return false;
+    }
+    res = (float)(long long)kd;
+    return true;
+}
+
+// (w0, w1) are the attempt-0 words, taken by the caller from the block shared by the voxel pair index>>1.
 __device__ __forceinline__ float poisson_ptrs(double lambda, uint32_t w0, uint32_t w1, uint32_t k0, uint32_t k1,
                                               uint32_t stream, uint64_t index)
 {
-    const uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32);
-    const double slam = sqrt(lambda);
-    const double b = 0.931 + 2.53 * slam;
-    const double a = -0.059 + 0.02483 * b;
-    const double bm2 = b - 2.0;
-    const double vrq = 0.9277 * bm2 - 3.6224;       // V <= vr  <=>  V*(b-2) <= 0.9277*(b-2) - 3.6224
-    const double bm34 = b - 3.4;
-    const double ianum = 1.1239 * bm34 + 1.1328;     // invalpha = ianum / bm34
+    const PtrsSetup s = ptrs_setup(lambda);
     double loglam = 0.0;
     bool have_loglam = false;
-    Philox4 r = Philox4{0u, 0u, 0u, 0u};
-    for (uint32_t attempt = 0; attempt < 0xFFFFFFF0u; ++attempt) {
-        if (attempt > 0) {
-            if (((attempt - 1u) & 1u) == 0u) {
-                r = philox4x32_10(c0, c1, stream, 2u + (attempt - 1u) / 2u, k0, k1);
-                w0 = r.x; w1 = r.y;
-            } else {
-                w0 = r.z; w1 = r.w;
-            }
-        }
-        const double U = u32_open(w0) - 0.5;
-        const double V = u32_open(w1);
-        const double us = 0.5 - fabs(U);
-        const double kd = floor((2.0 * a / us + b) * U + lambda + 0.43);
-        if (us >= 0.07 && V * bm2 <= vrq) return (float)(long long)kd;
-        if (kd < 0.0 || (us < 0.013 && V > us)) continue;
-        const long long k = (long long)kd;
-        const double us2 = us * us;
-        const double lhs = det_log((V * us2 * ianum) / (bm34 * (a + b * us2)));
-        if (!have_loglam) { loglam = det_log(lambda); have_loglam = true; }
-        const double rhs = (-lambda + kd * loglam) - det_lgamma_int(k);
-        if (lhs <= rhs) return (float)k;
-    }
-    return (float)lambda;
+    double us, V, kd;
+    const int st = ptrs_fast(s, lambda, w0, w1, us, V, kd);
+    if (st == 0) return (float)(long long)kd;
+    if (st == 2 && ptrs_exact(s, lambda, us, V, kd, loglam, have_loglam)) return (float)(long long)kd;
+    return (float)(long long)ptrs_retry(s, lambda, loglam, have_loglam, k0, k1, stream, index);
 }
 
 // Counter sampler v3 for one voxel (generic path: recomputes the shared blocks of index>>2 / index>>1).
@@ -212,18 +281,54 @@ __device__ __forceinline__ float4 poisson_counter4(double l0, double l1, double 
         if (s2) out.z = poisson_small(l2, r.z);
         if (s3) out.w = poisson_small(l3, r.w);
     }
+    // Bright voxels.  Phase 1: the attempt-0 squeeze of every bright voxel of the lane (all lanes busy).
+    // Phase 2: the unresolved voxels (exact test and/or retries, ~14 %) are processed one per lane per round, so
+    // the expensive divergent code runs max-pending-per-lane times per wave instead of once per voxel slot.
     const bool b0 = l0 >= 10.0, b1 = l1 >= 10.0, b2 = l2 >= 10.0, b3 = l3 >= 10.0;
+    uint32_t pend = 0u;                       // bit v: unresolved; bit 4+v: attempt 0 still needs its exact test
+    double pus[4], pV[4], pkd[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { pus[v] = 0.0; pV[v] = 0.0; pkd[v] = 0.0; }
     if (b0 || b1) {
         const uint64_t pr = index4 >> 1;
         const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
-        if (b0) out.x = poisson_ptrs(l0, r.x, r.y, k0, k1, stream, index4);
-        if (b1) out.y = poisson_ptrs(l1, r.z, r.w, k0, k1, stream, index4 + 1);
+        if (b0) {
+            const int st = ptrs_fast(ptrs_setup(l0), l0, r.x, r.y, pus[0], pV[0], pkd[0]);
+            if (st == 0) out.x = (float)(long long)pkd[0]; else pend |= (st == 2 ? 0x11u : 0x01u);
+        }
+        if (b1) {
+            const int st = ptrs_fast(ptrs_setup(l1), l1, r.z, r.w, pus[1], pV[1], pkd[1]);
+            if (st == 0) out.y = (float)(long long)pkd[1]; else pend |= (st == 2 ? 0x22u : 0x02u);
+        }
     }
     if (b2 || b3) {
         const uint64_t pr = (index4 >> 1) + 1;
         const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
-        if (b2) out.z = poisson_ptrs(l2, r.x, r.y, k0, k1, stream, index4 + 2);
-        if (b3) out.w = poisson_ptrs(l3, r.z, r.w, k0, k1, stream, index4 + 3);
+        if (b2) {
+            const int st = ptrs_fast(ptrs_setup(l2), l2, r.x, r.y, pus[2], pV[2], pkd[2]);
+            if (st == 0) out.z = (float)(long long)pkd[2]; else pend |= (st == 2 ? 0x44u : 0x04u);
+        }
+        if (b3) {
+            const int st = ptrs_fast(ptrs_setup(l3), l3, r.z, r.w, pus[3], pV[3], pkd[3]);
+            if (st == 0) out.w = (float)(long long)pkd[3]; else pend |= (st == 2 ? 0x88u : 0x08u);
+        }
+    }
+    while (pend & 0xFu) {
+        const int v = __ffs((int)(pend & 0xFu)) - 1;
+        const double lam = v == 0 ? l0 : (v == 1 ? l1 : (v == 2 ? l2 : l3));
+        const double us = v == 0 ? pus[0] : (v == 1 ? pus[1] : (v == 2 ? pus[2] : pus[3]));
+        const double V = v == 0 ? pV[0] : (v == 1 ? pV[1] : (v == 2 ? pV[2] : pV[3]));
+        const double kd0 = v == 0 ? pkd[0] : (v == 1 ? pkd[1] : (v == 2 ? pkd[2] : pkd[3]));
+        const bool exact0 = ((pend >> (4 + v)) & 1u) != 0u;
+        const PtrsSetup s = ptrs_setup(lam);
+        double loglam = 0.0;
+        bool have_loglam = false;
+        double res;
+        if (exact0 && ptrs_exact(s, lam, us, V, kd0, loglam, have_loglam)) res = kd0;
+        else res = ptrs_retry(s, lam, loglam, have_loglam, k0, k1, stream, index4 + (uint64_t)v);
+        const float fr = (float)(long long)res;
+        if (v == 0) out.x = fr; else if (v == 1) out.y = fr; else if (v == 2) out.z = fr; else out.w = fr;
+        pend &= ~(0x11u << v);
     }
     return out;
 }

@@ -221,7 +221,7 @@ int64_t orc_poisson_counter(double lambda, uint64_t seed, uint32_t stream, uint6
     const double ianum = 1.1239 * bm34 + 1.1328;         /* invalpha = ianum / bm34 */
     double loglam = 0.0;
     int have_loglam = 0;
-    for (uint32_t attempt = 0; attempt < 0xFFFFFFF0u; ++attempt) {
+    for (uint32_t attempt = 0; attempt < 60000u; ++attempt) {   /* cap: never reached in practice (p ~ 0.1^k) */
         uint32_t w0, w1;
         if (attempt == 0) {
             const uint64_t pr = index >> 1;
