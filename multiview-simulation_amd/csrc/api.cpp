@@ -461,10 +461,7 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     float* rot = o->rot;
     float* att = o->att;
     float* con = o->con;
-    if (!rot) { MVSIM_TRY(ctx->vol_a.reserve(vbytes)); rot = ctx->vol_a.as<float>(); }
     if (!att) { MVSIM_TRY(ctx->vol_b.reserve(vbytes)); att = ctx->vol_b.as<float>(); }
-    if (!con) con = rot == ctx->vol_a.as<float>() ? rot : nullptr;   // reuse the rot scratch for con
-    if (!con) { MVSIM_TRY(ctx->vol_c.reserve(vbytes)); con = ctx->vol_c.as<float>(); }
 
     MVSIM_TRY(psf_prepare(ctx, psf_host, kdim, dim));
 
@@ -472,13 +469,21 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     Affine inv;
     axis_rotation_host(dim, p->axis, p->degrees, m);
     affine_invert_host(m, inv.m);
+    // rotation about x: rotate and attenuate run as one kernel and `rot` is written only when requested
+    bool fused = false;
     ev_begin(ctx, ST_ROTATE);
-    MVSIM_TRY(launch_rotate(ctx->stream, gt, rot, dim, inv));
+    MVSIM_TRY(launch_rotate_attenuate(ctx->stream, gt, rot, att, dim, inv, p->delta, &fused));
+    if (!fused) {
+        if (!rot) { MVSIM_TRY(ctx->vol_a.reserve(vbytes)); rot = ctx->vol_a.as<float>(); }
+        MVSIM_TRY(launch_rotate(ctx->stream, gt, rot, dim, inv));
+    }
     ev_end(ctx, ST_ROTATE);
-
-    ev_begin(ctx, ST_ATTENUATE);
-    MVSIM_TRY(launch_attenuate(ctx->stream, rot, att, dim, p->delta));
-    ev_end(ctx, ST_ATTENUATE);
+    if (!fused) {
+        ev_begin(ctx, ST_ATTENUATE);
+        MVSIM_TRY(launch_attenuate(ctx->stream, rot, att, dim, p->delta));
+        ev_end(ctx, ST_ATTENUATE);
+    }
+    if (!con) { MVSIM_TRY(ctx->vol_a.reserve(vbytes)); con = ctx->vol_a.as<float>(); }   // vol_a: rot scratch is dead by now
 
     double *partial, *scal;
     MVSIM_TRY(scal_ptr(ctx, &partial, &scal));

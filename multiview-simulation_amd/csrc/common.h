@@ -128,6 +128,8 @@ namespace mvsim {
 // ---- kernel launchers (each enqueues on `s`, returns MVSIM_* status) ----------------------------
 int launch_rotate(hipStream_t s, const float* in, float* out, const int64_t dim[3], const Affine& inv);
 int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta);
+int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
+                            const Affine& inv, double delta, bool* fused);
 // sum -> scal[0]; partial workspace must hold >= SUM_BLOCKS doubles
 constexpr int SUM_BLOCKS = 2048;
 int launch_sum(hipStream_t s, const float* in, int64_t n, double* partial, double* scal);

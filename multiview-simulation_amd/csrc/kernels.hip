@@ -176,6 +176,121 @@ int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t d
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused rotate (about x) + attenuate for the per-view pipeline: a lane owns two adjacent (x,z) columns and
+// walks y from Ny-1 downwards; every step blends the 4 source rows exactly as k_rotate_axis0_v4 does and feeds
+// the value straight into the attenuation recurrence, so `rot` never makes the round trip through HBM
+// (saves 8 N bytes per view).  Same arithmetic, same order => bit-identical to the two separate kernels.
+// rot_out may be null.
+// ------------------------------------------------------------------------------------------------
+template <int U, bool WRITE_ROT>
+__global__ __launch_bounds__(64) void k_rotate_attenuate_axis0(const float* __restrict__ in, float* __restrict__ rot_out,
+                                                               float* __restrict__ att_out, int nx, int ny, int nz,
+                                                               int steps, Affine a, double delta)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int z = blockIdx.y;
+    if (x >= nx) return;
+    const long long row = (long long)nx;
+    const long long plane = row * ny;
+    float* __restrict__ patt = att_out + plane * z + x;
+    float* __restrict__ prot = WRITE_ROT ? rot_out + plane * z + x : nullptr;
+    const float* __restrict__ pin = in + x;
+    const double l2 = (double)z;
+    double n = 1.0;
+    int y = ny - 1;
+    int left = steps;
+    while (left > 0) {
+        float v00[U], v10[U], v11[U], v01[U];
+        double w00[U], w10[U], w11[U], w01[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int yy = y - u;
+            v00[u] = v10[u] = v11[u] = v01[u] = 0.f;
+            w00[u] = w10[u] = w11[u] = w01[u] = 0.0;
+            if (u < left) {
+                const double l1 = (double)yy;
+                const double py = 0.0 * a.m[4] + l1 * a.m[5] + l2 * a.m[6] + a.m[7];
+                const double pz = 0.0 * a.m[8] + l1 * a.m[9] + l2 * a.m[10] + a.m[11];
+                const double fy = floor(py), fz = floor(pz);
+                if (fy >= -1.0 && fz >= -1.0 && fy < (double)ny && fz < (double)nz) {
+                    const int sy = (int)fy, sz = (int)fz;
+                    const double w1 = py - fy, w2 = pz - fz;
+                    const double w1n = 1.0 - w1, w2n = 1.0 - w2;
+                    w00[u] = 1.0 * w1n * w2n; w10[u] = 1.0 * w1 * w2n; w11[u] = 1.0 * w1 * w2; w01[u] = 1.0 * w1n * w2;
+                    const bool ya = sy >= 0, yb = sy + 1 < ny, za = sz >= 0, zb = sz + 1 < nz;
+                    if (ya && za) v00[u] = pin[row * (sy + (long long)ny * sz)];
+                    if (yb && za) v10[u] = pin[row * (sy + 1 + (long long)ny * sz)];
+                    if (yb && zb) v11[u] = pin[row * (sy + 1 + (long long)ny * (sz + 1))];
+                    if (ya && zb) v01[u] = pin[row * (sy + (long long)ny * (sz + 1))];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u < left) {
+                const int yy = y - u;
+                float r = (float)((double)v00[u] * w00[u]);
+                r += (float)((double)v10[u] * w10[u]);
+                r += (float)((double)v11[u] * w11[u]);
+                r += (float)((double)v01[u] * w01[u]);
+                if (WRITE_ROT) prot[(long long)yy * nx] = r;
+                const double d = (double)r;
+                n = fmax(n - d * delta * n, 0.0);
+                patt[(long long)yy * nx] = (float)(d * n);
+            }
+        }
+        y -= U;
+        left -= U;
+    }
+    // rows the reference never visits (Ny > Nx): attenuated image stays zero; rot still needs its values
+    for (int yy = ny - 1 - steps; yy >= 0; --yy) {
+        patt[(long long)yy * nx] = 0.f;
+        if (WRITE_ROT) {
+            const double l1 = (double)yy;
+            const double py = 0.0 * a.m[4] + l1 * a.m[5] + l2 * a.m[6] + a.m[7];
+            const double pz = 0.0 * a.m[8] + l1 * a.m[9] + l2 * a.m[10] + a.m[11];
+            const double fy = floor(py), fz = floor(pz);
+            float o = 0.f;
+            if (fy >= -1.0 && fz >= -1.0 && fy < (double)ny && fz < (double)nz) {
+                const int sy = (int)fy, sz = (int)fz;
+                const double w1 = py - fy, w2 = pz - fz;
+                const double w1n = 1.0 - w1, w2n = 1.0 - w2;
+                const double q00 = 1.0 * w1n * w2n, q10 = 1.0 * w1 * w2n, q11 = 1.0 * w1 * w2, q01 = 1.0 * w1n * w2;
+                const bool ya = sy >= 0, yb = sy + 1 < ny, za = sz >= 0, zb = sz + 1 < nz;
+                const float a00 = (ya && za) ? pin[row * (sy + (long long)ny * sz)] : 0.f;
+                const float a10 = (yb && za) ? pin[row * (sy + 1 + (long long)ny * sz)] : 0.f;
+                const float a11 = (yb && zb) ? pin[row * (sy + 1 + (long long)ny * (sz + 1))] : 0.f;
+                const float a01 = (ya && zb) ? pin[row * (sy + (long long)ny * (sz + 1))] : 0.f;
+                o = (float)((double)a00 * q00); o += (float)((double)a10 * q10);
+                o += (float)((double)a11 * q11); o += (float)((double)a01 * q01);
+            }
+            prot[(long long)yy * nx] = o;
+        }
+    }
+}
+
+// returns MVSIM_OK and sets *fused = false when the fast-path conditions do not hold (caller runs the two kernels)
+int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
+                            const Affine& inv, double delta, bool* fused)
+{
+    const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
+    const bool x_identity = inv.m[0] == 1.0 && inv.m[1] == 0.0 && inv.m[2] == 0.0 && inv.m[3] == 0.0 &&
+                            inv.m[4] == 0.0 && inv.m[8] == 0.0;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(att) |
+                         reinterpret_cast<uintptr_t>(rot_or_null);
+    (void)al;
+    *fused = x_identity && !getenv("MVSIM_NO_FUSED_ROTATE");
+    if (!*fused) return MVSIM_OK;
+    dim3 grid((nx + 63) / 64, nz);
+    if (rot_or_null)
+        hipLaunchKernelGGL((k_rotate_attenuate_axis0<8, true>), grid, dim3(64), 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta);
+    else
+        hipLaunchKernelGGL((k_rotate_attenuate_axis0<8, false>), grid, dim3(64), 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sum (Tools.sumImage, Tools.java:124-132; mpicbg RealSum ~ exact-to-double): per-thread double
 // accumulation, wave shuffle + LDS block tree, fixed-order final pass => deterministic.
 // ------------------------------------------------------------------------------------------------
@@ -468,14 +583,28 @@ __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict_
             if (n == 0) break;
             for (int i = tid; i < n; i += 256) {
                 const PItem it = q[cur][i];
+                const double lam = (double)it.v * mul;
                 float val;
-                if (ptrs_step((double)it.v * mul, it.index, (uint32_t)it.attempt, k0, k1, stream, val)) {
-                    res[it.slot] = val;
+                if (it.attempt >= kPtrsMaxAttempts) {
+                    res[it.slot] = (float)(long long)lam;
                 } else {
-                    const int pos = atomicAdd(&qn[cur ^ 1], 1);
-                    PItem nx = it;
-                    nx.attempt = (unsigned short)(it.attempt + 1);
-                    q[cur ^ 1][pos] = nx;
+                    uint32_t w0, w1;
+                    if (it.attempt == 0) {
+                        const unsigned long long pr = it.index >> 1;
+                        const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
+                        const bool odd = (it.index & 1) != 0;
+                        w0 = odd ? r.z : r.x; w1 = odd ? r.w : r.y;
+                    } else {
+                        ptrs_retry_words(it.index, (uint32_t)it.attempt, k0, k1, stream, w0, w1);
+                    }
+                    if (ptrs_step_words(lam, w0, w1, val)) {
+                        res[it.slot] = val;
+                    } else {
+                        const int pos = atomicAdd(&qn[cur ^ 1], 1);
+                        PItem nx = it;
+                        nx.attempt = (unsigned short)(it.attempt + 1);
+                        q[cur ^ 1][pos] = nx;
+                    }
                 }
             }
             __syncthreads();                       // q[cur] / qn[cur] fully consumed

@@ -203,34 +203,99 @@ __device__ __forceinline__ double ptrs_retry(const PtrsSetup& s, double lambda, 
     return lambda;
 }
 
-// One attempt of one voxel, self-contained (used by the block-level work queue of k_extract4_noise): returns
-// true when the voxel is resolved.  attempt == kPtrsMaxAttempts resolves to floor(lambda).
-__device__ __forceinline__ bool ptrs_step(double lambda, uint64_t index, uint32_t attempt, uint32_t k0, uint32_t k1,
-                                          uint32_t stream, float& res)
+// fp32 screening of the exact test.  D = lhs - rhs is re-derived in a cancellation-free form (valid for k >= 16,
+// Stirling branch):  with t = (k+1-lambda)/lambda,
+//     rhs = lambda*g(t) + log1p(t) - log(k+1)/2 - log(2 pi)/2 - ser(k+1),   g(t) = t - (1+t) log1p(t) = -t^2/2 + t^3/6 - ...
+// so every term is O(1..50) and single precision is accurate to ~1e-5 absolute.  Returns +1 (surely accept),
+// -1 (surely reject) or 0 (too close to call: run the bit-defined fp64 test).  Pure optimisation: whenever it
+// answers, the answer equals the fp64 decision (margin >= 100x the error bound), so counts are unchanged.
+__device__ __forceinline__ int ptrs_screen(const PtrsSetup& s, double lambda, double us, double V, double kd)
 {
-    if (attempt >= kPtrsMaxAttempts) { res = (float)(long long)lambda; return true; }
-    const PtrsSetup s = ptrs_setup(lambda);
-    uint32_t w0, w1;
-    if (attempt == 0u) {
-        const uint64_t pr = index >> 1;
-        const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
-        const bool odd = (index & 1) != 0;
-        w0 = odd ? r.z : r.x; w1 = odd ? r.w : r.y;
-    } else {
-        const Philox4 r = philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), stream, 2u + (attempt - 1u) / 2u, k0, k1);
-        const bool second = ((attempt - 1u) & 1u) != 0u;
-        w0 = second ? r.z : r.x; w1 = second ? r.w : r.y;
+    const float lam = (float)lambda;
+    if (kd <= 16.0) {
+        // table branch of log(k!): -lambda + k log(lambda) - log(k!) has terms of magnitude <= ~100 here
+        // (lambda < ~60 for such k to be proposed at all), so single precision is good to ~1e-5 absolute
+        if (lambda > 64.0) return 0;
+        const float usq = (float)us * (float)us;
+        const float q0 = ((float)V * usq * (float)s.ianum) / ((float)s.bm34 * ((float)s.a + (float)s.b * usq));
+        const float kf = (float)kd;
+        const float ll = __logf(lam);
+        const float d0 = __logf(q0) - ((kf * ll - lam) - (float)kLogFact[(int)kd]);
+        const float e0 = 1.0e-4f + 4.0e-6f * (kf * ll + lam);
+        return d0 < -e0 ? 1 : (d0 > e0 ? -1 : 0);
     }
+    const float x = (float)kd + 1.0f;
+    const float t = (float)((kd + 1.0 - lambda) / lambda);          // formed in double: no cancellation error
+    const float usf = (float)us;
+    const float us2 = usf * usf;
+    const float q = ((float)V * us2 * (float)s.ianum) / ((float)s.bm34 * ((float)s.a + (float)s.b * us2));
+    const float lhs = __logf(q);
+    float lg;                                                         // lambda * g(t) + log1p(t)
+    if (fabsf(t) < 0.25f) {
+        // g(t) = sum_{n>=2} (-1)^(n-1) t^n / (n (n-1));  log1p(t) = sum_{n>=1} (-1)^(n-1) t^n / n
+        float g = 1.0f / 156.0f;                                      // n = 13
+        g = fmaf(g, -t, 1.0f / 132.0f);
+        g = fmaf(g, -t, 1.0f / 110.0f);
+        g = fmaf(g, -t, 1.0f / 90.0f);
+        g = fmaf(g, -t, 1.0f / 72.0f);
+        g = fmaf(g, -t, 1.0f / 56.0f);
+        g = fmaf(g, -t, 1.0f / 42.0f);
+        g = fmaf(g, -t, 1.0f / 30.0f);
+        g = fmaf(g, -t, 1.0f / 20.0f);
+        g = fmaf(g, -t, 1.0f / 12.0f);
+        g = fmaf(g, -t, 1.0f / 6.0f);
+        g = fmaf(g, -t, 1.0f / 2.0f);
+        g = -g * t * t;
+        lg = lam * g + __logf(1.0f + t);
+    } else {
+        const float l1p = __logf(1.0f + t);
+        lg = lam * (t - (1.0f + t) * l1p) + l1p;
+    }
+    const float ix = 1.0f / x;
+    const float ix2 = ix * ix;
+    const float ser = ix * (8.3333333e-02f + ix2 * (-2.7777778e-03f + ix2 * 7.9365079e-04f));
+    const float lx = __logf(x);
+    const float rhs = lg - 0.5f * lx - 0.9189385f - ser;
+    const float d = lhs - rhs;
+    // error budget: each term carries <= ~3 ulp of single precision relative to its own magnitude (q: 5 roundings,
+    // series: fma chain, v_log_f32: 1 ulp), i.e. <= 4e-7 * (|lhs| + |lg| + lx + 1); the margin below is >= 10x that.
+    const float eps = 2.0e-5f + 4.0e-6f * (fabsf(lhs) + fabsf(lg) + lx);
+    if (d < -eps) return 1;
+    if (d > eps) return -1;
+    return 0;
+}
+
+// One attempt of one voxel from its two random words (used by the block-level work queue of
+// k_extract4_noise): returns true when the voxel is resolved.
+__device__ __forceinline__ bool ptrs_step_words(double lambda, uint32_t w0, uint32_t w1, float& res)
+{
+    const PtrsSetup s = ptrs_setup(lambda);
     double us, V, kd;
     const int st = ptrs_fast(s, lambda, w0, w1, us, V, kd);
     if (st == 1) return false;
+#ifndef MVSIM_EXP_NOEXACT
     if (st == 2) {
-        double loglam = 0.0;
-        bool have = false;
-        if (!ptrs_exact(s, lambda, us, V, kd, loglam, have)) return false;
+        const int sc = ptrs_screen(s, lambda, us, V, kd);
+        if (sc < 0) return false;
+        if (sc == 0) {
+            double loglam = 0.0;
+            bool have = false;
+            if (!ptrs_exact(s, lambda, us, V, kd, loglam, have)) return false;
+        }
     }
+#endif
     res = (float)(long long)kd;
     return true;
+}
+
+// Random words of retry attempt a >= 1 of voxel `index`.
+__device__ __forceinline__ void ptrs_retry_words(uint64_t index, uint32_t attempt, uint32_t k0, uint32_t k1, uint32_t stream,
+                                                 uint32_t& w0, uint32_t& w1)
+{
+    const Philox4 r = philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), stream, 2u + (attempt - 1u) / 2u, k0, k1);
+    const bool second = ((attempt - 1u) & 1u) != 0u;
+    w0 = second ? r.z : r.x;
+    w1 = second ? r.w : r.y;
 }
 
 // (w0, w1) are the attempt-0 words, taken by the caller from the block shared by the voxel pair index>>1.
