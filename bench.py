@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slab", type=int, default=64, help="z extent of the CPU-baseline sample slab")
     ap.add_argument("--stage-timing", action="store_true", default=True)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="contexts/HIP streams per GPU; views alternate between them so that the VALU-bound Poisson "
+                         "kernel of one view overlaps the HBM-bound passes of the next")
     return ap.parse_args()
 
 
@@ -125,16 +128,20 @@ def main():
     psfs = [synth.gaussian_psf(args.psf, sigma=(2.0, 2.2, 6.0 + 0.05 * (v % 8))) for v in my_views]
     acq = [torch.empty(n * n * nzo, dtype=torch.float32, device=dev) for _ in my_views]
 
-    ctx = mvs.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one context (own HIP stream + workspaces) per concurrent view pipeline
+    ctxs = [mvs.Context(local_rank) for _ in range(max(1, args.streams))]
+    ctx = ctxs[0]
     params = [ctx.view_params(degrees=angles[v], inc=args.inc, snr=args.snr, seed=464232194, stream=v,
                               conv_method=args.conv_method) for v in my_views]
 
     def step():
         if world > 1:
+            for c in ctxs:
+                c.synchronize()                         # previous dataset's views no longer read the ground truth
             dist.broadcast(gt_dev, src=0)
+            torch.cuda.current_stream().synchronize()   # ground truth has landed before the view streams read it
         for i in range(len(my_views)):
-            ctx.simulate_view_dev(gt_dev.data_ptr(), dims, psfs[i].copy(), params[i], acq[i].data_ptr())
+            ctxs[i % len(ctxs)].simulate_view_dev(gt_dev.data_ptr(), dims, psfs[i].copy(), params[i], acq[i].data_ptr())
 
     def sync():
         torch.cuda.synchronize()
@@ -184,6 +191,7 @@ def main():
                        "volume": [n, n, n], "psf": [args.psf] * 3, "views_total": total_views,
                        "views_per_gpu": views_per_gpu, "inc": args.inc, "snr": args.snr,
                        "conv_method": "fft(rocFFT)" if args.conv_method == 1 else "direct",
+                       "streams_per_gpu": len(ctxs),
                        "collective": "RCCL broadcast of ground truth per step" if world > 1 else "none"},
         }
         if stage:
@@ -211,7 +219,8 @@ def main():
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
 
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 

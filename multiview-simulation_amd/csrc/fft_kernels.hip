@@ -125,11 +125,25 @@ __device__ __forceinline__ void wave_order()
 // wbuf: the LW lines owned by this wave (length L, pitch LP complex elements); tw: L twiddles
 // exp(-2 pi i k / L) in LDS.  Per radix pass: read all butterflies of the wave into registers, then
 // twiddle + DFT + write back in Stockham order.
-template <int L, int LP, int LW, int P>
-__device__ __forceinline__ void wpasses(float2*, const float2*, int) {}
+// Identity / "multiply by the PSF spectrum and conjugate" operators applied to the inputs of the FIRST radix
+// pass (the spectrum product of pass C rides on the second transform's loads: no separate LDS pass).
+struct LoadIdentity {
+    __device__ __forceinline__ float2 operator()(float2 v, int, int) const { return v; }
+};
+struct LoadMulConj {
+    const float2* g;        // spectrum lines of this wave, line-major: g[line * glen + n]
+    int glen;
+    __device__ __forceinline__ float2 operator()(float2 v, int line, int n) const
+    {
+        return cconj(cmul(v, g[line * glen + n]));
+    }
+};
 
-template <int L, int LP, int LW, int P, int R, int... Rest>
-__device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2* __restrict__ tw, int lane)
+template <int L, int LP, int LW, int P, class OP>
+__device__ __forceinline__ void wpasses(float2*, const float2*, int, const OP&) {}
+
+template <int L, int LP, int LW, int P, class OP, int R, int... Rest>
+__device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2* __restrict__ tw, int lane, const OP& op)
 {
     constexpr int STR = L / R;
     constexpr int NB = LW * STR;               // butterflies of this wave in this pass
@@ -142,7 +156,10 @@ __device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2*
             const int line = b / STR, i = b - line * STR;
             const float2* src = wbuf + line * LP + i;
 #pragma unroll
-            for (int r = 0; r < R; ++r) u[it][r] = src[r * STR];
+            for (int r = 0; r < R; ++r) {
+                u[it][r] = src[r * STR];
+                if (P == 1) u[it][r] = op(u[it][r], line, i + r * STR);
+            }
         }
     }
     wave_order();
@@ -165,7 +182,7 @@ __device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2*
         }
     }
     wave_order();
-    wpasses<L, LP, LW, P * R, Rest...>(wbuf, tw, lane);
+    wpasses<L, LP, LW, P * R, OP, Rest...>(wbuf, tw, lane, op);
 }
 
 #ifndef MVSIM_NL_BIG
@@ -202,7 +219,12 @@ template <int L, int... Rs> struct Plan {
     template <int LW>
     static __device__ __forceinline__ void run(float2* wbuf, const float2* tw, int lane)
     {
-        wpasses<L, L + 1, LW, 1, Rs...>(wbuf, tw, lane);
+        wpasses<L, L + 1, LW, 1, LoadIdentity, Rs...>(wbuf, tw, lane, LoadIdentity{});
+    }
+    template <int LW, class OP>
+    static __device__ __forceinline__ void run_op(float2* wbuf, const float2* tw, int lane, const OP& op)
+    {
+        wpasses<L, L + 1, LW, 1, OP, Rs...>(wbuf, tw, lane, op);
     }
 };
 
@@ -250,6 +272,7 @@ struct LinesArgs {
     const float2* tw;
     long long     src_es, src_outer, dst_es, dst_outer, spec_es, spec_outer;
     DimMap        lmap;     // SPARSE: position n reads source position map_src(lmap, n) (or zero)
+    int           dst_tile_major;   // FWD: store tile (bx,by) as NL contiguous lines of L: dst[((by*gridDim.x+bx)*NL + c)*L + n]
 };
 
 // second launch bound: two blocks per CU must stay resident (w = 2*T/256 waves per SIMD, rounded up)
@@ -300,33 +323,22 @@ __global__ __launch_bounds__(Cfg<PLAN::len>::T, (2 * Cfg<PLAN::len>::T + 255) / 
     __syncthreads();
     PLAN::template run<LW>(wbuf, tw, lane);
     if (MODE == CONV) {
-        // multiply by the PSF spectrum, conjugate, transform again (inverse = conj FFT conj).
-        // The spectrum tile is fetched here in two batches rather than prefetched: holding it across the
-        // first transform would push the kernel past 96 VGPRs and evict the second resident block.
-        __syncthreads();
-        const float2* gbase = p.spec + (long long)blockIdx.y * p.spec_outer + (long long)blockIdx.x * NL + c2;
-        constexpr int HB = (NIT + 1) / 2;
+        // x PSF spectrum, conjugate, transform again (inverse = conj FFT conj).  The spectrum is stored tile-major
+        // (each line contiguous), so the wave that owns a line streams its spectrum line straight into the first
+        // radix pass of the second transform: no barrier, no extra trip through LDS.
+        const float2* gl = p.spec + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * NL + (long long)wave * LW) * L;
+        PLAN::template run_op<LW>(wbuf, tw, lane, LoadMulConj{gl, L});
+    }
+    if (MODE == FWD && p.dst_tile_major) {
+        // wave-private store: every line of the tile contiguous (consumed by LoadMulConj above)
+        float2* gl = p.dst + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * NL + (long long)wave * LW) * L;
 #pragma unroll
-        for (int h0 = 0; h0 < NIT; h0 += HB) {
-            float4 g[HB];
-#pragma unroll
-            for (int q = 0; q < HB; ++q) {
-                const int n = r0 + (h0 + q) * ROWS;
-                if (h0 + q < NIT && ((L % ROWS == 0) || n < L)) g[q] = *reinterpret_cast<const float4*>(gbase + n * p.spec_es);
+        for (int j = 0; j < LW; ++j)
+            for (int n2 = lane * 2; n2 < L; n2 += 128) {
+                const float2 a = wbuf[j * LP + n2], b = wbuf[j * LP + n2 + 1];
+                *reinterpret_cast<float4*>(gl + j * L + n2) = make_float4(a.x, a.y, b.x, b.y);
             }
-#pragma unroll
-            for (int q = 0; q < HB; ++q) {
-                const int n = r0 + (h0 + q) * ROWS;
-                if (h0 + q < NIT && ((L % ROWS == 0) || n < L)) {
-                    const float2 a = cmul(buf[c2 * LP + n], make_float2(g[q].x, g[q].y));
-                    const float2 b = cmul(buf[(c2 + 1) * LP + n], make_float2(g[q].z, g[q].w));
-                    buf[c2 * LP + n] = cconj(a);
-                    buf[(c2 + 1) * LP + n] = cconj(b);
-                }
-            }
-        }
-        __syncthreads();
-        PLAN::template run<LW>(wbuf, tw, lane);
+        return;
     }
     __syncthreads();
     float2* dbase = p.dst + (long long)blockIdx.y * p.dst_outer + (long long)blockIdx.x * NL + c2;
@@ -863,6 +875,7 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
         c.src_es = plane; c.src_outer = hxp;                         // per ky row
         c.dst_es = plane; c.dst_outer = hxp;
         c.lmap = DimMap{kz, pz, kz - kz / 2, kz / 2, 1, kz / 2};
+        c.dst_tile_major = 1;                                         // consumed line by line in pass C
         MVSIM_TRY(launch_lines(s, pz, FWD, true, c, hxp / tile_z, py));
     }
     ev_end(ctx, ST_PSF);
