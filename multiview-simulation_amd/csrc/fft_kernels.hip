@@ -185,6 +185,10 @@ __device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2*
     wpasses<L, LP, LW, P * R, OP, Rest...>(wbuf, tw, lane, op);
 }
 
+// complex elements per wave in the x passes: 576 (2 rows of 288) keeps 8 blocks x 4 waves resident per CU
+#ifndef MVSIM_X_ELEMS
+#define MVSIM_X_ELEMS 576
+#endif
 #ifndef MVSIM_NL_BIG
 #define MVSIM_NL_BIG ((L <= 576) ? 16 : 8)
 #endif
@@ -203,9 +207,9 @@ template <int L> struct Cfg {
     static constexpr size_t LDS = (size_t)(NL * LP + L) * sizeof(float2) + 32 * sizeof(double);
 };
 
-// x passes: rows are contiguous in HBM; 4 waves per block, each owning LW rows (~1152 complex per wave).
+// x passes: rows are contiguous in HBM; 4 waves per block, each owning LW rows (~MVSIM_X_ELEMS complex per wave).
 template <int M> struct CfgX {
-    static constexpr int LW = clampi(1152 / M, 1, 8);
+    static constexpr int LW = clampi(MVSIM_X_ELEMS / M, 1, 8);
     static constexpr int NW = 4;
     static constexpr int NL = NW * LW;
     static constexpr int LP = M + 1;
@@ -368,7 +372,6 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* _
     using C = CfgX<M>;
     constexpr int NR = C::NL, LP = C::LP, T = C::T, LW = C::LW;
     constexpr int PAIRS = (M + 1) / 2;               // lanes needed for one row (2 complex = 4 floats per lane)
-    constexpr int PIT = (PAIRS + 63) / 64;
     extern __shared__ __align__(16) float2 lds[];
     float2* tw = lds + NR * LP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -377,48 +380,55 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* _
 
     const int nxs = map.x.n;
     const bool fast_x = (nxs & 3) == 0 && map.x.mode == 0;     // 16-B aligned interior loads
-    float4 v[LW][PIT];
+    // row offsets of the wave's LW rows (wave-uniform)
+    long long offs[LW];
 #pragma unroll
     for (int j = 0; j < LW; ++j) {
         const long long row = row0 + j;
-        long long off = -1;
+        offs[j] = -1;
         if (row < rows) {
             const unsigned py = (unsigned)map.y.P;
             const unsigned urow = (unsigned)row;      // rows = Py*Pz < 2^31
             const int z = (int)(urow / py), y = (int)(urow - (unsigned)z * py);
             const int sy = map_src(map.y, y), sz = map_src(map.z, z);
-            if (sy >= 0 && sz >= 0) off = (long long)nxs * (sy + (long long)map.y.n * sz);
+            if (sy >= 0 && sz >= 0) offs[j] = (long long)nxs * (sy + (long long)map.y.n * sz);
         }
+    }
+    // (row, lane-pair) items flattened over the wave's rows: every load iteration has all 64 lanes busy
+    constexpr int LITEMS = LW * PAIRS;
+    constexpr int LIT = (LITEMS + 63) / 64;
+    float4 v[LIT];
 #pragma unroll
-        for (int it = 0; it < PIT; ++it) {
-            const int q = lane + it * 64;             // floats 4q .. 4q+3 of the padded row
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (off >= 0 && q < PAIRS) {
-                const float* __restrict__ srow = src + off;
-                if (fast_x && 4 * q + 3 < nxs) {
-                    t = *reinterpret_cast<const float4*>(srow + 4 * q);
-                } else {
-                    const int s0 = map_src(map.x, 4 * q), s1 = map_src(map.x, 4 * q + 1);
-                    const int s2 = map_src(map.x, 4 * q + 2), s3 = map_src(map.x, 4 * q + 3);
-                    t.x = s0 >= 0 ? srow[s0] : 0.f;
-                    t.y = s1 >= 0 ? srow[s1] : 0.f;
-                    t.z = s2 >= 0 ? srow[s2] : 0.f;
-                    t.w = s3 >= 0 ? srow[s3] : 0.f;
-                }
+    for (int it = 0; it < LIT; ++it) {
+        const int e = lane + it * 64;
+        const int j = e / PAIRS, q = e - j * PAIRS;   // floats 4q .. 4q+3 of padded row j
+        long long off = -1;
+#pragma unroll
+        for (int jj = 0; jj < LW; ++jj) off = (j == jj) ? offs[jj] : off;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (off >= 0 && e < LITEMS) {
+            const float* __restrict__ srow = src + off;
+            if (fast_x && 4 * q + 3 < nxs) {
+                t = *reinterpret_cast<const float4*>(srow + 4 * q);
+            } else {
+                const int s0 = map_src(map.x, 4 * q), s1 = map_src(map.x, 4 * q + 1);
+                const int s2 = map_src(map.x, 4 * q + 2), s3 = map_src(map.x, 4 * q + 3);
+                t.x = s0 >= 0 ? srow[s0] : 0.f;
+                t.y = s1 >= 0 ? srow[s1] : 0.f;
+                t.z = s2 >= 0 ? srow[s2] : 0.f;
+                t.w = s3 >= 0 ? srow[s3] : 0.f;
             }
-            v[j][it] = t;
         }
+        v[it] = t;
     }
     for (int i = tid; i < M; i += T) tw[i] = twg[i];
 #pragma unroll
-    for (int j = 0; j < LW; ++j) {
-#pragma unroll
-        for (int it = 0; it < PIT; ++it) {
-            const int q = lane + it * 64;
-            if (q < PAIRS) {
-                wbuf[j * LP + 2 * q] = make_float2(v[j][it].x, v[j][it].y);
-                if (2 * q + 1 < M) wbuf[j * LP + 2 * q + 1] = make_float2(v[j][it].z, v[j][it].w);
-            }
+    for (int it = 0; it < LIT; ++it) {
+        const int e = lane + it * 64;
+        if (e < LITEMS) {
+            const int j = e / PAIRS, q = e - j * PAIRS;
+            wbuf[j * LP + 2 * q] = make_float2(v[it].x, v[it].y);
+            if (2 * q + 1 < M) wbuf[j * LP + 2 * q + 1] = make_float2(v[it].z, v[it].w);
         }
     }
     __syncthreads();                                  // twiddle table complete (rows are wave-private)
@@ -426,40 +436,53 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* _
     // Post-process to the half spectrum, in symmetric pairs.  With s = Z[k] + conj Z[M-k], d = Z[k] - conj Z[M-k],
     // t = -i w_P^k d:   2 X[k] = s + t,   2 X[M-k] = conj(s - t).   The factor 2 is NOT divided out here: image and
     // PSF spectra both carry it and pass E folds the exact power of two into its final scale.
-    // Lane q owns k = 2q, 2q+1 (one 16-B store) and the mirrored M-2q, M-2q-1 (two 8-B stores).
-    constexpr int HQ = M / 4;                         // pairs k = 0 .. M/2-1 in lanes of two; k = M/2, pads: tail lanes
-    for (int j = 0; j < LW; ++j) {
+    // Item (row j, q) owns k = 2q, 2q+1 (one 16-B store) and the mirrored M-2q, M-2q-1 (two 8-B stores); items are
+    // flattened over the wave's rows so that all lanes stay busy.
+    constexpr int HQ = M / 4;
+    constexpr int PITEMS = LW * HQ;
+#pragma unroll 1
+    for (int e = lane; e < PITEMS; e += 64) {
+        const int j = e / HQ, q = e - j * HQ;
         const long long row = row0 + j;
-        if (row >= rows) break;
+        if (row >= rows) continue;
         float2* __restrict__ drow = dst + row * hxp;
         const float2* __restrict__ zrow = wbuf + j * LP;
-        for (int q = lane; q < HQ; q += 64) {
-            float2 lo[2], hi[2];
+        float2 lo[2], hi[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = 2 * q + h;
-                const float2 zk = zrow[k];
-                const float2 zm = cconj(zrow[k == 0 ? 0 : M - k]);
-                const float2 sm = cadd(zk, zm), d = csub(zk, zm);
-                const float2 wd = cmul(twx[k], d);
-                const float2 t = make_float2(wd.y, -wd.x);                 // -i * w^k * d
-                lo[h] = cadd(sm, t);
-                hi[h] = cconj(csub(sm, t));                                 // element M-k (k = 0: element M)
-            }
-            *reinterpret_cast<float4*>(drow + 2 * q) = make_float4(lo[0].x, lo[0].y, lo[1].x, lo[1].y);
-            drow[M - 2 * q] = hi[0];
-            drow[M - 2 * q - 1] = hi[1];
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * q + h;
+            const float2 zk = zrow[k];
+            const float2 zm = cconj(zrow[k == 0 ? 0 : M - k]);
+            const float2 sm = cadd(zk, zm), d = csub(zk, zm);
+            const float2 wd = cmul(twx[k], d);
+            const float2 t = make_float2(wd.y, -wd.x);                 // -i * w^k * d
+            lo[h] = cadd(sm, t);
+            hi[h] = cconj(csub(sm, t));                                 // element M-k (k = 0: element M)
         }
-        // k = M/2 is its own mirror (needs M % 4 == 0, true for every table size >= 16 that is even twice);
-        // generic tail: elements not covered above + zero padding up to hxp
-        for (int k = 2 * HQ + lane; k <= M - 2 * HQ; k += 64) {
+        *reinterpret_cast<float4*>(drow + 2 * q) = make_float4(lo[0].x, lo[0].y, lo[1].x, lo[1].y);
+        drow[M - 2 * q] = hi[0];
+        drow[M - 2 * q - 1] = hi[1];
+    }
+    // per row: the middle elements not covered by the pairs (k = M/2 when M % 4 == 0) and the zero padding up
+    // to hxp; flattened over rows as well
+    const int nmid = M - 4 * HQ + 1;
+    const int ntail = nmid + (hxp - M - 1);
+    for (int e = lane; e < LW * ntail; e += 64) {
+        const int j = e / ntail, u = e - j * ntail;
+        const long long row = row0 + j;
+        if (row >= rows) continue;
+        float2* __restrict__ drow = dst + row * hxp;
+        const float2* __restrict__ zrow = wbuf + j * LP;
+        if (u < nmid) {
+            const int k = 2 * HQ + u;
             const float2 zk = zrow[k == M ? 0 : k];
             const float2 zm = cconj(zrow[k == 0 ? 0 : M - k]);
             const float2 sm = cadd(zk, zm), d = csub(zk, zm);
             const float2 wd = cmul(twx[k], d);
             drow[k] = cadd(sm, make_float2(wd.y, -wd.x));
+        } else {
+            drow[M + 1 + (u - nmid)] = make_float2(0.f, 0.f);
         }
-        for (int k = M + 1 + lane; k < hxp; k += 64) drow[k] = make_float2(0.f, 0.f);
     }
 }
 
@@ -476,7 +499,6 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     constexpr int M = PLAN::len;
     using C = CfgX<M>;
     constexpr int NR = C::NL, LP = C::LP, T = C::T, LW = C::LW, NW = C::NW;
-    constexpr int RB = LW >= 2 ? 2 : 1;                                       // rows per load batch
     extern __shared__ __align__(16) float2 lds[];
     float2* tw = lds + NR * LP;
     double* red = reinterpret_cast<double*>(lds + NR * LP + M);              // NW doubles
@@ -488,74 +510,76 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     // Pre-process in symmetric pairs.  With A = X[k], B = conj X[M-k], s = A + B, d = A - B, t = i w_P^{-k} d:
     //   Z[k] = s + t,  Z[M-k] = conj(s - t);  the inverse FFT runs as conj(FFT(conj Z)), so conj(Z) is staged:
     //   buf[k] = conj(s + t),  buf[M-k] = s - t.
-    // Lane q owns k = 2q, 2q+1 (one 16-B load) and the mirrored M-2q, M-2q-1 (two 8-B loads), q < M/4.
+    // Item (row j, q) owns k = 2q, 2q+1 (one 16-B load) and the mirrored M-2q, M-2q-1 (two 8-B loads), q < M/4;
+    // items are flattened over the wave's rows so that every iteration has all 64 lanes busy.
     constexpr int HQ = M / 4;
-    constexpr int HIT = (HQ + 63) / 64;
+    constexpr int ITEMS = LW * HQ;
+    constexpr int HIT = (ITEMS + 63) / 64;
+    long long offs[LW];
 #pragma unroll
-    for (int j0 = 0; j0 < LW; j0 += RB) {
-        float4 xa[RB][HIT];
-        float2 xb0[RB][HIT], xb1[RB][HIT];
-        bool live[RB];
-        long long offs[RB];
+    for (int j = 0; j < LW; ++j) {
+        const long long row = row0 + j;
+        offs[j] = -1;
+        if (row < rows) {
+            const unsigned urow = (unsigned)row;      // rows = Ny*Nz < 2^31
+            const int z = (int)(urow / (unsigned)ny), y = (int)(urow - (unsigned)z * (unsigned)ny);
+            offs[j] = ((long long)z * py + y) * hxp;
+        }
+    }
+    float4 xa[HIT];
+    float2 xb0[HIT], xb1[HIT];
 #pragma unroll
-        for (int jj = 0; jj < RB; ++jj) {
-            const long long row = row0 + j0 + jj;
-            long long off = -1;
-            if (j0 + jj < LW && row < rows) {
-                const unsigned urow = (unsigned)row;  // rows = Ny*Nz < 2^31
-                const int z = (int)(urow / (unsigned)ny), y = (int)(urow - (unsigned)z * (unsigned)ny);
-                off = ((long long)z * py + y) * hxp;
-            }
-            live[jj] = off >= 0;
-            offs[jj] = off;
+    for (int it = 0; it < HIT; ++it) {
+        const int e = lane + it * 64;
+        const int j = e / HQ, q = e - j * HQ;
+        long long off = -1;
 #pragma unroll
-            for (int it = 0; it < HIT; ++it) {
-                const int q = lane + it * 64;
-                xa[jj][it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                xb0[jj][it] = xb1[jj][it] = make_float2(0.f, 0.f);
-                if (off >= 0 && q < HQ) {
-                    const float2* __restrict__ sp = srcc + off;
-                    xa[jj][it] = *reinterpret_cast<const float4*>(sp + 2 * q);   // X[2q], X[2q+1]
-                    xb0[jj][it] = sp[M - 2 * q];                                   // X[M-2q]
-                    xb1[jj][it] = sp[M - 2 * q - 1];                               // X[M-2q-1]
-                }
+        for (int jj = 0; jj < LW; ++jj) off = (j == jj) ? offs[jj] : off;
+        xa[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xb0[it] = xb1[it] = make_float2(0.f, 0.f);
+        if (off >= 0 && e < ITEMS) {
+            const float2* __restrict__ sp = srcc + off;
+            xa[it] = *reinterpret_cast<const float4*>(sp + 2 * q);   // X[2q], X[2q+1]
+            xb0[it] = sp[M - 2 * q];                                   // X[M-2q]
+            xb1[it] = sp[M - 2 * q - 1];                               // X[M-2q-1]
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int e = lane + it * 64;
+        if (e < ITEMS) {
+            const int j = e / HQ, q = e - j * HQ;
+            float2* zrow = wbuf + j * LP;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * q + h;
+                const float2 a = h == 0 ? make_float2(xa[it].x, xa[it].y) : make_float2(xa[it].z, xa[it].w);
+                const float2 b = cconj(h == 0 ? xb0[it] : xb1[it]);
+                const float2 sm = cadd(a, b), d = csub(a, b);
+                const float2 wd = cmul(cconj(twx[k]), d);                  // w^{-k} d
+                const float2 t = make_float2(-wd.y, wd.x);                  // i w^{-k} d
+                zrow[k] = cconj(cadd(sm, t));                               // dead rows were loaded as zeros
+                if (k > 0) zrow[M - k] = csub(sm, t);
             }
         }
+    }
+    // middle elements not covered by the pairs (k = M/2 when M % 4 == 0): generic, straight from HBM
+    constexpr int NMID = M - 4 * HQ + 1;
+    for (int e = lane; e < LW * NMID; e += 64) {
+        const int j = e / NMID, k = 2 * HQ + (e - j * NMID);
+        if (k >= M) continue;
+        long long off = -1;
 #pragma unroll
-        for (int jj = 0; jj < RB; ++jj) {
-            if (j0 + jj >= LW) break;
-            float2* zrow = wbuf + (j0 + jj) * LP;
-#pragma unroll
-            for (int it = 0; it < HIT; ++it) {
-                const int q = lane + it * 64;
-                if (q < HQ) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int k = 2 * q + h;
-                        const float2 a = h == 0 ? make_float2(xa[jj][it].x, xa[jj][it].y) : make_float2(xa[jj][it].z, xa[jj][it].w);
-                        const float2 b = cconj(h == 0 ? xb0[jj][it] : xb1[jj][it]);
-                        const float2 sm = cadd(a, b), d = csub(a, b);
-                        const float2 wd = cmul(cconj(twx[k]), d);                  // w^{-k} d
-                        const float2 t = make_float2(-wd.y, wd.x);                  // i w^{-k} d
-                        const float2 zk = cconj(cadd(sm, t));
-                        zrow[k] = live[jj] ? zk : make_float2(0.f, 0.f);
-                        if (k > 0) zrow[M - k] = live[jj] ? csub(sm, t) : make_float2(0.f, 0.f);
-                    }
-                }
-            }
-            // middle elements not covered by the pairs (k = M/2 when M % 4 == 0): generic, straight from HBM
-            for (int k = 2 * HQ + lane; k <= M - 2 * HQ && k < M; k += 64) {
-                float2 zk = make_float2(0.f, 0.f);
-                if (live[jj]) {
-                    const float2* __restrict__ sp = srcc + offs[jj];
-                    const float2 a = sp[k], b = cconj(sp[M - k]);
-                    const float2 sm = cadd(a, b), d = csub(a, b);
-                    const float2 wd = cmul(cconj(twx[k]), d);
-                    zk = cconj(cadd(sm, make_float2(-wd.y, wd.x)));
-                }
-                zrow[k] = zk;
-            }
+        for (int jj = 0; jj < LW; ++jj) off = (j == jj) ? offs[jj] : off;
+        float2 zk = make_float2(0.f, 0.f);
+        if (off >= 0) {
+            const float2* __restrict__ sp = srcc + off;
+            const float2 a = sp[k], b = cconj(sp[M - k]);
+            const float2 sm = cadd(a, b), d = csub(a, b);
+            const float2 wd = cmul(cconj(twx[k]), d);
+            zk = cconj(cadd(sm, make_float2(-wd.y, wd.x)));
         }
+        wbuf[j * LP + k] = zk;
     }
     __syncthreads();                                  // twiddle table complete (rows are wave-private)
     PLAN::template run<LW>(wbuf, tw, lane);
