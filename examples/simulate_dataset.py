@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""The whole driver loop of SimulateMultiViewDataset.main (:554-663) on the GPU path, with synthetic inputs
+instead of the reference's phantom generator and TIFF PSFs (both out of scope):
+
+    ground truth -> for each angle: rotate, attenuate, weights, convolve, adjust, extractSlices,
+    makeIsotropic, rotate back (view, weights, PSF) -> cross-view weight normalisation -> sum of weights
+
+    python examples/simulate_dataset.py --size 64 --views 7 --out /tmp/mvsim_out
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+mvs = importlib.import_module("multiview-simulation_amd")
+synth = importlib.import_module("multiview-simulation_amd.synthetic")
+S, T = mvs.SimulateMultiViewDataset, mvs.Tools
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--views", type=int, default=7)           # angleIncrement = 52 -> 7 views (:540)
+    ap.add_argument("--psf", type=int, default=15)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+
+    poissonSNR, lightsheetSpacing, attenuation, osem, angleOffset = 25.0, 3, 0.01, 3.0, 15   # :531-548
+    angleIncrement = 360 // a.views
+    rendered = synth.sphere_phantom(a.size)
+    obj = S.rotateAroundAxis(rendered, 0, angleOffset)        # ground truth (:557)
+    rnd = mvs.JavaRandom(464232194)
+    weights, out = [], {"rendered": rendered, "groundtruth": obj}
+    for angle in range(0, 360, angleIncrement)[: a.views]:
+        rot = S.rotateAroundAxis(rendered, 0, angle + angleOffset)
+        att = S.attenuate3d(rot, attenuation)
+        w = S.computeWeightImage(rot, attenuation)
+        psf = synth.gaussian_psf(a.psf, sigma=(2.0, 2.2, 4.0))
+        con = S.convolve(att, psf, None)                      # normalises psf in place
+        T.adjustImage(con, S.minValue, S.avgIntensity)
+        acq = S.extractSlices(con, lightsheetSpacing, poissonSNR, rnd)
+        iso = S.makeIsotropic(acq, lightsheetSpacing)
+        view = S.rotateAroundAxis(iso, 0, -angle)
+        viewWeights = S.rotateAroundAxis(w, 0, -angle)
+        viewPSF = S.rotateAroundAxis(psf, 0, -angle)
+        weights.append(viewWeights)
+        out.update({f"rot_view_{angle}": rot, f"att_view_{angle}": att, f"con_view_{angle}": con,
+                    f"acq_view_{angle}": acq, f"iso_view_{angle}": iso, f"aligned_view_{angle}": view,
+                    f"aligned_view_psf_{angle}": viewPSF})
+        print(f"angle {angle:3d}: acq {acq.shape} mean count {acq.mean():8.2f}  iso {iso.shape}")
+    S.normalizeWeights(weights, osem)                         # :615-640
+    sumWeights = np.zeros_like(weights[0])
+    for i, w in enumerate(weights):
+        out[f"aligned_view_weights{i * angleIncrement}"] = w
+        sumWeights = sumWeights + w                           # :648-661
+    out["sum_weights"] = sumWeights
+    print(f"sum of weights: min {sumWeights.min():.3f} max {sumWeights.max():.3f}")
+    if a.out:
+        os.makedirs(a.out, exist_ok=True)
+        np.savez_compressed(os.path.join(a.out, "dataset.npz"), **out)
+        print("written", os.path.join(a.out, "dataset.npz"))
+
+
+if __name__ == "__main__":
+    main()

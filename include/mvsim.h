@@ -121,6 +121,19 @@ int mvsim_extract_slices_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[
 int mvsim_make_isotropic_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float* out);
 int mvsim_compute_weight_image_dev(mvsim_ctx* ctx, const int64_t dim[3], float* out);
 
+/* ---- cross-view weight normalisation (after the view loop, SMVD:615-640 and :648-661) ------------------ */
+#define MVSIM_MAX_VIEWS 32
+/* out[i] = sum over views (float accumulation in view order, starting from 0), SMVD:625-628 / :648-661.
+ * vols: HOST array of n_views DEVICE pointers. */
+int mvsim_sum_views_dev(mvsim_ctx* ctx, const float* const* vols, int n_views, int64_t n, float* out);
+/* In place on every view: sum == 0 -> 0, else min(1, osem * (w / sum)) in float (SMVD:630-639).
+ * sum_or_null: per-voxel sum over ALL views (e.g. after mvsim_comm_allreduce_sum when views are sharded over
+ * ranks); NULL => summed here over the given views. */
+int mvsim_normalize_weights_dev(mvsim_ctx* ctx, float* const* weights, int n_views, int64_t n,
+                                const float* sum_or_null, float osem);
+/* Host buffers: weights[v] are host pointers of n floats each. */
+int mvsim_normalize_weights(mvsim_ctx* ctx, float* const* weights, int n_views, int64_t n, float osem);
+
 /* ---- fused per-view pipeline: loop body SMVD:570-585 -------------------------------------- */
 typedef struct mvsim_view_params {
     int32_t  axis;            /* 0 (SMVD:570)                                  */
@@ -173,6 +186,9 @@ int mvsim_comm_init(mvsim_ctx* ctx, int nranks, int rank, const unsigned char id
 /* Broadcast the ground-truth volume (device pointer, count floats) from root; enqueued on
  * the context stream.  The only collective on the path (views are independent, SMVD:567). */
 int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, int root);
+/* In-place sum over ranks (RCCL all-reduce) of a device float buffer: the per-voxel weight sums of SMVD:625-628
+ * when the views live on different GPUs.  Summation order differs from the sequential reference (<= 1 ulp). */
+int mvsim_comm_allreduce_sum(mvsim_ctx* ctx, float* buf_dev, int64_t count);
 int mvsim_comm_destroy(mvsim_ctx* ctx);
 /* view v of n_views belongs to rank v % nranks; returns how many views `rank` owns and writes
  * their indices (capacity max_out). */

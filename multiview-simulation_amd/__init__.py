@@ -226,6 +226,25 @@ class Context:
         _lib.check(self._L.mvsim_compute_weight_image(self._h, (C.c_int64 * 3)(nx, ny, nz), _ptr(out)))
         return out
 
+    # -- cross-view weight normalisation (SimulateMultiViewDataset.java:615-640)
+    def normalize_weights(self, weights: list, osem: float) -> None:
+        """In place on a list of equally sized float32 arrays (one per view)."""
+        for w in weights:
+            _check_inplace(w, "weights")
+        n = weights[0].size
+        if any(w.size != n for w in weights):
+            raise ValueError("weights: all views must have the same size")
+        arr = (C.c_void_p * len(weights))(*[w.ctypes.data for w in weights])
+        _lib.check(self._L.mvsim_normalize_weights(self._h, arr, len(weights), n, osem))
+
+    def normalize_weights_dev(self, dptrs: list, n: int, osem: float, sum_dptr: int = 0) -> None:
+        arr = (C.c_void_p * len(dptrs))(*dptrs)
+        _lib.check(self._L.mvsim_normalize_weights_dev(self._h, arr, len(dptrs), n, C.c_void_p(sum_dptr or None), osem))
+
+    def sum_views_dev(self, dptrs: list, n: int, out_dptr: int) -> None:
+        arr = (C.c_void_p * len(dptrs))(*dptrs)
+        _lib.check(self._L.mvsim_sum_views_dev(self._h, arr, len(dptrs), n, C.c_void_p(out_dptr)))
+
     # -- fused per-view pipeline
     def view_params(self, **kw) -> ViewParams:
         p = ViewParams()
@@ -315,6 +334,9 @@ class Context:
 
     def comm_broadcast_volume(self, dptr: int, count: int, root: int = 0) -> None:
         _lib.check(self._L.mvsim_comm_broadcast_volume(self._h, C.c_void_p(dptr), count, root))
+
+    def comm_allreduce_sum(self, dptr: int, count: int) -> None:
+        _lib.check(self._L.mvsim_comm_allreduce_sum(self._h, C.c_void_p(dptr), count))
 
     def comm_destroy(self) -> None:
         _lib.check(self._L.mvsim_comm_destroy(self._h))
@@ -418,6 +440,11 @@ class SimulateMultiViewDataset:
     def makeIsotropic(img, inc: int) -> np.ndarray:
         """:144-171"""
         return default_context().make_isotropic(img, inc)
+
+    @staticmethod
+    def normalizeWeights(weights: list, osem: float) -> None:
+        """:615-640 (the block of main() after the view loop) -- in place on the list of aligned weight images."""
+        default_context().normalize_weights(weights, osem)
 
     @staticmethod
     def computeWeightImage(img, delta: float = 0.0) -> np.ndarray:

@@ -81,6 +81,9 @@ SIGNATURES = {
     "mvsim_extract_slices_dev": (C.c_int, [_vp, _vp, _i64p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _vp]),
     "mvsim_make_isotropic_dev": (C.c_int, [_vp, _vp, _i64p, C.c_int, _vp]),
     "mvsim_compute_weight_image_dev": (C.c_int, [_vp, _i64p, _vp]),
+    "mvsim_sum_views_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, _vp]),
+    "mvsim_normalize_weights_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, _vp, C.c_float]),
+    "mvsim_normalize_weights": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_float]),
     "mvsim_view_params_default": (None, [C.POINTER(ViewParams)]),
     "mvsim_simulate_view_dev": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams),
                                           C.POINTER(ViewOutputs), C.POINTER(C.c_double)]),
@@ -91,6 +94,7 @@ SIGNATURES = {
     "mvsim_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "mvsim_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "mvsim_comm_broadcast_volume": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "mvsim_comm_allreduce_sum": (C.c_int, [_vp, _vp, C.c_int64]),
     "mvsim_comm_destroy": (C.c_int, [_vp]),
     "mvsim_shard_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
 }

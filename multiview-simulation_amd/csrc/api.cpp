@@ -441,6 +441,53 @@ int mvsim_compute_weight_image_dev(mvsim_ctx* ctx, const int64_t dim[3], float* 
     return launch_weight_image(ctx->stream, out, dim);
 }
 
+// ---- cross-view weight normalisation -------------------------------------------------------------------
+int mvsim_sum_views_dev(mvsim_ctx* ctx, const float* const* vols, int n_views, int64_t n, float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(vols && out && n >= 1, "null pointer or empty image");
+    MVSIM_CHECK_ARG(n_views >= 1 && n_views <= MVSIM_MAX_VIEWS, "n_views must be in [1, MVSIM_MAX_VIEWS]");
+    for (int v = 0; v < n_views; ++v) MVSIM_CHECK_ARG(vols[v] != nullptr, "null view pointer");
+    return launch_weights(ctx->stream, const_cast<float* const*>(vols), n_views, n, nullptr, out, 0.0f, true);
+}
+
+int mvsim_normalize_weights_dev(mvsim_ctx* ctx, float* const* weights, int n_views, int64_t n, const float* sum_or_null,
+                                float osem)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(weights && n >= 1, "null pointer or empty image");
+    MVSIM_CHECK_ARG(n_views >= 1 && n_views <= MVSIM_MAX_VIEWS, "n_views must be in [1, MVSIM_MAX_VIEWS]");
+    for (int v = 0; v < n_views; ++v) MVSIM_CHECK_ARG(weights[v] != nullptr, "null view pointer");
+    return launch_weights(ctx->stream, weights, n_views, n, sum_or_null, nullptr, osem, false);
+}
+
+int mvsim_normalize_weights(mvsim_ctx* ctx, float* const* weights, int n_views, int64_t n, float osem)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(weights && n >= 1, "null pointer or empty image");
+    MVSIM_CHECK_ARG(n_views >= 1 && n_views <= MVSIM_MAX_VIEWS, "n_views must be in [1, MVSIM_MAX_VIEWS]");
+    const size_t bytes = (size_t)n * sizeof(float);
+    std::vector<DevBuf> bufs((size_t)n_views);
+    std::vector<float*> dptr((size_t)n_views);
+    int rc = MVSIM_OK;
+    for (int v = 0; v < n_views && rc == MVSIM_OK; ++v) {
+        if (!weights[v]) { set_error("invalid argument: null view pointer"); rc = MVSIM_EINVAL; break; }
+        rc = bufs[v].reserve(bytes);
+        if (rc == MVSIM_OK && hipMemcpyAsync(bufs[v].p, weights[v], bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            set_error("upload of view %d failed", v); rc = MVSIM_EHIP;
+        }
+        dptr[v] = bufs[v].as<float>();
+    }
+    if (rc == MVSIM_OK) rc = launch_weights(ctx->stream, dptr.data(), n_views, n, nullptr, nullptr, osem, false);
+    for (int v = 0; v < n_views && rc == MVSIM_OK; ++v)
+        if (hipMemcpyAsync(weights[v], bufs[v].p, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+            set_error("download of view %d failed", v); rc = MVSIM_EHIP;
+        }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : bufs) b.release();
+    return rc;
+}
+
 // ---- fused per-view pipeline ------------------------------------------------------------------------
 int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host,
                             const int64_t kdim[3], const mvsim_view_params* p, const mvsim_view_outputs* o,

@@ -58,6 +58,15 @@ int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, i
     return MVSIM_OK;
 }
 
+int mvsim_comm_allreduce_sum(mvsim_ctx* ctx, float* buf_dev, int64_t count)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr && buf_dev != nullptr && count >= 0, "null pointer or negative count");
+    MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
+    MVSIM_HIP(hipSetDevice(ctx->device));
+    MVSIM_NCCL(ncclAllReduce(buf_dev, buf_dev, (size_t)count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    return MVSIM_OK;
+}
+
 int mvsim_comm_destroy(mvsim_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return MVSIM_OK;

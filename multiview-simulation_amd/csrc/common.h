@@ -143,6 +143,8 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
                    uint32_t stream, uint64_t index_offset);
 int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc);
 int launch_weight_image(hipStream_t s, float* out, const int64_t dim[3]);
+int launch_weights(hipStream_t s, float* const* views, int nv, int64_t n, const float* sum_in, float* sum_out,
+                   float osem, bool sum_only);
 
 // FFT convolution pieces
 int launch_pad_mirror(hipStream_t s, const float* img, const int64_t dim[3], const int64_t kdim[3],

@@ -739,4 +739,51 @@ int launch_weight_image(hipStream_t s, float* out, const int64_t dim[3])
     return MVSIM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cross-view weight normalisation (SimulateMultiViewDataset.java:615-640): per voxel, float sum over the
+// views in view order; zero sum -> all zero, else w <- min(1, osem * (w / sum)).
+// ------------------------------------------------------------------------------------------------
+struct ViewPtrs {
+    float* p[MVSIM_MAX_VIEWS];
+};
+
+template <bool HAVE_SUM, bool WRITE_SUM_ONLY>
+__global__ __launch_bounds__(256) void k_weights(ViewPtrs vp, int nv, long long n, const float* __restrict__ sum_in,
+                                                 float* __restrict__ sum_out, float osem)
+{
+    const long long nthreads = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += nthreads) {
+        float sum;
+        if (HAVE_SUM) {
+            sum = sum_in[i];
+        } else {
+            sum = 0.0f;
+            for (int v = 0; v < nv; ++v) sum += vp.p[v][i];
+        }
+        if (WRITE_SUM_ONLY) { sum_out[i] = sum; continue; }
+        for (int v = 0; v < nv; ++v) {
+            float w = 0.0f;
+            if (sum != 0.0f) w = fminf(1.0f, osem * (vp.p[v][i] / sum));
+            vp.p[v][i] = w;
+        }
+    }
+}
+
+int launch_weights(hipStream_t s, float* const* views, int nv, int64_t n, const float* sum_in, float* sum_out,
+                   float osem, bool sum_only)
+{
+    ViewPtrs vp;
+    for (int v = 0; v < MVSIM_MAX_VIEWS; ++v) vp.p[v] = v < nv ? views[v] : nullptr;
+    long long want = (n + 255) / 256;
+    int blocks = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+    if (sum_only)
+        hipLaunchKernelGGL((k_weights<false, true>), dim3(blocks), dim3(256), 0, s, vp, nv, (long long)n, sum_in, sum_out, osem);
+    else if (sum_in)
+        hipLaunchKernelGGL((k_weights<true, false>), dim3(blocks), dim3(256), 0, s, vp, nv, (long long)n, sum_in, sum_out, osem);
+    else
+        hipLaunchKernelGGL((k_weights<false, false>), dim3(blocks), dim3(256), 0, s, vp, nv, (long long)n, sum_in, sum_out, osem);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
 }  // namespace mvsim

@@ -99,6 +99,7 @@ def lib():
         L.orc_isotropic_nz.restype = C.c_int64
         L.orc_make_isotropic.argtypes = [_f32p, _i64p, C.c_int, _f32p]
         L.orc_compute_weight_image.argtypes = [_i64p, _f32p]
+        L.orc_normalize_weights.argtypes = [C.POINTER(_f32p), C.c_int, C.c_int64, C.c_float]
         _lib = L
     return _lib
 
@@ -352,6 +353,14 @@ def compute_weight_image(shape_zyx) -> np.ndarray:
     out = np.empty((nz, ny, nx), dtype=np.float32)
     lib().orc_compute_weight_image((C.c_int64 * 3)(nx, ny, nz), _p(out))
     return out
+
+
+def normalize_weights(weights: list, osem: float) -> None:
+    """SMVD:615-640, in place on a list of float32 arrays."""
+    arr = (_f32p * len(weights))(*[_p(w) for w in weights])
+    rc = lib().orc_normalize_weights(arr, len(weights), weights[0].size, osem)
+    if rc:
+        raise ValueError("normalize_weights")
 
 
 def simulate_view(gt, psf, angle_deg: int, *, axis: int = 0, delta: float = 0.01, min_value: float = 1e-4,

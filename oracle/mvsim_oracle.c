@@ -570,3 +570,21 @@ int orc_compute_weight_image(const int64_t dim[3], float* out)
         }
     return 0;
 }
+
+/* SMVD:615-640: float sum over the views in view order; zero sum -> zeros, else min(1, osem * (w / sum)). */
+int orc_normalize_weights(float* const* weights, int n_views, int64_t n, float osem)
+{
+    if (n_views < 1) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        float sum = 0.0f;
+        for (int v = 0; v < n_views; ++v) sum += weights[v][i];
+        for (int v = 0; v < n_views; ++v) {
+            if (sum == 0.0f) weights[v][i] = 0.0f;
+            else {
+                const float w = osem * (weights[v][i] / sum);
+                weights[v][i] = w < 1.0f ? w : 1.0f;       /* Math.min(1, w) */
+            }
+        }
+    }
+    return 0;
+}

@@ -90,6 +90,8 @@ double orc_poisson_mul(double snr);                /* Tools:76 */
 int64_t orc_isotropic_nz(int64_t nz_acq, int inc);
 int orc_make_isotropic(const float* in, const int64_t dim[3], int inc, float* out);
 int orc_compute_weight_image(const int64_t dim[3], float* out);
+/* ---- SMVD:615-640 cross-view weight normalisation (in place) ---- */
+int orc_normalize_weights(float* const* weights, int n_views, int64_t n, float osem);
 
 #ifdef __cplusplus
 }

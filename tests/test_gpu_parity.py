@@ -323,3 +323,36 @@ def test_linearity_of_convolution_256(ctx, synth):
     lhs = ctx.convolve(a + b, psf.copy(), method=1)
     rhs = ctx.convolve(a, psf.copy(), method=1) + ctx.convolve(b, psf.copy(), method=1)
     assert rel_to_max(lhs, rhs) <= CONV_TOL
+
+
+def test_normalize_weights_matches_oracle(ctx, mvs, orc):
+    rng = np.random.default_rng(21)
+    ws = [rng.random((6, 16, 20), dtype=np.float32) * (rng.random((6, 16, 20)) > 0.3) for _ in range(7)]
+    ws = [np.ascontiguousarray(w, dtype=np.float32) for w in ws]
+    a = [w.copy() for w in ws]
+    b = [w.copy() for w in ws]
+    ctx.normalize_weights(a, 3.0)
+    orc.normalize_weights(b, 3.0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    # device-resident form with an externally supplied sum (the sharded multi-GPU case)
+    n = ws[0].size
+    d = [ctx.dev_alloc(n * 4) for _ in ws]
+    d_sum = ctx.dev_alloc(n * 4)
+    try:
+        for p, w in zip(d, ws):
+            ctx.upload(p, w)
+        ctx.sum_views_dev(d, n, d_sum)
+        tot = ctx.download(d_sum, ws[0].shape)
+        s = np.zeros_like(ws[0])
+        for w in ws:
+            s = s + w
+        assert np.array_equal(tot, s)
+        ctx.normalize_weights_dev(d[:3], n, 3.0, sum_dptr=d_sum)     # "this rank" owns views 0..2
+        for p, y in zip(d[:3], b[:3]):
+            assert np.array_equal(ctx.download(p, ws[0].shape), y)
+    finally:
+        for p in d + [d_sum]:
+            ctx.dev_free(p)
+    with pytest.raises(ValueError):
+        ctx.normalize_weights([np.zeros(4, np.float32)] * 40, 3.0)

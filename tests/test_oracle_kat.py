@@ -320,3 +320,22 @@ def test_golden_view_fixture_reproduces(orc, golden_dir):
         assert np.array_equal(res[k], g[k]), k
     assert res["corr"] == float(g["corr"])
     assert np.array_equal(psf, g["psf_norm"])
+
+
+def test_normalize_weights_kats(orc):
+    """SMVD:615-640: per-voxel float sum over views; zero sum -> zeros; else min(1, osem * w / sum)."""
+    w = [np.array([0.0, 0.5, 1.0, 0.2], np.float32), np.array([0.0, 0.5, 1.0, 0.0], np.float32),
+         np.array([0.0, 0.0, 1.0, 0.0], np.float32)]
+    orc.normalize_weights(w, 3.0)
+    assert np.array_equal(w[0], np.array([0.0, 1.0, 1.0, 1.0], np.float32))     # 3*0.5 = 1.5 -> clipped to 1
+    assert np.array_equal(w[1], np.array([0.0, 1.0, 1.0, 0.0], np.float32))
+    assert np.array_equal(w[2], np.array([0.0, 0.0, 1.0, 0.0], np.float32))
+    rng = np.random.default_rng(20)
+    ws = [rng.random(1000, dtype=np.float32) for _ in range(7)]
+    ref = [x.copy() for x in ws]
+    orc.normalize_weights(ws, 3.0)
+    s = np.zeros(1000, np.float32)
+    for x in ref:
+        s = s + x
+    for a, b in zip(ws, ref):
+        assert np.array_equal(a, np.minimum(np.float32(1), np.float32(3.0) * (b / s)))
