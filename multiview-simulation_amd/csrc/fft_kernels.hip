@@ -276,6 +276,9 @@ struct LinesArgs {
     const float2* tw;
     long long     src_es, src_outer, dst_es, dst_outer, spec_es, spec_outer;
     DimMap        lmap;     // SPARSE: position n reads source position map_src(lmap, n) (or zero)
+    int           gap_lo, gap_hi;   // positions n in [gap_lo, gap_hi) are structurally zero: not loaded (gap_hi <= gap_lo: none)
+    int           outer_skip_lo, outer_skip_len;   // outer index by >= outer_skip_lo is shifted by outer_skip_len (skipped planes)
+    int           store_limit;      // > 0: positions n >= store_limit are never read downstream and are not stored
     int           dst_tile_major;   // FWD: store tile (bx,by) as NL contiguous lines of L: dst[((by*gridDim.x+bx)*NL + c)*L + n]
 };
 
@@ -298,7 +301,8 @@ __global__ __launch_bounds__(Cfg<PLAN::len>::T, (2 * Cfg<PLAN::len>::T + 255) / 
     float2* wbuf = buf + wave * LW * LP;    // the lines this wave transforms
 
     // all global loads of the tile are issued before anything waits
-    const float2* sbase = p.src + (long long)blockIdx.y * p.src_outer + (long long)blockIdx.x * NL + c2;
+    const int by = (int)blockIdx.y >= p.outer_skip_lo ? (int)blockIdx.y + p.outer_skip_len : (int)blockIdx.y;
+    const float2* sbase = p.src + (long long)by * p.src_outer + (long long)blockIdx.x * NL + c2;
     float4 v[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(Cfg<PLAN::len>::T, (2 * Cfg<PLAN::len>::T + 255) / 
             if (SPARSE) {
                 const int sn = map_src(p.lmap, n);
                 if (sn >= 0) v[it] = *reinterpret_cast<const float4*>(sbase + sn * p.src_es);
-            } else {
+            } else if (n < p.gap_lo || n >= p.gap_hi) {
                 v[it] = *reinterpret_cast<const float4*>(sbase + n * p.src_es);
             }
         }
@@ -345,11 +349,12 @@ __global__ __launch_bounds__(Cfg<PLAN::len>::T, (2 * Cfg<PLAN::len>::T + 255) / 
         return;
     }
     __syncthreads();
-    float2* dbase = p.dst + (long long)blockIdx.y * p.dst_outer + (long long)blockIdx.x * NL + c2;
+    float2* dbase = p.dst + (long long)by * p.dst_outer + (long long)blockIdx.x * NL + c2;
+    const int nstore = p.store_limit > 0 ? p.store_limit : L;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int n = r0 + it * ROWS;
-        if ((L % ROWS == 0) || n < L) {
+        if (((L % ROWS == 0) || n < L) && n < nstore) {
             float2 a = buf[c2 * LP + n], b = buf[(c2 + 1) * LP + n];
             if (MODE != FWD) { a = cconj(a); b = cconj(b); }
             *reinterpret_cast<float4*>(dbase + n * p.dst_es) = make_float4(a.x, a.y, b.x, b.y);
@@ -393,6 +398,16 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* _
             const int sy = map_src(map.y, y), sz = map_src(map.z, z);
             if (sy >= 0 && sz >= 0) offs[j] = (long long)nxs * (sy + (long long)map.y.n * sz);
         }
+    }
+    // rows in the zero gap of the padded volume are never read by pass B/C (they skip the gap): if none of the
+    // wave's rows carries data the wave only has to keep the block barrier company
+    bool any_row = false;
+#pragma unroll
+    for (int j = 0; j < LW; ++j) any_row |= offs[j] >= 0;
+    if (!any_row && map.x.mode == 0) {
+        for (int i = tid; i < M; i += T) tw[i] = twg[i];
+        __syncthreads();
+        return;
     }
     // (row, lane-pair) items flattened over the wave's rows: every load iteration has all 64 lanes busy
     constexpr int LITEMS = LW * PAIRS;
@@ -917,16 +932,27 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
             *dm[d] = DimMap{n[d], Pd[d], n[d] + c, left, 0, 0};
         }
         MVSIM_TRY(launch_r2c(s, M, img, m, F, tw_m, tw_px, hxp, rows_all));
+        // zero gap of the padded volume: y in [Ny + cy, Py - lefty), z in [Nz + cz, Pz - leftz).  Pass A does not
+        // transform (or write) rows there, pass B skips the gap planes and does not load gap rows, pass C does
+        // not load gap planes.
+        const int ygap_lo = m.y.a, ygap_hi = py - m.y.b, zgap_lo = m.z.a, zgap_hi = pz - m.z.b;
         LinesArgs b{};
         b.src = F; b.dst = F; b.tw = tw_py; b.src_es = b.dst_es = hxp; b.src_outer = b.dst_outer = plane;
         b.lmap = ident_none;
-        MVSIM_TRY(launch_lines(s, py, FWD, false, b, hxp / tile_y, pz));
+        b.gap_lo = ygap_lo; b.gap_hi = ygap_hi;
+        b.outer_skip_lo = zgap_lo; b.outer_skip_len = zgap_hi > zgap_lo ? zgap_hi - zgap_lo : 0;
+        MVSIM_TRY(launch_lines(s, py, FWD, false, b, hxp / tile_y, pz - b.outer_skip_len));
+        b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
         LinesArgs c{};
         c.src = F; c.dst = F; c.spec = G; c.tw = tw_pz;
         c.src_es = c.dst_es = c.spec_es = plane; c.src_outer = c.dst_outer = c.spec_outer = hxp;
         c.lmap = ident_none;
+        c.gap_lo = zgap_lo; c.gap_hi = zgap_hi;
+        c.outer_skip_lo = 1 << 30;
+        c.store_limit = (int)dim[2];                                  // pass D only reads planes z < Nz
         MVSIM_TRY(launch_lines(s, pz, CONV, false, c, hxp / tile_z, py));
         b.tw = tw_py;
+        b.store_limit = (int)dim[1];                                  // pass E only reads rows y < Ny
         MVSIM_TRY(launch_lines(s, py, INV, false, b, hxp / tile_y, (int)dim[2]));   // planes z >= Nz are never read
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
         const float scale = (float)(0.25 / ((double)px * (double)py * (double)pz));
