@@ -47,9 +47,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slab", type=int, default=64, help="z extent of the CPU-baseline sample slab")
     ap.add_argument("--stage-timing", action="store_true", default=True)
-    ap.add_argument("--streams", type=int, default=2,
-                    help="contexts/HIP streams per GPU; views alternate between them so that the VALU-bound Poisson "
-                         "kernel of one view overlaps the HBM-bound passes of the next")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="contexts/HIP streams per GPU; with 2 the views alternate between them so that the VALU-bound "
+                         "Poisson kernel of one view overlaps the HBM-bound passes of the next (+4 %% throughput, but "
+                         "per-kernel durations then include time sharing; the default keeps the roofline clean)")
     return ap.parse_args()
 
 
@@ -152,6 +153,11 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # per-stage HIP events are recorded inside the timed region, on the stream each view runs on (one event set
+    # per view; read once after the final sync): the stage durations include whatever overlap the streams produce
+    if args.stage_timing:
+        for c in ctxs:
+            c.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -162,17 +168,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # per-stage HIP-event timings (events recorded on the stream the kernels run on), outside the timed region
     stage = None
     if rank == 0 and args.stage_timing:
-        ctx.enable_timing(True)
         acc = {}
-        reps = max(2, min(args.steps, 5))
-        for _ in range(reps):
-            ctx.simulate_view_dev(gt_dev.data_ptr(), dims, psfs[0].copy(), params[0], acq[0].data_ptr())
-            for k, v in ctx.timings().items():
-                acc[k] = acc.get(k, 0.0) + v / reps
-        ctx.enable_timing(False)
+        for c in ctxs:
+            for k, v in c.timings().items():
+                acc[k] = acc.get(k, 0.0) + v / len(ctxs)
+            c.enable_timing(False)
         stage = acc
 
     if rank == 0:
@@ -190,7 +192,7 @@ def main():
                                    f"device-resident; BASELINE configs[1] per view, configs[2] sharding",
                        "volume": [n, n, n], "psf": [args.psf] * 3, "views_total": total_views,
                        "views_per_gpu": views_per_gpu, "inc": args.inc, "snr": args.snr,
-                       "conv_method": "fft(rocFFT)" if args.conv_method == 1 else "direct",
+                       "conv_method": "fft (hand-written LDS FFT passes; rocFFT only for unsupported sizes)" if args.conv_method == 1 else "direct stencil",
                        "streams_per_gpu": len(ctxs),
                        "collective": "RCCL broadcast of ground truth per step" if world > 1 else "none"},
         }
@@ -203,7 +205,7 @@ def main():
             conv_bytes = 8 * nvox + 4 * args.psf ** 3
             ach = conv_bytes / (conv_ms * 1e-3) / 1e9
             out["roofline"] = {
-                "bound": "hbm", "kernel": "convolve stage (PSF spectrum + pad + r2c + product + c2r + crop)",
+                "bound": "hbm", "kernel": "convolve stage: k_fft_x_r2c, k_fft_lines<FWD|CONV|INV>, k_fft_x_c2r (+ PSF spectrum)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes": conv_bytes, "launch_ms": conv_ms,
                 "whole_view": {"bytes": b_view, "ms": stage["total_ms"],

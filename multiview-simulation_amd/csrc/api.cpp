@@ -127,18 +127,6 @@ static int check_dim(const int64_t dim[3])
 
 static int64_t nvox(const int64_t dim[3]) { return dim[0] * dim[1] * dim[2]; }
 
-static void ev_begin(mvsim_ctx* ctx, int st)
-{
-    if (ctx->timing) (void)hipEventRecord(ctx->ev[st][0], ctx->stream);
-}
-static void ev_end(mvsim_ctx* ctx, int st)
-{
-    if (ctx->timing) { (void)hipEventRecord(ctx->ev[st][1], ctx->stream); ctx->ev_used[st] = true; }
-}
-static void ev_reset(mvsim_ctx* ctx)
-{
-    for (int s = 0; s < ST_COUNT; ++s) ctx->ev_used[s] = false;
-}
 
 static int set_device(mvsim_ctx* ctx)
 {
@@ -263,7 +251,8 @@ int mvsim_destroy(mvsim_ctx* ctx)
     ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
-        for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(ctx->ev[s][0]); (void)hipEventDestroy(ctx->ev[s][1]); }
+        for (int k = 0; k < mvsim_ctx::TIMING_SLOTS; ++k)
+            for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(ctx->evr[k][s][0]); (void)hipEventDestroy(ctx->evr[k][s][1]); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MVSIM_OK;
@@ -503,7 +492,7 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     MVSIM_CHECK_ARG(dim[0] <= dim[1], "attenuate3d: Nx > Ny walks outside the interval in the reference");
     const int64_t n = nvox(dim);
     const size_t vbytes = (size_t)n * sizeof(float);
-    ev_reset(ctx);
+    ev_next(ctx);
 
     float* rot = o->rot;
     float* att = o->att;
@@ -721,34 +710,51 @@ int mvsim_enable_timing(mvsim_ctx* ctx, int enable)
 {
     MVSIM_TRY(set_device(ctx));
     if (enable && !ctx->ev_created) {
-        for (int s = 0; s < ST_COUNT; ++s) {
-            MVSIM_HIP(hipEventCreate(&ctx->ev[s][0]));
-            MVSIM_HIP(hipEventCreate(&ctx->ev[s][1]));
-        }
+        for (int k = 0; k < mvsim_ctx::TIMING_SLOTS; ++k)
+            for (int s = 0; s < ST_COUNT; ++s) {
+                MVSIM_HIP(hipEventCreate(&ctx->evr[k][s][0]));
+                MVSIM_HIP(hipEventCreate(&ctx->evr[k][s][1]));
+            }
         ctx->ev_created = true;
     }
     ctx->timing = enable != 0;
-    ev_reset(ctx);
+    ctx->ev_cur = 0;
+    ctx->ev_calls = 0;
+    for (int s = 0; s < ST_COUNT; ++s) ctx->ev_used[0][s] = false;
     return MVSIM_OK;
 }
 
+// Averages over the calls recorded since timing was enabled or last read (at most the last TIMING_SLOTS calls).
 int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t)
 {
     MVSIM_TRY(set_device(ctx));
     MVSIM_CHECK_ARG(t != nullptr, "timings pointer is null");
     MVSIM_CHECK_ARG(ctx->ev_created, "timing was never enabled");
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
-    float ms[ST_COUNT] = {};
-    float total = 0.f;
-    for (int s = 0; s < ST_COUNT; ++s) {
-        if (!ctx->ev_used[s]) continue;
-        MVSIM_HIP(hipEventElapsedTime(&ms[s], ctx->ev[s][0], ctx->ev[s][1]));
-        total += ms[s];
+    double sum[ST_COUNT] = {};
+    int cnt[ST_COUNT] = {};
+    const long long calls = ctx->ev_calls == 0 ? 1 : ctx->ev_calls;    // stage operators outside simulate_view use slot 0
+    const int nslots = (int)(calls < mvsim_ctx::TIMING_SLOTS ? calls : mvsim_ctx::TIMING_SLOTS);
+    for (int j = 0; j < nslots; ++j) {
+        const int k = ((ctx->ev_cur - j) % mvsim_ctx::TIMING_SLOTS + mvsim_ctx::TIMING_SLOTS) % mvsim_ctx::TIMING_SLOTS;
+        for (int s = 0; s < ST_COUNT; ++s) {
+            if (!ctx->ev_used[k][s]) continue;
+            float ms = 0.f;
+            MVSIM_HIP(hipEventElapsedTime(&ms, ctx->evr[k][s][0], ctx->evr[k][s][1]));
+            sum[s] += ms;
+            cnt[s] += 1;
+            ctx->ev_used[k][s] = false;
+        }
     }
+    float ms[ST_COUNT];
+    float total = 0.f;
+    for (int s = 0; s < ST_COUNT; ++s) { ms[s] = cnt[s] ? (float)(sum[s] / cnt[s]) : 0.f; total += ms[s]; }
     t->rotate_ms = ms[ST_ROTATE]; t->attenuate_ms = ms[ST_ATTENUATE]; t->psf_ms = ms[ST_PSF];
     t->convolve_ms = ms[ST_CONVOLVE]; t->adjust_ms = ms[ST_ADJUST]; t->extract_ms = ms[ST_EXTRACT];
     t->total_ms = total;
     ctx->last = *t;
+    ctx->ev_cur = 0;
+    ctx->ev_calls = 0;
     return MVSIM_OK;
 }
 

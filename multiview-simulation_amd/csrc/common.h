@@ -111,10 +111,14 @@ struct mvsim_ctx {
     std::map<std::string, mvsim::FftPlan> plans;
     bool   fft_ready = false;
 
-    // timing
+    // timing: a ring of event sets, one set per stage-operator / simulate_view call, so that a host can time
+    // many asynchronous calls and read the averages once (mvsim_get_timings)
+    static constexpr int TIMING_SLOTS = 64;
     bool       timing = false;
-    hipEvent_t ev[mvsim::ST_COUNT][2] = {};
-    bool       ev_used[mvsim::ST_COUNT] = {};
+    hipEvent_t evr[TIMING_SLOTS][mvsim::ST_COUNT][2] = {};
+    bool       ev_used[TIMING_SLOTS][mvsim::ST_COUNT] = {};
+    int        ev_cur = 0;          // slot being recorded
+    long long  ev_calls = 0;        // slots started since timing was enabled / last read
     bool       ev_created = false;
     mvsim_timings last = {};
 
@@ -166,6 +170,27 @@ bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3])
 int  custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                          const int64_t kdim[3], const int64_t P[3], float* out);
 void custom_fft_release(mvsim_ctx* ctx);
+
+// stage timing helpers (events are recorded on the stream the kernels run on)
+inline void ev_begin(mvsim_ctx* ctx, int st)
+{
+    if (ctx->timing) (void)hipEventRecord(ctx->evr[ctx->ev_cur][st][0], ctx->stream);
+}
+inline void ev_end(mvsim_ctx* ctx, int st)
+{
+    if (ctx->timing) {
+        (void)hipEventRecord(ctx->evr[ctx->ev_cur][st][1], ctx->stream);
+        ctx->ev_used[ctx->ev_cur][st] = true;
+    }
+}
+// start a new slot (called once per timed call)
+inline void ev_next(mvsim_ctx* ctx)
+{
+    if (!ctx->timing) return;
+    if (ctx->ev_calls > 0) ctx->ev_cur = (ctx->ev_cur + 1) % mvsim_ctx::TIMING_SLOTS;
+    ctx->ev_calls += 1;
+    for (int s = 0; s < ST_COUNT; ++s) ctx->ev_used[ctx->ev_cur][s] = false;
+}
 
 void axis_rotation_host(const int64_t dim[3], int axis, int degrees, double m[12]);
 void affine_invert_host(const double m[12], double inv[12]);

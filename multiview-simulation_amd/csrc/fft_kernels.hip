@@ -847,15 +847,6 @@ void custom_fft_release(mvsim_ctx* ctx)
     ctx->cfft_g2.release();
 }
 
-static void ev_begin(mvsim_ctx* ctx, int st)
-{
-    if (ctx->timing) (void)hipEventRecord(ctx->ev[st][0], ctx->stream);
-}
-static void ev_end(mvsim_ctx* ctx, int st)
-{
-    if (ctx->timing) { (void)hipEventRecord(ctx->ev[st][1], ctx->stream); ctx->ev_used[st] = true; }
-}
-
 int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                         const int64_t kdim[3], const int64_t P[3], float* out)
 {

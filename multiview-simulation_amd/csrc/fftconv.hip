@@ -251,14 +251,6 @@ void fft_release(mvsim_ctx* ctx)
     custom_fft_release(ctx);
 }
 
-static void ev_begin(mvsim_ctx* ctx, int st)
-{
-    if (ctx->timing) { (void)hipEventRecord(ctx->ev[st][0], ctx->stream); }
-}
-static void ev_end(mvsim_ctx* ctx, int st)
-{
-    if (ctx->timing) { (void)hipEventRecord(ctx->ev[st][1], ctx->stream); ctx->ev_used[st] = true; }
-}
 
 int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,
                  const int64_t kdim[3], float* out_dev, bool want_sum)
