@@ -248,7 +248,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     mvsim_comm_destroy(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release();
+    ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
         for (int k = 0; k < mvsim_ctx::TIMING_SLOTS; ++k)
@@ -406,9 +406,11 @@ int mvsim_extract_slices_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[
     MVSIM_CHECK_ARG(in && out, "null buffer");
     MVSIM_CHECK_ARG(inc >= 1, "inc must be >= 1");
     const bool noise = snr >= 0.0f;   // SMVD:211
+    void* qws = nullptr;
+    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(dim[0] * dim[1] * mvsim_extract_nz(dim[2], inc), nullptr))); qws = ctx->pqueue.p; }
     ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, in, out, dim, inc, false, nullptr, 0.0f, noise,
-                             mvsim_poisson_mul((double)snr), seed, stream, 0));
+                             mvsim_poisson_mul((double)snr), seed, stream, 0, qws));
     ev_end(ctx, ST_EXTRACT);
     return MVSIM_OK;
 }
@@ -533,10 +535,12 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     if (materialise) MVSIM_TRY(launch_adjust_apply(ctx->stream, con, n, scal, p->min_value));
     ev_end(ctx, ST_ADJUST);
 
-    ev_begin(ctx, ST_EXTRACT);
     const bool noise = p->snr >= 0.0f;
+    void* qws = nullptr;
+    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc), nullptr))); qws = ctx->pqueue.p; }
+    ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, con, o->acq, dim, p->inc, !materialise, scal, p->min_value, noise,
-                             mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0));
+                             mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws));
     ev_end(ctx, ST_EXTRACT);
 
     if (correction) {
@@ -644,9 +648,10 @@ int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr, uin
     MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
     MVSIM_TRY(ctx->out_buf.reserve(bytes));
     const int64_t dim[3] = {n, 1, 1};
+    MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(n, nullptr)));
     ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, ctx->vol_a.as<float>(), ctx->out_buf.as<float>(), dim, 1, false, nullptr,
-                             0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset));
+                             0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset, ctx->pqueue.p));
     ev_end(ctx, ST_EXTRACT);
     return down(ctx, img, ctx->out_buf.p, bytes);
 }

@@ -103,6 +103,7 @@ struct mvsim_ctx {
     mvsim::DevBuf fft_real;                 // P^3 floats
     mvsim::DevBuf fft_spec_img, fft_spec_psf;
     mvsim::DevBuf fft_work;
+    mvsim::DevBuf pqueue;                   // Poisson work queue: [count][items]
     mvsim::DevBuf partials;                 // doubles: block partial sums + [sum, corr]
     mvsim::DevBuf partials_e;               // per-block sums of the c2r/crop pass
     mvsim::DevBuf cfft_f, cfft_g;           // custom FFT: image / PSF half spectra [Pz][Py][Hxp]
@@ -144,7 +145,9 @@ int launch_norm_apply(hipStream_t s, float* img, int64_t n, const double* scal);
 // extract (+ optional adjust using scal[1]) (+ optional Poisson).  in: Nx*Ny*Nz, out: Nx*Ny*nzo
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                   uint32_t stream, uint64_t index_offset);
+                   uint32_t stream, uint64_t index_offset, void* queue_ws);
+// bytes of the Poisson work queue (HBM) for n_out output voxels
+size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity);
 int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc);
 int launch_weight_image(hipStream_t s, float* out, const int64_t dim[3]);
 int launch_weights(hipStream_t s, float* const* views, int nv, int64_t n, const float* sum_in, float* sum_out,

@@ -480,15 +480,19 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
     }
 }
 
-// Noise form for production sizes.  Phase 1 (every lane busy): adjust, the low-lambda inversion and the
-// attempt-0 squeeze of PTRS for the lane's 4 voxels.  The ~14 % of bright voxels that need the exact test or a
-// retry go into a block-level work queue in LDS and are processed COMPACTED, one attempt per pass, so the
-// divergent fp64 code (logs, divisions) runs with full waves instead of once per voxel slot with 1-in-7 lanes
-// active.  Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.
+// Noise form for production sizes, two launches.
+//   k_extract4_noise : every lane busy -- adjust, the low-lambda inversion and the attempt-0 squeeze of PTRS for
+//                      the lane's 4 voxels.  The ~1/3 of bright voxels that still need the exact test or a retry
+//                      are appended to a work queue in HBM (wave-aggregated atomic append).
+//   k_poisson_resolve: one queue item per lane, looped until resolved; no LDS, no barriers, full occupancy, and
+//                      every lane starts with real work -- the divergent fp64 code (logs, divisions) no longer
+//                      runs once per voxel slot with 1-in-7 lanes active.
+// Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.
 struct PItem {
-    unsigned long long index;
-    float v;
-    unsigned short slot, attempt;
+    unsigned long long index;     // source voxel index (RNG counter)
+    unsigned long long out;       // element index in the output
+    float v;                      // adjusted voxel value (lambda = v * mul)
+    unsigned int attempt;         // first attempt still to evaluate (0: exact test of attempt 0 pending)
 };
 
 template <bool ADJUST>
@@ -496,134 +500,144 @@ __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict_
                                                         long long plane4, long long nzo, int inc,
                                                         const double* __restrict__ scal, float min_value, double mul,
                                                         uint32_t k0, uint32_t k1, uint32_t stream,
-                                                        unsigned long long index_offset)
+                                                        unsigned long long index_offset, PItem* __restrict__ queue,
+                                                        unsigned int* __restrict__ qcount, unsigned int segcap)
 {
-    __shared__ PItem q[2][1024];
-    __shared__ float res[1024];
-    __shared__ int qn[2];
+    // every block appends to its OWN queue segment: the append counter lives in LDS (one global counter would
+    // serialise at ~88 atomics/us chip-wide)
+    __shared__ unsigned int nq;
+    if (threadIdx.x == 0) nq = 0u;
+    __syncthreads();
+    PItem* __restrict__ seg = queue + (unsigned long long)blockIdx.x * segcap;
     double corr = 1.0;
     if (ADJUST) corr = scal[1];
-    const int tid = threadIdx.x;
     const long long total4 = plane4 * nzo;
-    const long long stride = (long long)gridDim.x * 256;
+    const long long nthreads = (long long)gridDim.x * 256;
     const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
     float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
-    for (long long base = (long long)blockIdx.x * 256; base < total4; base += stride) {
-        const long long o = base + tid;
-        const bool active = o < total4;
-        if (tid == 0) { qn[0] = 0; qn[1] = 0; }
-        __syncthreads();
-        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t pend = 0u;
-        if (active) {
-            const long long k = o / plane4;
-            const long long i = o - k * plane4;
-            const long long src4 = k * inc * plane4 + i;
-            float4 v = in4[src4];
-            if (ADJUST) {
-                v.x = adjust_one(v.x, corr, min_value);
-                v.y = adjust_one(v.y, corr, min_value);
-                v.z = adjust_one(v.z, corr, min_value);
-                v.w = adjust_one(v.w, corr, min_value);
-            }
-            const unsigned long long index4 = index_offset + 4ull * (unsigned long long)src4;
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-            double lam[4];
-            bool small_any = false, bright01 = false, bright23 = false;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total4; o += nthreads) {
+        const long long k = o / plane4;
+        const long long src4 = k * inc * plane4 + (o - k * plane4);
+        float4 v = in4[src4];
+        if (ADJUST) {
+            v.x = adjust_one(v.x, corr, min_value);
+            v.y = adjust_one(v.y, corr, min_value);
+            v.z = adjust_one(v.z, corr, min_value);
+            v.w = adjust_one(v.w, corr, min_value);
+        }
+        const unsigned long long index4 = index_offset + 4ull * (unsigned long long)src4;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        double lam[4];
+        bool small_any = false;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                lam[c] = (double)vv[c] * mul;
-                small_any |= lam[c] > 0.0 && lam[c] < 10.0;
-            }
-            bright01 = lam[0] >= 10.0 || lam[1] >= 10.0;
-            bright23 = lam[2] >= 10.0 || lam[3] >= 10.0;
-            float ov[4] = {0.f, 0.f, 0.f, 0.f};
-            if (small_any) {
-                const unsigned long long g = index4 >> 2;
-                const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream, 0u, k0, k1);
+        for (int c = 0; c < 4; ++c) {
+            lam[c] = (double)vv[c] * mul;
+            small_any |= lam[c] > 0.0 && lam[c] < 10.0;
+        }
+        const bool bright01 = lam[0] >= 10.0 || lam[1] >= 10.0;
+        const bool bright23 = lam[2] >= 10.0 || lam[3] >= 10.0;
+        float ov[4] = {0.f, 0.f, 0.f, 0.f};
+        if (small_any) {
+            const unsigned long long g = index4 >> 2;
+            const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream, 0u, k0, k1);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (lam[c] > 0.0 && lam[c] < 10.0) ov[c] = poisson_small(lam[c], w[c]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 0 ? bright01 : bright23) {
+                const unsigned long long pr = (index4 >> 1) + (unsigned long long)h;
+                const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
                 const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (lam[c] > 0.0 && lam[c] < 10.0) ov[c] = poisson_small(lam[c], w[c]);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 0 ? bright01 : bright23) {
-                    const unsigned long long pr = (index4 >> 1) + (unsigned long long)h;
-                    const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
-                    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int c = 2 * h + e;
-                        if (lam[c] >= 10.0) {
-                            double us, V, kd;
-                            const int st = ptrs_fast(ptrs_setup(lam[c]), lam[c], w[2 * e], w[2 * e + 1], us, V, kd);
-                            if (st == 0) {
-                                ov[c] = (float)(long long)kd;
-                            } else {
-                                const int pos = atomicAdd(&qn[0], 1);
+                for (int e = 0; e < 2; ++e) {
+                    const int c = 2 * h + e;
+                    if (lam[c] >= 10.0) {
+                        double us, V, kd;
+                        const int st = ptrs_fast(ptrs_setup(lam[c]), lam[c], w[2 * e], w[2 * e + 1], us, V, kd);
+                        if (st == 0) {
+                            ov[c] = (float)(long long)kd;
+                        } else {
+                            const unsigned int pos = atomicAdd(&nq, 1u);
+                            if (pos < segcap) {
                                 PItem it;
                                 it.index = index4 + (unsigned long long)c;
+                                it.out = 4ull * (unsigned long long)o + (unsigned long long)c;
                                 it.v = vv[c];
-                                it.slot = (unsigned short)(tid * 4 + c);
-                                it.attempt = (unsigned short)(st == 2 ? 0 : 1);   // exact test of attempt 0, or straight to a retry
-                                q[0][pos] = it;
-                                pend |= 1u << c;
+                                it.attempt = st == 2 ? 0u : 1u;   // exact test of attempt 0, or straight to a retry
+                                seg[pos] = it;
+                            } else {
+                                // queue full (pathological input): resolve in place
+                                ov[c] = poisson_counter(lam[c], k0, k1, stream, index4 + (unsigned long long)c);
                             }
                         }
                     }
                 }
             }
-            r4 = make_float4(ov[0], ov[1], ov[2], ov[3]);
         }
-        int cur = 0;
-        for (;;) {
-            __syncthreads();                       // pushes into q[cur] are complete
-            const int n = qn[cur];
-            if (n == 0) break;
-            for (int i = tid; i < n; i += 256) {
-                const PItem it = q[cur][i];
-                const double lam = (double)it.v * mul;
-                float val;
-                if (it.attempt >= kPtrsMaxAttempts) {
-                    res[it.slot] = (float)(long long)lam;
-                } else {
-                    uint32_t w0, w1;
-                    if (it.attempt == 0) {
-                        const unsigned long long pr = it.index >> 1;
-                        const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
-                        const bool odd = (it.index & 1) != 0;
-                        w0 = odd ? r.z : r.x; w1 = odd ? r.w : r.y;
-                    } else {
-                        ptrs_retry_words(it.index, (uint32_t)it.attempt, k0, k1, stream, w0, w1);
-                    }
-                    if (ptrs_step_words(lam, w0, w1, val)) {
-                        res[it.slot] = val;
-                    } else {
-                        const int pos = atomicAdd(&qn[cur ^ 1], 1);
-                        PItem nx = it;
-                        nx.attempt = (unsigned short)(it.attempt + 1);
-                        q[cur ^ 1][pos] = nx;
-                    }
-                }
-            }
-            __syncthreads();                       // q[cur] / qn[cur] fully consumed
-            if (tid == 0) qn[cur] = 0;
-            cur ^= 1;
-        }
-        if (active) {
-            if (pend & 1u) r4.x = res[tid * 4 + 0];
-            if (pend & 2u) r4.y = res[tid * 4 + 1];
-            if (pend & 4u) r4.z = res[tid * 4 + 2];
-            if (pend & 8u) r4.w = res[tid * 4 + 3];
-            out4[o] = r4;
-        }
+        out4[o] = make_float4(ov[0], ov[1], ov[2], ov[3]);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) qcount[blockIdx.x] = nq < segcap ? nq : segcap;
+}
+
+// One block per queue segment (same grid as k_extract4_noise; the grid-stride walk of that kernel spreads the
+// bright voxels evenly over the segments).
+__global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out, const PItem* __restrict__ queue,
+                                                         const unsigned int* __restrict__ qcount, unsigned int segcap,
+                                                         double mul, uint32_t k0, uint32_t k1, uint32_t stream)
+{
+    const unsigned int n = qcount[blockIdx.x];
+    const PItem* __restrict__ seg = queue + (unsigned long long)blockIdx.x * segcap;
+    for (unsigned int i = threadIdx.x; i < n; i += 256u) {
+        const PItem it = seg[i];
+        const double lam = (double)it.v * mul;
+        float val = 0.f;
+        for (uint32_t a = it.attempt;; ++a) {
+            if (a >= kPtrsMaxAttempts) { val = (float)(long long)lam; break; }
+            uint32_t w0, w1;
+            if (a == 0u) {
+                const unsigned long long pr = it.index >> 1;
+                const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
+                const bool odd = (it.index & 1ull) != 0ull;
+                w0 = odd ? r.z : r.x;
+                w1 = odd ? r.w : r.y;
+            } else {
+                ptrs_retry_words(it.index, a, k0, k1, stream, w0, w1);
+            }
+            if (ptrs_step_words(lam, w0, w1, val)) break;
+        }
+        out[it.out] = val;
+    }
+}
+
+// Work-queue geometry for n_out output voxels: `blocks` blocks of 256 lanes x 4 voxels walk the volume with a
+// grid stride; each owns a segment that holds half of its voxels (more than any real volume leaves pending;
+// beyond that the kernel resolves in place).
+constexpr int POISSON_MAX_BLOCKS = 256 * 64;
+static void poisson_geometry(int64_t n_out, int* blocks, unsigned int* segcap)
+{
+    long long want = (n_out / 4 + 255) / 256;
+    const int b = (int)(want < 1 ? 1 : (want > POISSON_MAX_BLOCKS ? POISSON_MAX_BLOCKS : want));
+    const long long iters = (n_out / 4 + (long long)b * 256 - 1) / ((long long)b * 256);
+    *blocks = b;
+    *segcap = (unsigned int)(iters * 1024 / 2 + 64);
+}
+
+size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)
+{
+    int blocks;
+    unsigned int segcap;
+    poisson_geometry(n_out, &blocks, &segcap);
+    if (capacity) *capacity = (unsigned long long)blocks * segcap;
+    return (size_t)POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);   // [counts][segments]
 }
 
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                   uint32_t stream, uint64_t index_offset)
+                   uint32_t stream, uint64_t index_offset, void* queue_ws)
 {
     const long long plane = (long long)dim[0] * dim[1];
     const long long nzo = (dim[2] - 1) / inc + 1;
@@ -637,13 +651,19 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
 #define MVSIM_LAUNCH_EX4(A, N)                                                                               \
     hipLaunchKernelGGL((k_extract4<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, scal, \
                        min_value, mul, k0, k1, stream, (unsigned long long)index_offset)
-        if (noise && !getenv("MVSIM_POISSON_NOQUEUE")) {
+        if (noise && queue_ws && !getenv("MVSIM_POISSON_NOQUEUE")) {
+            int qblocks;
+            unsigned int segcap;
+            poisson_geometry(total, &qblocks, &segcap);
+            unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
+            PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)POISSON_MAX_BLOCKS * sizeof(unsigned int));
             if (adjust)
-                hipLaunchKernelGGL((k_extract4_noise<true>), dim3(blocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
-                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset);
+                hipLaunchKernelGGL((k_extract4_noise<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
+                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
             else
-                hipLaunchKernelGGL((k_extract4_noise<false>), dim3(blocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
-                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset);
+                hipLaunchKernelGGL((k_extract4_noise<false>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
+                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
+            hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks), dim3(256), 0, s, out, queue, qcount, segcap, mul, k0, k1, stream);
         }
         else if (adjust && noise) MVSIM_LAUNCH_EX4(true, true);
         else if (adjust) MVSIM_LAUNCH_EX4(true, false);
