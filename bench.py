@@ -32,6 +32,12 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
+# HBM bytes per view and stage measured with rocprofv3 PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes) for
+# the default workload; key = (volume edge, PSF edge, inc).  Source: profiles/r01_c_pmc_hbm_traffic.txt
+MEASURED_TRAFFIC = {
+    (512, 31, 1): {"rotate_attenuate": 1.07e9, "convolve": 8.55e9, "extract_poisson": 1.07e9},
+}
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
@@ -198,16 +204,40 @@ def main():
         }
         if stage:
             nprime = n * n * nzo
+            k3 = args.psf ** 3
+            # ALGORITHMIC bytes per reference stage: each stage reads its input once and
+            # writes its output once; adjustImage costs nothing extra on the fused path.
+            alg = {
+                "rotate_attenuate": 16 * nvox,               # rotate 8N + attenuate 8N (one fused kernel)
+                "convolve": 8 * nvox + 4 * k3,               # + PSF spectrum, 9 launches
+                "extract_poisson": 8 * nprime,               # 2 launches
+            }
+            ms = {
+                "rotate_attenuate": stage["rotate_ms"] + stage["attenuate_ms"],
+                "convolve": stage["psf_ms"] + stage["convolve_ms"] + stage["adjust_ms"],
+                "extract_poisson": stage["extract_ms"],
+            }
+            stages = {k: {"algorithmic_bytes": alg[k], "ms": round(ms[k], 4),
+                          "GBps": alg[k] / (ms[k] * 1e-3) / 1e9, "frac": alg[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                      for k in alg}
+            dom = max(ms, key=ms.get)
             b_view = 24 * nvox + 8 * nprime
             b_cn = 8 * nvox + 8 * nprime
-            conv_ms = stage["psf_ms"] + stage["convolve_ms"]
-            cn_ms = conv_ms + stage["adjust_ms"] + stage["extract_ms"]
-            conv_bytes = 8 * nvox + 4 * args.psf ** 3
-            ach = conv_bytes / (conv_ms * 1e-3) / 1e9
+            cn_ms = ms["convolve"] + ms["extract_poisson"]
+            names = {
+                "convolve": "convolve stage = 9 launches: PSF spectrum (k_fft_x_r2c, 2x k_fft_lines<FWD,sparse>), "
+                            "k_fft_x_r2c, k_fft_lines<FWD>, k_fft_lines<CONV>, k_fft_lines<INV>, k_fft_x_c2r, k_reduce_partials",
+                "extract_poisson": "extract stage = k_extract4_noise + k_poisson_resolve",
+                "rotate_attenuate": "k_rotate_attenuate_axis0",
+            }
             out["roofline"] = {
-                "bound": "hbm", "kernel": "convolve stage: k_fft_x_r2c, k_fft_lines<FWD|CONV|INV>, k_fft_x_c2r (+ PSF spectrum)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes": conv_bytes, "launch_ms": conv_ms,
+                "bound": "hbm", "kernel": names[dom],
+                "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stages[dom]["frac"],
+                # HBM bytes per launch group from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate
+                # passes of this same command: profiles/r01_c_pmc_hbm_traffic.txt (not collected live)
+                "traffic": MEASURED_TRAFFIC.get((n, args.psf, args.inc), {}).get(dom),
+                "algorithmic_bytes": alg[dom], "launch_ms": ms[dom],
+                "stages": stages,
                 "whole_view": {"bytes": b_view, "ms": stage["total_ms"],
                                "frac": b_view / (stage["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "convolve_noise": {"bytes": b_cn, "ms": cn_ms, "frac": b_cn / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
