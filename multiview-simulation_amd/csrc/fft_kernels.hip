@@ -85,6 +85,64 @@ template <> __device__ __forceinline__ void dft<8>(float2* u)
     }
 }
 
+__device__ __forceinline__ float2 cscale(float c, float2 a) { return make_float2(c * a.x, c * a.y); }
+__device__ __forceinline__ float2 cfma(float c, float2 a, float2 b) { return make_float2(fmaf(c, a.x, b.x), fmaf(c, a.y, b.y)); }
+
+template <> __device__ __forceinline__ void dft<5>(float2* u)
+{
+    const float c1 = 0.30901699437494745f, c2 = -0.8090169943749473f;    // cos(2pi/5), cos(4pi/5)
+    const float s1 = 0.9510565162951535f, s2 = 0.5877852522924732f;      // sin(2pi/5), sin(4pi/5)
+    const float2 t1 = cadd(u[1], u[4]), t2 = cadd(u[2], u[3]);
+    const float2 d1 = csub(u[1], u[4]), d2 = csub(u[2], u[3]);
+    const float2 m1 = cfma(c2, t2, cfma(c1, t1, u[0]));
+    const float2 m2 = cfma(c1, t2, cfma(c2, t1, u[0]));
+    const float2 q1 = mul_mi(cfma(s2, d2, cscale(s1, d1)));             // -i (s1 d1 + s2 d2)
+    const float2 q2 = mul_mi(cfma(-s1, d2, cscale(s2, d1)));            // -i (s2 d1 - s1 d2)
+    u[0] = cadd(u[0], cadd(t1, t2));
+    u[1] = cadd(m1, q1);
+    u[4] = csub(m1, q1);
+    u[2] = cadd(m2, q2);
+    u[3] = csub(m2, q2);
+}
+
+template <> __device__ __forceinline__ void dft<7>(float2* u)
+{
+    const float c1 = 0.6234898018587336f, c2 = -0.22252093395631434f, c3 = -0.900968867902419f;
+    const float s1 = 0.7818314824680298f, s2 = 0.9749279121818236f, s3 = 0.43388373911755823f;
+    const float2 t1 = cadd(u[1], u[6]), t2 = cadd(u[2], u[5]), t3 = cadd(u[3], u[4]);
+    const float2 d1 = csub(u[1], u[6]), d2 = csub(u[2], u[5]), d3 = csub(u[3], u[4]);
+    const float2 m1 = cfma(c3, t3, cfma(c2, t2, cfma(c1, t1, u[0])));
+    const float2 m2 = cfma(c1, t3, cfma(c3, t2, cfma(c2, t1, u[0])));
+    const float2 m3 = cfma(c2, t3, cfma(c1, t2, cfma(c3, t1, u[0])));
+    const float2 q1 = mul_mi(cfma(s3, d3, cfma(s2, d2, cscale(s1, d1))));
+    const float2 q2 = mul_mi(cfma(-s1, d3, cfma(-s3, d2, cscale(s2, d1))));
+    const float2 q3 = mul_mi(cfma(s2, d3, cfma(-s1, d2, cscale(s3, d1))));
+    u[0] = cadd(cadd(u[0], t1), cadd(t2, t3));
+    u[1] = cadd(m1, q1);
+    u[6] = csub(m1, q1);
+    u[2] = cadd(m2, q2);
+    u[5] = csub(m2, q2);
+    u[3] = cadd(m3, q3);
+    u[4] = csub(m3, q3);
+}
+
+template <> __device__ __forceinline__ void dft<10>(float2* u)
+{
+    float2 e[5] = {u[0], u[2], u[4], u[6], u[8]};
+    float2 o[5] = {u[1], u[3], u[5], u[7], u[9]};
+    dft<5>(e);
+    dft<5>(o);
+    o[1] = cmul(o[1], make_float2(0.8090169943749475f, -0.5877852522924731f));     // w10^1
+    o[2] = cmul(o[2], make_float2(0.30901699437494745f, -0.9510565162951535f));    // w10^2
+    o[3] = cmul(o[3], make_float2(-0.30901699437494734f, -0.9510565162951536f));   // w10^3
+    o[4] = cmul(o[4], make_float2(-0.8090169943749473f, -0.5877852522924732f));    // w10^4
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        u[k] = cadd(e[k], o[k]);
+        u[k + 5] = csub(e[k], o[k]);
+    }
+}
+
 template <> __device__ __forceinline__ void dft<9>(float2* u)
 {
     // 9 = 3 x 3: columns n1 (stride 3), twiddle w9^(n1*k2), rows
@@ -661,23 +719,40 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
 #define MVSIM_FFT_SIZES(X) \
     X(16, 4, 4)            \
     X(18, 9, 2)            \
+    X(20, 5, 4)            \
     X(24, 3, 8)            \
     X(32, 4, 8)            \
     X(36, 9, 4)            \
+    X(40, 5, 8)            \
     X(48, 3, 4, 4)         \
+    X(56, 7, 8)            \
     X(64, 8, 8)            \
     X(72, 9, 8)            \
+    X(80, 5, 4, 4)         \
     X(96, 3, 8, 4)         \
+    X(112, 7, 4, 4)        \
     X(128, 4, 8, 4)        \
+    X(140, 7, 5, 4)        \
     X(144, 9, 4, 4)        \
+    X(160, 5, 8, 4)        \
     X(192, 3, 8, 8)        \
+    X(224, 7, 8, 4)        \
     X(256, 4, 8, 8)        \
+    X(280, 7, 5, 8)        \
     X(288, 9, 8, 4)        \
+    X(320, 5, 8, 8)        \
+    X(360, 9, 5, 8)        \
     X(384, 3, 8, 4, 4)     \
+    X(448, 7, 8, 8)        \
     X(512, 8, 8, 8)        \
+    X(560, 7, 8, 10)       \
     X(576, 9, 8, 8)        \
+    X(640, 5, 8, 4, 4)     \
+    X(720, 9, 8, 10)       \
     X(768, 3, 8, 8, 4)     \
+    X(896, 7, 8, 4, 4)     \
     X(1024, 4, 8, 8, 4)    \
+    X(1120, 7, 8, 5, 4)    \
     X(1152, 9, 8, 4, 4)
 
 static const int kSizes[] = {

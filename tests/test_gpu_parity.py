@@ -65,6 +65,20 @@ def test_convolve_matches_oracle(ctx, orc, synth, method, shape, kshape):
     assert np.allclose(p1, p2, rtol=0, atol=1e-9) and abs(float(p1.astype(np.float64).sum()) - 1) < 1e-6
 
 
+@pytest.mark.parametrize("shape,kshape", [((33, 100, 66), (8, 13, 15)),     # padded 40 (5*8), 112 (7*4*4), 2*40
+                                          ((130, 50, 270), (11, 7, 11)),    # padded 140 (7*5*4), 56 (7*8), 2*140
+                                          ((150, 36, 40), (11, 5, 9))])     # padded 160 (5*8*4), 40, 2*24
+def test_convolve_radix5_7_sizes(ctx, orc, shape, kshape):
+    rng = np.random.default_rng(13)
+    v = rng.random(shape, dtype=np.float32)
+    psf = rng.random(kshape, dtype=np.float32) + 0.01
+    got = ctx.convolve(v, psf.copy(), method=1)
+    want = orc.convolve_fft(v, psf.copy())          # float32 FFT restatement (the direct sum is slow at these sizes)
+    assert rel_to_max(got, want) <= CONV_TOL
+    got2 = ctx.convolve(v, psf.copy(), method=2)    # and the FFT-independent stencil
+    assert rel_to_max(got, got2) <= CONV_TOL
+
+
 @pytest.mark.parametrize("method", [1, 2])
 def test_convolve_delta_shift_kat(ctx, method):
     v = np.random.default_rng(4).random((10, 11, 12), dtype=np.float32)
