@@ -108,7 +108,7 @@ struct mvsim_ctx {
     mvsim::DevBuf partials_e;               // per-block sums of the c2r/crop pass
     mvsim::DevBuf cfft_f, cfft_g;           // custom FFT: image / PSF half spectra [Pz][Py][Hxp]
     mvsim::DevBuf cfft_g1, cfft_g2;         // compact PSF intermediates [Kz][Ky][Hxp], [Kz][Py][Hxp]
-    std::map<int, void*> twiddles;          // length -> device table exp(-2 pi i k / L), k = 0..L
+    std::map<int, void*> twiddles;          // 2*length + kind -> device twiddle table (fft_kernels.hip)
     std::map<std::string, mvsim::FftPlan> plans;
     bool   fft_ready = false;
 

@@ -197,10 +197,13 @@ struct LoadMulConj {
     }
 };
 
-template <int L, int LP, int LW, int P, class OP>
+// Twiddles: one table per transform length, laid out PER PASS and r-major -- pass (P, R) owns (R-1)*P entries at
+// offset TOFF, entry (r-1)*P + k = exp(-2 pi i r k / (P R)).  Consecutive lanes (consecutive k) read consecutive
+// LDS words: conflict-free, unlike indexing one exp(-2 pi i j / L) table at stride r*L/(P R).
+template <int L, int LP, int LW, int P, int TOFF, class OP>
 __device__ __forceinline__ void wpasses(float2*, const float2*, int, const OP&) {}
 
-template <int L, int LP, int LW, int P, class OP, int R, int... Rest>
+template <int L, int LP, int LW, int P, int TOFF, class OP, int R, int... Rest>
 __device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2* __restrict__ tw, int lane, const OP& op)
 {
     constexpr int STR = L / R;
@@ -229,9 +232,8 @@ __device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2*
             const int k = i % P;
             const int j = (i - k) * R + k;
             if (P > 1) {
-                const int idx = k * (L / (P * R));
 #pragma unroll
-                for (int r = 1; r < R; ++r) u[it][r] = cmul(u[it][r], tw[r * idx]);
+                for (int r = 1; r < R; ++r) u[it][r] = cmul(u[it][r], tw[TOFF + (r - 1) * P + k]);
             }
             dft<R>(u[it]);
             float2* dst = wbuf + line * LP + j;
@@ -240,7 +242,7 @@ __device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2*
         }
     }
     wave_order();
-    wpasses<L, LP, LW, P * R, OP, Rest...>(wbuf, tw, lane, op);
+    wpasses<L, LP, LW, P * R, TOFF + (P > 1 ? (R - 1) * P : 0), OP, Rest...>(wbuf, tw, lane, op);
 }
 
 // complex elements per wave in the x passes: 576 (2 rows of 288) keeps 8 blocks x 4 waves resident per CU
@@ -281,12 +283,12 @@ template <int L, int... Rs> struct Plan {
     template <int LW>
     static __device__ __forceinline__ void run(float2* wbuf, const float2* tw, int lane)
     {
-        wpasses<L, L + 1, LW, 1, LoadIdentity, Rs...>(wbuf, tw, lane, LoadIdentity{});
+        wpasses<L, L + 1, LW, 1, 0, LoadIdentity, Rs...>(wbuf, tw, lane, LoadIdentity{});
     }
     template <int LW, class OP>
     static __device__ __forceinline__ void run_op(float2* wbuf, const float2* tw, int lane, const OP& op)
     {
-        wpasses<L, L + 1, LW, 1, OP, Rs...>(wbuf, tw, lane, op);
+        wpasses<L, L + 1, LW, 1, 0, OP, Rs...>(wbuf, tw, lane, op);
     }
 };
 
@@ -755,6 +757,17 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     X(1120, 7, 8, 5, 4)    \
     X(1152, 9, 8, 4, 4)
 
+struct PlanDesc {
+    int len;
+    int nrad;
+    int rad[5];
+};
+static const PlanDesc kPlans[] = {
+#define X(L, ...) {L, (int)(sizeof((int[]){__VA_ARGS__}) / sizeof(int)), {__VA_ARGS__}},
+    MVSIM_FFT_SIZES(X)
+#undef X
+};
+
 static const int kSizes[] = {
 #define X(L, ...) L,
     MVSIM_FFT_SIZES(X)
@@ -893,21 +906,43 @@ bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3])
     return true;
 }
 
-static int ensure_twiddles(mvsim_ctx* ctx, int L, const float2** out)
+// kind 0: per-pass transform table of the plan for length L (see wpasses); kind 1: plain exp(-2 pi i k / L),
+// k = 0..L (the real<->complex post/pre-processing of the x passes).
+static int ensure_twiddles(mvsim_ctx* ctx, int L, int kind, const float2** out)
 {
-    auto it = ctx->twiddles.find(L);
+    const int key = L * 2 + kind;
+    auto it = ctx->twiddles.find(key);
     if (it != ctx->twiddles.end()) { *out = reinterpret_cast<const float2*>(it->second); return MVSIM_OK; }
-    std::vector<float2> h((size_t)L + 1);
-    for (int k = 0; k <= L; ++k) {
-        const double a = -2.0 * M_PI * (double)k / (double)L;
-        h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    std::vector<float2> h((size_t)L + 1, make_float2(0.f, 0.f));
+    if (kind == 1) {
+        for (int k = 0; k <= L; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)L;
+            h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    } else {
+        const fft::PlanDesc* pd = nullptr;
+        for (const auto& d : fft::kPlans) if (d.len == L) pd = &d;
+        if (!pd) { set_error("custom FFT: no plan for length %d", L); return MVSIM_EINVAL; }
+        int P = 1, off = 0;
+        for (int i = 0; i < pd->nrad; ++i) {
+            const int R = pd->rad[i];
+            if (P > 1) {
+                for (int r = 1; r < R; ++r)
+                    for (int k = 0; k < P; ++k) {
+                        const double a = -2.0 * M_PI * (double)r * (double)k / ((double)P * (double)R);
+                        h[(size_t)off + (size_t)(r - 1) * P + k] = make_float2((float)std::cos(a), (float)std::sin(a));
+                    }
+                off += (R - 1) * P;
+            }
+            P *= R;
+        }
     }
     void* d = nullptr;
     MVSIM_HIP(hipMalloc(&d, h.size() * sizeof(float2)));
     // synchronous copy from a temporary: happens once per length per context
     hipError_t e = hipMemcpy(d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); set_error("twiddle upload failed: %s", hipGetErrorString(e)); return MVSIM_EHIP; }
-    ctx->twiddles[L] = d;
+    ctx->twiddles[key] = d;
     *out = reinterpret_cast<const float2*>(d);
     return MVSIM_OK;
 }
@@ -944,10 +979,10 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
     double* scal = ctx->partials.as<double>() + SUM_BLOCKS;
 
     const float2 *tw_m, *tw_px, *tw_py, *tw_pz;
-    MVSIM_TRY(ensure_twiddles(ctx, M, &tw_m));
-    MVSIM_TRY(ensure_twiddles(ctx, px, &tw_px));
-    MVSIM_TRY(ensure_twiddles(ctx, py, &tw_py));
-    MVSIM_TRY(ensure_twiddles(ctx, pz, &tw_pz));
+    MVSIM_TRY(ensure_twiddles(ctx, M, 0, &tw_m));
+    MVSIM_TRY(ensure_twiddles(ctx, px, 1, &tw_px));
+    MVSIM_TRY(ensure_twiddles(ctx, py, 0, &tw_py));
+    MVSIM_TRY(ensure_twiddles(ctx, pz, 0, &tw_pz));
 
     float2* F = ctx->cfft_f.as<float2>();
     float2* G = ctx->cfft_g.as<float2>();
