@@ -462,10 +462,13 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
     const long long nthreads = (long long)gridDim.x * 256;
     const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
     float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+    const bool small32 = total4 < (1ll << 32);
     for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total4; o += nthreads) {
-        const long long k = o / plane4;
-        const long long i = o - k * plane4;
-        const long long src4 = k * inc * plane4 + i;
+        long long src4 = o;
+        if (inc != 1) {
+            const long long k = small32 ? (long long)((unsigned)o / (unsigned)plane4) : o / plane4;
+            src4 = k * inc * plane4 + (o - k * plane4);
+        }
         float4 v = in4[src4];
         if (ADJUST) {
             v.x = adjust_one(v.x, corr, min_value);
@@ -515,9 +518,14 @@ __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict_
     const long long nthreads = (long long)gridDim.x * 256;
     const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
     float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+    const bool small32 = total4 < (1ll << 32);
     for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total4; o += nthreads) {
-        const long long k = o / plane4;
-        const long long src4 = k * inc * plane4 + (o - k * plane4);
+        long long src4 = o;                                  // inc == 1: extracted planes are the source planes
+        if (inc != 1) {
+            // 64-bit division by a run-time value costs ~100 instructions: avoid it whenever the index fits 32 bits
+            const long long k = small32 ? (long long)((unsigned)o / (unsigned)plane4) : o / plane4;
+            src4 = k * inc * plane4 + (o - k * plane4);
+        }
         float4 v = in4[src4];
         if (ADJUST) {
             v.x = adjust_one(v.x, corr, min_value);
@@ -560,18 +568,14 @@ __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict_
                         if (st == 0) {
                             ov[c] = (float)(long long)kd;
                         } else {
+                            // the segment holds every voxel of the block (worst case: all pending), so this cannot overflow
                             const unsigned int pos = atomicAdd(&nq, 1u);
-                            if (pos < segcap) {
-                                PItem it;
-                                it.index = index4 + (unsigned long long)c;
-                                it.out = 4ull * (unsigned long long)o + (unsigned long long)c;
-                                it.v = vv[c];
-                                it.attempt = st == 2 ? 0u : 1u;   // exact test of attempt 0, or straight to a retry
-                                seg[pos] = it;
-                            } else {
-                                // queue full (pathological input): resolve in place
-                                ov[c] = poisson_counter(lam[c], k0, k1, stream, index4 + (unsigned long long)c);
-                            }
+                            PItem it;
+                            it.index = index4 + (unsigned long long)c;
+                            it.out = 4ull * (unsigned long long)o + (unsigned long long)c;
+                            it.v = vv[c];
+                            it.attempt = st == 2 ? 0u : 1u;       // exact test of attempt 0, or straight to a retry
+                            seg[pos] = it;
                         }
                     }
                 }
@@ -614,8 +618,7 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out
 }
 
 // Work-queue geometry for n_out output voxels: `blocks` blocks of 256 lanes x 4 voxels walk the volume with a
-// grid stride; each owns a segment that holds half of its voxels (more than any real volume leaves pending;
-// beyond that the kernel resolves in place).
+// grid stride; each owns a segment that can hold all of its voxels (24 B per output voxel of HBM workspace).
 constexpr int POISSON_MAX_BLOCKS = 256 * 64;
 static void poisson_geometry(int64_t n_out, int* blocks, unsigned int* segcap)
 {
@@ -623,7 +626,7 @@ static void poisson_geometry(int64_t n_out, int* blocks, unsigned int* segcap)
     const int b = (int)(want < 1 ? 1 : (want > POISSON_MAX_BLOCKS ? POISSON_MAX_BLOCKS : want));
     const long long iters = (n_out / 4 + (long long)b * 256 - 1) / ((long long)b * 256);
     *blocks = b;
-    *segcap = (unsigned int)(iters * 1024 / 2 + 64);
+    *segcap = (unsigned int)(iters * 1024);       // every voxel of the block: the squeeze accepts only ~35 % at lambda = 10
 }
 
 size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)

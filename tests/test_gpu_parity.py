@@ -370,3 +370,73 @@ def test_normalize_weights_matches_oracle(ctx, mvs, orc):
             ctx.dev_free(p)
     with pytest.raises(ValueError):
         ctx.normalize_weights([np.zeros(4, np.float32)] * 40, 3.0)
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def test_degenerate_and_ragged_shapes(ctx, orc):
+    """1-voxel volumes, PSFs larger than the image (multiple mirror reflections), inc beyond Nz."""
+    one = np.full((1, 1, 1), 2.5, np.float32)
+    p1 = np.full((1, 1, 1), 7.0, np.float32)
+    assert np.array_equal(ctx.rotate_around_axis(one, 0, 37), orc.rotate_around_axis(one, 0, 37))
+    assert np.array_equal(ctx.attenuate3d(one, 0.1), orc.attenuate3d(one, 0.1))
+    for method in (1, 2):
+        assert np.allclose(ctx.convolve(one, p1.copy(), method=method), 2.5, rtol=1e-6)
+    assert np.array_equal(ctx.extract_slices(one, 5, -1.0, 0), one)
+    rng = np.random.default_rng(30)
+    small = rng.random((4, 5, 6), dtype=np.float32)
+    big_psf = rng.random((9, 11, 13), dtype=np.float32) + 0.01
+    want = orc.convolve_direct(small, big_psf.copy())
+    for method in (1, 2):
+        assert rel_to_max(ctx.convolve(small, big_psf.copy(), method=method), want) <= CONV_TOL
+    v = rng.random((3, 6, 6), dtype=np.float32)
+    assert np.array_equal(ctx.extract_slices(v, 100, -1.0, 0), v[:1])
+    assert ctx.extract_slices(v, 3, 25.0, 9).shape == (1, 6, 6)
+
+
+def test_fused_view_other_axes_and_odd_dims(ctx, orc):
+    """axis != 0 and odd sizes take the generic rotate + separate attenuate path inside simulate_view."""
+    rng = np.random.default_rng(31)
+    gt = rng.random((11, 13, 9), dtype=np.float32)
+    psf0 = rng.random((3, 5, 3), dtype=np.float32) + 0.05
+    for axis, deg in ((1, 40), (2, -25), (0, 77)):
+        p = ctx.view_params(axis=axis, degrees=deg, inc=2, snr=25.0, seed=SEED, stream=2, conv_method=1)
+        res = ctx.simulate_view(gt, psf0.copy(), p, want=("rot", "att", "con", "acq"))
+        rot = orc.rotate_around_axis(gt, axis, deg)
+        att = orc.attenuate3d(rot, 0.01)
+        assert np.array_equal(res["rot"], rot) and np.array_equal(res["att"], att)
+        con = orc.convolve_direct(att, psf0.copy())
+        orc.adjust_image(con, 1e-4, 1.0)
+        assert rel_to_max(res["con"], con) <= CONV_TOL
+        assert np.array_equal(res["acq"], orc.extract_slices_counter(res["con"], 2, 25.0, SEED, 2))
+
+
+def test_context_reuse_across_sizes_and_cache_release(mvs, orc, synth):
+    """Workspaces and plans regrow / are rebuilt when the same context sees different problem sizes."""
+    with mvs.Context(0) as c:
+        outs = []
+        for n, k in ((24, 5), (40, 9), (16, 3), (40, 9)):
+            v = synth.sphere_phantom(n)
+            psf = synth.gaussian_psf(k, sigma=(1.0, 1.2, 1.5))
+            got = c.convolve(v, psf.copy(), method=1)
+            assert rel_to_max(got, orc.convolve_fft(v, psf.copy())) <= CONV_TOL
+            outs.append(got)
+        assert np.array_equal(outs[1], outs[3])          # same inputs, same context -> same bits
+        c.release_caches()
+        again = c.convolve(synth.sphere_phantom(40), synth.gaussian_psf(9, sigma=(1.0, 1.2, 1.5)), method=1)
+        assert np.array_equal(again, outs[1])
+
+
+def test_invalid_arguments_are_rejected(ctx):
+    v = np.zeros((4, 4, 4), np.float32)
+    with pytest.raises(ValueError):
+        ctx.rotate_around_axis(v, 3, 10)
+    with pytest.raises(ValueError):
+        ctx.rotate_around_axis(np.zeros((4, 4), np.float32), 0, 10)
+    with pytest.raises(ValueError):
+        ctx.convolve(v, np.ones((3, 3, 3), np.float32), method=7)
+    with pytest.raises(ValueError):
+        ctx.make_isotropic(v, 0)
+    with pytest.raises(ValueError):
+        ctx.adjust_image(np.zeros((4, 4, 4), np.float64), 1e-4, 1.0)      # wrong dtype for an in-place operator
+    with pytest.raises(ValueError):
+        ctx.simulate_view(v, np.ones((3, 3, 3), np.float32), ctx.view_params(inc=0))
