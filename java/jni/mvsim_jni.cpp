@@ -134,6 +134,15 @@ JNIEXPORT void JNICALL JNI_FN(axisRotation)(JNIEnv* env, jclass, jlongArray dim,
     env->SetDoubleArrayRegion(m12, 0, 12, m);
 }
 
+JNIEXPORT void JNICALL JNI_FN(normalizeWeights)(JNIEnv* env, jclass, jlong h, jobjectArray weights, jlong n, jfloat osem)
+{
+    const jsize nv = env->GetArrayLength(weights);
+    if (nv > MVSIM_MAX_VIEWS) { throw_for(env, MVSIM_EINVAL); return; }
+    float* ptr[MVSIM_MAX_VIEWS];
+    for (jsize v = 0; v < nv; ++v) ptr[v] = fptr(env, env->GetObjectArrayElement(weights, v));
+    throw_for(env, mvsim_normalize_weights(ctx_of(h), ptr, (int)nv, n, osem));
+}
+
 JNIEXPORT jdouble JNICALL JNI_FN(simulateView)(JNIEnv* env, jclass, jlong h, jobject gt, jlongArray dim, jobject psf,
                                                jlongArray kdim, jint axis, jint degrees, jdouble delta,
                                                jfloat min_value, jfloat target, jint inc, jfloat snr, jlong seed,

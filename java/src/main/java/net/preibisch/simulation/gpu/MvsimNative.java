@@ -31,6 +31,9 @@ final class MvsimNative
 	static native void computeWeightImage( long ctx, long[] dim, FloatBuffer out );
 	static native void axisRotation( long[] dim, int axis, int degrees, double[] m12 );
 
+	/** Cross-view weight normalisation (:615-640), in place on every buffer. */
+	static native void normalizeWeights( long ctx, FloatBuffer[] weights, long n, float osem );
+
 	/** Fused loop body of SimulateMultiViewDataset.main (:570-585); rot/att/con may be null. */
 	static native double simulateView( long ctx, FloatBuffer gt, long[] dim, FloatBuffer psf, long[] kdim,
 			int axis, int degrees, double delta, float minValue, float targetAverage, int inc, float snr, long seed, int stream,

@@ -105,6 +105,20 @@ public class SimulateMultiViewDatasetGPU
 		return Buffers.toImg( out, d );
 	}
 
+	/**
+	 * The block of main() after the view loop (:615-640): per voxel, sum the weights of all views; zero sum gives
+	 * zero weights, otherwise w = min( 1, osem * w / sum ).  In place on the given images.
+	 */
+	public static void normalizeWeights( final java.util.List< Img< FloatType > > weights, final float osem )
+	{
+		final FloatBuffer[] b = new FloatBuffer[ weights.size() ];
+		for ( int i = 0; i < b.length; ++i )
+			b[ i ] = Buffers.toBuffer( weights.get( i ) );
+		MvsimNative.normalizeWeights( GpuContextPool.get(), b, b[ 0 ].capacity(), osem );
+		for ( int i = 0; i < b.length; ++i )
+			Buffers.copyBack( b[ i ], weights.get( i ) );
+	}
+
 	/** One view of the main loop (:570-585) with intermediates kept in HBM; returns { rot, att, con, acq }. */
 	public static Img< FloatType >[] simulateView( final RandomAccessibleInterval< FloatType > groundTruth, final Img< FloatType > psf,
 			final int degrees, final double attenuation, final int lightsheetSpacing, final float poissonSNR, final Random rnd, final int view )
