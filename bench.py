@@ -7,9 +7,11 @@ A *step* simulates `--views-per-gpu` views (default 8: the "512^3 volume x 8 vie
 BASELINE.json) of one ground-truth volume on every rank: rotate -> attenuate -> PSF convolve -> adjust
 -> slice extraction -> Poisson, device-resident (ground truth and all acquisitions stay in HBM).
 With N > 1 ranks (one process per GPU, torch.distributed / RCCL) the views of a dataset shard
-round-robin over the ranks (view v -> rank v % N); each step starts with the broadcast of the ground
-truth from rank 0 over xGMI -- the only collective on the path -- and is followed by the views of this
-rank.  Scaling is weak: per-GPU work (8 views) is fixed, the dataset has 8*N views.
+round-robin over the ranks (view v -> rank v % N); every step contains one broadcast of a ground truth
+from rank 0 over xGMI -- the only collective on the path -- and the views of this rank.  The broadcast
+is issued one dataset ahead into the second of two ground-truth buffers on its own HIP stream, so it
+overlaps the views of the current dataset (`--serial-broadcast` puts it in front of them instead).
+Scaling is weak: per-GPU work (8 views) is fixed, the dataset has 8*N views.
 
 Rank 0 prints ONE JSON line (schema in the task contract) including
   roofline     -- HBM roofline of the dominant stage, algorithmic bytes / HIP-event time
@@ -33,7 +35,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 # HBM bytes per view and stage measured with rocprofv3 PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes) for
-# the default workload; key = (volume edge, PSF edge, inc).  Source: profiles/r01_c_pmc_hbm_traffic.txt
+# the default workload; key = (volume edge, PSF edge, inc).  Source: profiles/r01_d_pmc_hbm_traffic.txt
 MEASURED_TRAFFIC = {
     (512, 31, 1): {"rotate_attenuate": 1.06e9, "convolve": 7.96e9, "extract_poisson": 1.52e9},
 }
@@ -57,6 +59,10 @@ def parse_args():
                     help="contexts/HIP streams per GPU; with 2 the views alternate between them so that the VALU-bound "
                          "Poisson kernel of one view overlaps the HBM-bound passes of the next (+4 %% throughput, but "
                          "per-kernel durations then include time sharing; the default keeps the roofline clean)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the N > 1 control flow with several ranks on one GPU)")
+    ap.add_argument("--serial-broadcast", action="store_true",
+                    help="N > 1: broadcast the ground truth at the start of each step instead of one step ahead")
     return ap.parse_args()
 
 
@@ -105,11 +111,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     mvs = importlib.import_module("multiview-simulation_amd")
     synth = importlib.import_module("multiview-simulation_amd.synthetic")
@@ -123,12 +133,16 @@ def main():
     angles = [15 + (360 * v) // total_views for v in range(total_views)]
     nzo = (n - 1) // args.inc + 1
 
-    # synthetic inputs (rank 0 owns the ground truth; other ranks receive it by broadcast every step)
-    gt_dev = torch.empty(nvox, dtype=torch.float32, device=dev)
+    # synthetic inputs (rank 0 owns the ground truth; other ranks receive it by broadcast, once per step = dataset).
+    # N > 1 keeps two ground-truth buffers so that the broadcast of the next dataset runs (RCCL, own stream) while
+    # the views of the current one are being computed.
+    gt_bufs = [torch.empty(nvox, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    gt_dev = gt_bufs[0]
     gt_host = None
     if rank == 0:
         gt_host = synth.sphere_phantom(n)
-        gt_dev.copy_(torch.from_numpy(gt_host.reshape(-1)))
+        for b in gt_bufs:
+            b.copy_(torch.from_numpy(gt_host.reshape(-1)))
     psf_raw = synth.gaussian_psf(args.psf, sigma=(2.0, 2.2, 6.0))
     # one PSF per view (the reference loads Angle<k>.tif per view, SMVD:579): vary sigma_z slightly so no
     # spectrum can be shared between views
@@ -136,19 +150,52 @@ def main():
     acq = [torch.empty(n * n * nzo, dtype=torch.float32, device=dev) for _ in my_views]
 
     # one context (own HIP stream + workspaces) per concurrent view pipeline
-    ctxs = [mvs.Context(local_rank) for _ in range(max(1, args.streams))]
+    ctxs = [mvs.Context(dev_index) for _ in range(max(1, args.streams))]
     ctx = ctxs[0]
+    view_streams = []
+    if world > 1:
+        # the view pipelines run on torch-owned HIP streams so that torch events can order them against the
+        # broadcast stream without blocking the host
+        view_streams = [torch.cuda.Stream(device=dev) for _ in ctxs]
+        for c, vs in zip(ctxs, view_streams):
+            c.set_stream(vs.cuda_stream)
+        bc_stream = torch.cuda.Stream(device=dev)
+    views_done = [[], []]      # per ground-truth buffer: events after the last views that read it
+    bcast_done = [None, None]  # per ground-truth buffer: event after the broadcast that filled it
+    step_no = [0]
+
+    def issue_broadcast(b):
+        with torch.cuda.stream(bc_stream):
+            for e in views_done[b]:
+                bc_stream.wait_event(e)             # readers of the previous contents have finished
+            work = dist.broadcast(gt_bufs[b], src=0, async_op=True)
+            work.wait()                             # nccl: bc_stream waits for the collective; gloo: host waits
+            e = torch.cuda.Event()
+            e.record(bc_stream)
+            bcast_done[b] = e
     params = [ctx.view_params(degrees=angles[v], inc=args.inc, snr=args.snr, seed=464232194, stream=v,
                               conv_method=args.conv_method) for v in my_views]
 
     def step():
+        cur = 0
         if world > 1:
-            for c in ctxs:
-                c.synchronize()                         # previous dataset's views no longer read the ground truth
-            dist.broadcast(gt_dev, src=0)
-            torch.cuda.current_stream().synchronize()   # ground truth has landed before the view streams read it
+            cur = step_no[0] % 2
+            if args.serial_broadcast or bcast_done[cur] is None:
+                issue_broadcast(cur)                    # this dataset's ground truth (prologue / serial mode)
+            for vs in view_streams:
+                vs.wait_event(bcast_done[cur])          # ground truth has landed before the views read it
+            if not args.serial_broadcast:
+                issue_broadcast(1 - cur)                # next dataset's ground truth, overlapped with these views
+        gt_ptr = gt_bufs[cur].data_ptr()
         for i in range(len(my_views)):
-            ctxs[i % len(ctxs)].simulate_view_dev(gt_dev.data_ptr(), dims, psfs[i].copy(), params[i], acq[i].data_ptr())
+            ctxs[i % len(ctxs)].simulate_view_dev(gt_ptr, dims, psfs[i].copy(), params[i], acq[i].data_ptr())
+        if world > 1:
+            views_done[cur] = []
+            for vs in view_streams:
+                e = torch.cuda.Event()
+                e.record(vs)
+                views_done[cur].append(e)
+            step_no[0] += 1
 
     def sync():
         torch.cuda.synchronize()
@@ -159,6 +206,18 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if world > 1 and args.warmup > 0:
+        # outside the timed region: every rank must hold rank 0's ground truth in each buffer a broadcast has filled
+        for b_i, done in enumerate(bcast_done):
+            if done is None:
+                continue
+            chk = torch.stack([gt_bufs[b_i].double().sum(), gt_bufs[b_i].double().abs().max()])
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi) or float(hi[1]) == 0.0:
+                raise SystemExit(f"rank {rank}: ground-truth buffer {b_i} differs between ranks after the broadcast")
+        sync()
     # per-stage HIP events are recorded inside the timed region, on the stream each view runs on (one event set
     # per view; read once after the final sync): the stage durations include whatever overlap the streams produce
     if args.stage_timing:
@@ -200,7 +259,8 @@ def main():
                        "views_per_gpu": views_per_gpu, "inc": args.inc, "snr": args.snr,
                        "conv_method": "fft (hand-written LDS FFT passes; rocFFT only for unsupported sizes)" if args.conv_method == 1 else "direct stencil",
                        "streams_per_gpu": len(ctxs),
-                       "collective": "RCCL broadcast of ground truth per step" if world > 1 else "none"},
+                       "collective": ("none" if world == 1 else "RCCL broadcast of the ground truth, one per step, "
+                                      + ("serial" if args.serial_broadcast else "issued one dataset ahead"))},
         }
         if stage:
             nprime = n * n * nzo
