@@ -63,6 +63,8 @@ int  mvsim_dev_alloc(mvsim_ctx* ctx, size_t bytes, void** dptr);
 int  mvsim_dev_free(mvsim_ctx* ctx, void* dptr);
 int  mvsim_upload(mvsim_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  mvsim_download(mvsim_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* byte-wise fill, asynchronous on the context stream (e.g. the zero canvas of the phantom generator) */
+int  mvsim_dev_memset(mvsim_ctx* ctx, void* dptr, int value, size_t bytes);
 
 /* ---- pure host helpers --------------------------------------------------------------- */
 /* SMVD:80-102 axisRotation(Interval,int axis,int degrees): forward model T(+c) R T(-c) as a
@@ -105,8 +107,20 @@ int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr,
 int mvsim_make_isotropic(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float* out);
 /* SMVD:280-316 computeWeightImage (the reference ignores its delta argument). */
 int mvsim_compute_weight_image(mvsim_ctx* ctx, const int64_t dim[3], float* out);
+/* SMVD:436-522 drawSpheres(img, minValue, maxValue, scale, halfPixelOffset, rnd), in place.  rnd_state is the
+ * 48-bit state of the caller's java.util.Random ((seed ^ 0x5DEECE66D) & (2^48-1) right after `new Random(seed)`);
+ * it is advanced exactly as the reference advances it.  The walk over the large sphere (one shared sequential
+ * random stream) runs on the host, the max-compositing of the small spheres on the GPU.  n_spheres may be NULL. */
+int mvsim_draw_spheres(mvsim_ctx* ctx, float* img, const int64_t dim[3], double min_value, double max_value,
+                       int scale, int half_pixel_offset, uint64_t* rnd_state, int64_t* n_spheres);
+/* SMVD:394-424 downSample2x: out has dim[d]/2 - 1 samples per dimension. */
+int mvsim_downsample2x(mvsim_ctx* ctx, const float* in, const int64_t dim[3], float* out);
 
 /* ---- stage operators, device-resident buffers (asynchronous on the context stream) ------ */
+/* (mvsim_draw_spheres_dev returns after the host walk; the compositing kernels are asynchronous.) */
+int mvsim_draw_spheres_dev(mvsim_ctx* ctx, float* img, const int64_t dim[3], double min_value, double max_value,
+                           int scale, int half_pixel_offset, uint64_t* rnd_state, int64_t* n_spheres);
+int mvsim_downsample2x_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], float* out);
 int mvsim_rotate_around_axis_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3],
                                  int axis, int degrees, float* out);
 int mvsim_attenuate3d_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], double delta, float* out);

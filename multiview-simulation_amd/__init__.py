@@ -220,6 +220,58 @@ class Context:
         _lib.check(self._L.mvsim_make_isotropic(self._h, _ptr(v), _dim(v), inc, _ptr(out)))
         return out
 
+    # -- ground-truth phantom (SimulateMultiViewDataset.java:366-522)
+    def draw_spheres(self, img: np.ndarray, min_value: float, max_value: float, scale: int, half_pixel_offset: bool,
+                     rnd: "JavaRandom") -> int:
+        """drawSpheres, in place on a contiguous float32 (Nz,Ny,Nx) image; ``rnd`` is advanced exactly as the
+        reference advances its java.util.Random.  Returns the number of small spheres drawn."""
+        _check_inplace(img)
+        st = C.c_uint64(rnd._s)
+        n = C.c_int64(0)
+        _lib.check(self._L.mvsim_draw_spheres(self._h, _ptr(img), _dim(img), float(min_value), float(max_value),
+                                              int(scale), int(bool(half_pixel_offset)), C.byref(st), C.byref(n)))
+        rnd._s = int(st.value)
+        return int(n.value)
+
+    def downsample2x(self, img) -> np.ndarray:
+        v = _as_volume(img)
+        nz, ny, nx = v.shape
+        if min(nz, ny, nx) < 4:
+            raise ValueError("downSample2x needs at least 4 samples per dimension")
+        out = np.empty((nz // 2 - 1, ny // 2 - 1, nx // 2 - 1), dtype=np.float32)
+        _lib.check(self._L.mvsim_downsample2x(self._h, _ptr(v), _dim(v), _ptr(out)))
+        return out
+
+    def simulate_phantom(self, size: int = 289, scale: int = 2, half_pixel_offset: bool = False,
+                         rnd: "JavaRandom | None" = None) -> np.ndarray:
+        """`simulate` (:366-392) with the canvas resident in HBM: zero canvas of (size[+1])*scale voxels per
+        dimension, drawSpheres, 2x down-sampling when scale == 2; only the result crosses PCIe."""
+        if rnd is None:
+            rnd = SimulateMultiViewDataset.rnd
+        if scale == 2:
+            size += 1
+        n = size * scale
+        dim = (C.c_int64 * 3)(n, n, n)
+        nbytes = n ** 3 * 4
+        canvas = self.dev_alloc(nbytes)
+        out_d = 0
+        try:
+            _lib.check(self._L.mvsim_dev_memset(self._h, canvas, 0, nbytes))
+            st = C.c_uint64(rnd._s)
+            _lib.check(self._L.mvsim_draw_spheres_dev(self._h, canvas, dim, 0.0, 1.0, int(scale),
+                                                      int(bool(half_pixel_offset)), C.byref(st), None))
+            rnd._s = int(st.value)
+            if scale != 2:
+                return self.download(canvas, (n, n, n))
+            o = n // 2 - 1
+            out_d = self.dev_alloc(o ** 3 * 4)
+            _lib.check(self._L.mvsim_downsample2x_dev(self._h, canvas, dim, out_d))
+            return self.download(out_d, (o, o, o))
+        finally:
+            self.dev_free(canvas)
+            if out_d:
+                self.dev_free(out_d)
+
     def compute_weight_image(self, shape_zyx) -> np.ndarray:
         nz, ny, nx = (int(s) for s in shape_zyx)
         out = np.empty((nz, ny, nx), dtype=np.float32)
@@ -435,6 +487,23 @@ class SimulateMultiViewDataset:
         out = np.array(img, dtype=np.float32, order="C", copy=True)
         Tools.poissonProcess(out, poissonSNR, rnd)
         return out
+
+    @staticmethod
+    def simulate(halfPixelOffset: bool = False, rnd=None) -> np.ndarray:
+        """:366-392 -- the 289^3 sphere phantom (rendered at 2x on the GPU, then down-sampled)."""
+        return default_context().simulate_phantom(289, 2, halfPixelOffset, rnd)
+
+    @staticmethod
+    def drawSpheres(img: np.ndarray, minValue: float, maxValue: float, scale: int, halfPixelOffset: bool,
+                    rnd=None) -> None:
+        """:436-522, in place."""
+        default_context().draw_spheres(img, minValue, maxValue, scale, halfPixelOffset,
+                                       rnd if rnd is not None else SimulateMultiViewDataset.rnd)
+
+    @staticmethod
+    def downSample2x(img) -> np.ndarray:
+        """:394-424"""
+        return default_context().downsample2x(img)
 
     @staticmethod
     def makeIsotropic(img, inc: int) -> np.ndarray:

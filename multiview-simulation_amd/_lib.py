@@ -60,6 +60,7 @@ SIGNATURES = {
     "mvsim_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "mvsim_dev_free": (C.c_int, [_vp, _vp]),
     "mvsim_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "mvsim_dev_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
     "mvsim_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "mvsim_axis_rotation": (C.c_int, [_i64p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mvsim_extract_nz": (C.c_int64, [C.c_int64, C.c_int]),
@@ -80,6 +81,12 @@ SIGNATURES = {
     "mvsim_adjust_image_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, C.POINTER(C.c_double)]),
     "mvsim_extract_slices_dev": (C.c_int, [_vp, _vp, _i64p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _vp]),
     "mvsim_make_isotropic_dev": (C.c_int, [_vp, _vp, _i64p, C.c_int, _vp]),
+    "mvsim_draw_spheres": (C.c_int, [_vp, _vp, _i64p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]),
+    "mvsim_draw_spheres_dev": (C.c_int, [_vp, _vp, _i64p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]),
+    "mvsim_downsample2x": (C.c_int, [_vp, _vp, _i64p, _vp]),
+    "mvsim_downsample2x_dev": (C.c_int, [_vp, _vp, _i64p, _vp]),
     "mvsim_compute_weight_image_dev": (C.c_int, [_vp, _i64p, _vp]),
     "mvsim_sum_views_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, _vp]),
     "mvsim_normalize_weights_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, _vp, C.c_float]),

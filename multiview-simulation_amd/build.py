@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvsim.so")
-SOURCES = ["api.cpp", "comm.cpp", "kernels.hip", "fftconv.hip", "fft_kernels.hip", "stencil.hip"]
+SOURCES = ["api.cpp", "comm.cpp", "kernels.hip", "fftconv.hip", "fft_kernels.hip", "stencil.hip", "phantom.hip"]
 HEADERS = ["common.h", "poisson_dev.h", "../../include/mvsim.h"]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 

@@ -248,7 +248,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     mvsim_comm_destroy(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release();
+    ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
         for (int k = 0; k < mvsim_ctx::TIMING_SLOTS; ++k)
@@ -305,6 +305,15 @@ int mvsim_upload(mvsim_ctx* ctx, void* dst_dev, const void* src_host, size_t byt
     MVSIM_CHECK_ARG(dst_dev && src_host, "null pointer");
     MVSIM_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    return MVSIM_OK;
+}
+
+int mvsim_dev_memset(mvsim_ctx* ctx, void* dptr, int value, size_t bytes)
+{
+    MVSIM_TRY(set_device(ctx));
+    if (bytes == 0) return MVSIM_OK;
+    MVSIM_CHECK_ARG(dptr != nullptr, "null pointer");
+    MVSIM_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
     return MVSIM_OK;
 }
 
@@ -654,6 +663,52 @@ int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr, uin
                              0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset, ctx->pqueue.p));
     ev_end(ctx, ST_EXTRACT);
     return down(ctx, img, ctx->out_buf.p, bytes);
+}
+
+int mvsim_draw_spheres_dev(mvsim_ctx* ctx, float* img, const int64_t dim[3], double min_value, double max_value,
+                           int scale, int half_pixel_offset, uint64_t* rnd_state, int64_t* n_spheres)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(img && rnd_state, "null pointer");
+    MVSIM_CHECK_ARG(scale >= 1 && scale <= 64, "scale must be in 1..64");
+    return draw_spheres_dev(ctx, img, dim, min_value, max_value, scale, half_pixel_offset, rnd_state, n_spheres);
+}
+
+int mvsim_downsample2x_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3], float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out && in != out, "null or aliased buffer");
+    MVSIM_CHECK_ARG(dim[0] >= 4 && dim[1] >= 4 && dim[2] >= 4, "downSample2x needs at least 4 samples per dimension");
+    return launch_downsample2x(ctx->stream, in, dim, out);
+}
+
+int mvsim_draw_spheres(mvsim_ctx* ctx, float* img, const int64_t dim[3], double min_value, double max_value,
+                       int scale, int half_pixel_offset, uint64_t* rnd_state, int64_t* n_spheres)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(img && rnd_state, "null pointer");
+    const size_t bytes = (size_t)nvox(dim) * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
+    MVSIM_TRY(mvsim_draw_spheres_dev(ctx, ctx->vol_a.as<float>(), dim, min_value, max_value, scale, half_pixel_offset,
+                                     rnd_state, n_spheres));
+    return down(ctx, img, ctx->vol_a.p, bytes);
+}
+
+int mvsim_downsample2x(mvsim_ctx* ctx, const float* in, const int64_t dim[3], float* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(in && out, "null buffer");
+    MVSIM_CHECK_ARG(dim[0] >= 4 && dim[1] >= 4 && dim[2] >= 4, "downSample2x needs at least 4 samples per dimension");
+    const size_t bytes = (size_t)nvox(dim) * sizeof(float);
+    const size_t obytes = (size_t)(dim[0] / 2 - 1) * (size_t)(dim[1] / 2 - 1) * (size_t)(dim[2] / 2 - 1) * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, in, bytes));
+    MVSIM_TRY(ctx->out_buf.reserve(obytes));
+    MVSIM_TRY(mvsim_downsample2x_dev(ctx, ctx->vol_a.as<float>(), dim, ctx->out_buf.as<float>()));
+    return down(ctx, out, ctx->out_buf.p, obytes);
 }
 
 int mvsim_make_isotropic(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int inc, float* out)

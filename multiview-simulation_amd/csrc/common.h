@@ -104,6 +104,7 @@ struct mvsim_ctx {
     mvsim::DevBuf fft_spec_img, fft_spec_psf;
     mvsim::DevBuf fft_work;
     mvsim::DevBuf pqueue;                   // Poisson work queue: [count][items]
+    mvsim::DevBuf sphere_list;              // phantom generator: (centre, radius, value) items
     mvsim::DevBuf partials;                 // doubles: block partial sums + [sum, corr]
     mvsim::DevBuf partials_e;               // per-block sums of the c2r/crop pass
     mvsim::DevBuf cfft_f, cfft_g;           // custom FFT: image / PSF half spectra [Pz][Py][Hxp]
@@ -149,6 +150,10 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
 // bytes of the Poisson work queue (HBM) for n_out output voxels
 size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity);
 int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc);
+// phantom generator (phantom.hip)
+int launch_downsample2x(hipStream_t s, const float* in, const int64_t dim[3], float* out);
+int draw_spheres_dev(mvsim_ctx* ctx, float* img, const int64_t dim[3], double min_value, double max_value, int scale,
+                     int half_pixel_offset, uint64_t* rnd_state, int64_t* n_spheres);
 int launch_weight_image(hipStream_t s, float* out, const int64_t dim[3]);
 int launch_weights(hipStream_t s, float* const* views, int nv, int64_t n, const float* sum_in, float* sum_out,
                    float osem, bool sum_only);

@@ -98,6 +98,13 @@ def lib():
         L.orc_isotropic_nz.argtypes = [C.c_int64, C.c_int]
         L.orc_isotropic_nz.restype = C.c_int64
         L.orc_make_isotropic.argtypes = [_f32p, _i64p, C.c_int, _f32p]
+        L.orc_draw_spheres.argtypes = [_f32p, _i64p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p,
+                                       C.POINTER(C.c_int64)]
+        L.orc_draw_spheres.restype = C.c_int
+        L.orc_downsample2x.argtypes = [_f32p, _i64p, _f32p]
+        L.orc_downsample2x.restype = C.c_int
+        L.orc_hypersphere_size.argtypes = [C.c_int64]
+        L.orc_hypersphere_size.restype = C.c_int64
         L.orc_compute_weight_image.argtypes = [_i64p, _f32p]
         L.orc_normalize_weights.argtypes = [C.POINTER(_f32p), C.c_int, C.c_int64, C.c_float]
         _lib = L
@@ -346,6 +353,41 @@ def make_isotropic(vol, inc: int) -> np.ndarray:
     out = np.empty((lib().orc_isotropic_nz(nz, inc), ny, nx), dtype=np.float32)
     lib().orc_make_isotropic(_p(v), _dim(v), inc, _p(out))
     return out
+
+
+def draw_spheres(img: np.ndarray, min_value: float, max_value: float, scale: int, half_pixel_offset: bool,
+                 rnd: "JRandom") -> int:
+    """SMVD:436-522, in place on a contiguous float32 (Nz,Ny,Nx) image; returns the number of small spheres."""
+    assert img.dtype == np.float32 and img.flags.c_contiguous and img.ndim == 3
+    n = C.c_int64(0)
+    rc = lib().orc_draw_spheres(_p(img), _dim(img), float(min_value), float(max_value), int(scale),
+                                int(bool(half_pixel_offset)), C.byref(rnd.st), C.byref(n))
+    if rc != 0:
+        raise ValueError(f"orc_draw_spheres failed ({rc})")
+    return int(n.value)
+
+
+def downsample2x(vol) -> np.ndarray:
+    """SMVD:394-424."""
+    v = _vol(vol)
+    nz, ny, nx = v.shape
+    out = np.empty((nz // 2 - 1, ny // 2 - 1, nx // 2 - 1), dtype=np.float32)
+    if lib().orc_downsample2x(_p(v), _dim(v), _p(out)) != 0:
+        raise ValueError("orc_downsample2x: image too small")
+    return out
+
+
+def simulate_phantom(size: int = 289, scale: int = 2, half_pixel_offset: bool = False, rnd: "JRandom" = None) -> np.ndarray:
+    """SMVD:366-392 (`simulate`): spheres at `scale`x resolution, then 2x downsampling."""
+    if scale == 2:
+        size += 1
+    img = np.zeros((size * scale,) * 3, dtype=np.float32)
+    draw_spheres(img, 0.0, 1.0, scale, half_pixel_offset, rnd if rnd is not None else JRandom(464232194))
+    return downsample2x(img) if scale == 2 else img
+
+
+def hypersphere_size(radius: int) -> int:
+    return int(lib().orc_hypersphere_size(int(radius)))
 
 
 def compute_weight_image(shape_zyx) -> np.ndarray:

@@ -571,6 +571,107 @@ int orc_compute_weight_image(const int64_t dim[3], float* out)
     return 0;
 }
 
+/* ---- phantom generator, SMVD:366-522 -------------------------------------------------------------------------
+ * HyperSphereCursor as a literal state machine: position, per-dimension radius r[] and remaining steps s[];
+ * fwd() moves the lowest dimension that still has steps and re-derives the radii of the dimensions below it
+ * from the radius of the dimension above ((long)Math.sqrt, i.e. truncation).  reset() parks the cursor one step
+ * in front of the first voxel of the outermost (last) dimension. */
+typedef struct {
+    int64_t c[3], pos[3], r[3], s[3], radius;
+} hs_cursor;
+
+static void hs_reset(hs_cursor* h, const int64_t c[3], int64_t radius)
+{
+    h->radius = radius;
+    for (int d = 0; d < 3; ++d) { h->c[d] = c[d]; h->pos[d] = c[d]; h->r[d] = 0; h->s[d] = 0; }
+    h->r[2] = radius;
+    h->s[2] = 2 * radius + 1;
+    h->pos[2] = c[2] - radius - 1;
+}
+
+static int hs_has_next(const hs_cursor* h) { return h->s[0] > 0 || h->s[1] > 0 || h->s[2] > 0; }
+
+static void hs_fwd(hs_cursor* h)
+{
+    int d = 0;
+    while (d < 3 && h->s[d] <= 0) ++d;
+    h->s[d] -= 1;
+    h->pos[d] += 1;
+    for (int e = d - 1; e >= 0; --e) {
+        const int64_t rad = h->r[e + 1];
+        const int64_t off = h->pos[e + 1] - h->c[e + 1];
+        const int64_t rad2 = (int64_t)sqrt((double)(rad * rad - off * off));
+        h->r[e] = rad2;
+        h->s[e] = 2 * rad2;
+        h->pos[e] = h->c[e] - rad2;
+    }
+}
+
+int64_t orc_hypersphere_size(int64_t radius)
+{
+    const int64_t c[3] = {0, 0, 0};
+    hs_cursor h;
+    hs_reset(&h, c, radius);
+    int64_t n = 0;
+    while (hs_has_next(&h)) { hs_fwd(&h); ++n; }
+    return n;
+}
+
+static int64_t ipow(int64_t a, int b) { int64_t r = 1; while (b-- > 0) r *= a; return r; }
+
+/* SMVD:436-522 */
+int orc_draw_spheres(float* img, const int64_t dim[3], double min_value, double max_value, int scale,
+                     int half_pixel_offset, orc_jrandom* rnd, int64_t* n_spheres)
+{
+    int64_t c[3], min_size = dim[0];
+    for (int d = 0; d < 3; ++d) { c[d] = dim[d] / 2; if (dim[d] < min_size) min_size = dim[d]; }
+    const int max_radius = 10 * scale;
+    const int64_t radius_large = min_size / 2 - 47 * scale - 1;
+    if (scale < 1 || radius_large < 0) return -1;
+    const int64_t modulus = ipow(7 * scale, 3);            /* Util.pow( 7*scale, numDimensions ) */
+    int64_t drawn = 0;
+    hs_cursor big;
+    hs_reset(&big, c, radius_large);
+    while (hs_has_next(&big)) {
+        hs_fwd(&big);
+        const int radius = orc_jrandom_next_int_bound(rnd, max_radius) + 1;
+        int64_t sc[3] = {big.pos[0], big.pos[1], big.pos[2]};
+        if (half_pixel_offset) { sc[0] += 1; sc[1] += 1; }
+        double random_value = orc_jrandom_next_double(rnd);
+        const int64_t rounded = (int64_t)floor(random_value * 10000 + 0.5);      /* Math.round */
+        if (rounded % modulus == 0) {
+            random_value = orc_jrandom_next_double(rnd) * (max_value - min_value) + min_value;
+            hs_cursor sm;
+            hs_reset(&sm, sc, radius);
+            while (hs_has_next(&sm)) {
+                hs_fwd(&sm);
+                if (sm.pos[0] < 0 || sm.pos[1] < 0 || sm.pos[2] < 0 || sm.pos[0] >= dim[0] || sm.pos[1] >= dim[1] ||
+                    sm.pos[2] >= dim[2])
+                    return -2;                                  /* the reference would throw */
+                float* v = img + sm.pos[0] + dim[0] * (sm.pos[1] + dim[1] * sm.pos[2]);
+                const double cur = (double)*v;
+                *v = (float)(random_value > cur ? random_value : cur);          /* Math.max, setReal */
+            }
+            ++drawn;
+        }
+    }
+    if (n_spheres) *n_spheres = drawn;
+    return 0;
+}
+
+/* SMVD:394-424: samples at 2l + 0.5 with the n-linear interpolator over the mirror-single extension */
+int orc_downsample2x(const float* in, const int64_t dim[3], float* out)
+{
+    const int64_t od[3] = {dim[0] / 2 - 1, dim[1] / 2 - 1, dim[2] / 2 - 1};
+    if (od[0] < 1 || od[1] < 1 || od[2] < 1) return -1;
+    for (int64_t z = 0; z < od[2]; ++z)
+        for (int64_t y = 0; y < od[1]; ++y)
+            for (int64_t x = 0; x < od[0]; ++x)
+                out[x + od[0] * (y + od[1] * z)] =
+                    nlinear3(in, dim, tap_mirror, (double)x * 2.0 + 0.5, (double)y * 2.0 + 0.5, (double)z * 2.0 + 0.5);
+    return 0;
+}
+
 /* SMVD:615-640: float sum over the views in view order; zero sum -> zeros, else min(1, osem * (w / sum)). */
 int orc_normalize_weights(float* const* weights, int n_views, int64_t n, float osem)
 {

@@ -90,6 +90,18 @@ double orc_poisson_mul(double snr);                /* Tools:76 */
 int64_t orc_isotropic_nz(int64_t nz_acq, int inc);
 int orc_make_isotropic(const float* in, const int64_t dim[3], int inc, float* out);
 int orc_compute_weight_image(const int64_t dim[3], float* out);
+/* ---- "next" rank 3: ground-truth phantom, SMVD:366-522.
+ *      drawSpheres walks an ImgLib2 HyperSphereCursor (imglib2-algorithm, absent from /root/reference): the
+ *      iteration order and the integer radii are restated from the published algorithm as recalled --
+ *      raster order, last dimension outermost, nested radii r[d-1] = (long)sqrt(r[d]^2 - pos_d^2) -- and are
+ *      specification-to-test like the rest of this oracle (PARITY UNPINNED).
+ *      n_spheres (may be NULL) receives the number of small spheres drawn. ---- */
+int orc_draw_spheres(float* img, const int64_t dim[3], double min_value, double max_value, int scale,
+                     int half_pixel_offset, orc_jrandom* rnd, int64_t* n_spheres);
+/* out has dim[d]/2 - 1 samples per dimension */
+int orc_downsample2x(const float* in, const int64_t dim[3], float* out);
+int64_t orc_hypersphere_size(int64_t radius);       /* voxels a 3-D HyperSphere of that radius iterates */
+
 /* ---- SMVD:615-640 cross-view weight normalisation (in place) ---- */
 int orc_normalize_weights(float* const* weights, int n_views, int64_t n, float osem);
 

@@ -49,7 +49,23 @@ def view():
                         att=res["att"], con=res["con"], acq=res["acq"], corr=res["corr"], **p)
 
 
+def phantom():
+    """drawSpheres + downSample2x (SMVD:394-522) on a 260^3 canvas at scale 2, the reference's seed."""
+    import hashlib
+    canvas, scale, seed = 260, 2, 464232194
+    img = np.zeros((canvas,) * 3, np.float32)
+    r = O.JRandom(seed)
+    n = O.draw_spheres(img, 0.0, 1.0, scale, False, r)
+    ds = O.downsample2x(img)
+    d = {"canvas": canvas, "scale": scale, "seed": seed, "n_spheres": n, "rnd_state_after": int(r.st.s),
+         "canvas_sha256": hashlib.sha256(img.tobytes()).hexdigest(),
+         "downsampled_sha256": hashlib.sha256(ds.tobytes()).hexdigest(),
+         "downsampled_nonzero": int((ds > 0).sum())}
+    json.dump(d, open(os.path.join(HERE, "phantom_vectors.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     jdk()
     view()
+    phantom()
     print("golden fixtures written to", HERE)

@@ -194,6 +194,70 @@ def test_make_isotropic_and_weight_image(ctx, orc):
     assert np.max(np.abs(w - orc.compute_weight_image((3, 100, 4)))) <= 6e-8
 
 
+# ------------------------------------------------------------------------------------------------ phantom (8f rank 3)
+@pytest.mark.parametrize("canvas,scale,half", [(160, 1, False), (160, 1, True), (260, 2, False), (150, 1, False)])
+def test_draw_spheres_bit_exact_and_random_stream(ctx, mvs, orc, canvas, scale, half):
+    """SMVD:436-522: same spheres, same voxels, same java.util.Random state afterwards as the oracle."""
+    seed = 464232194
+    a = np.zeros((canvas,) * 3, np.float32)
+    ro = orc.JRandom(seed)
+    n_o = orc.draw_spheres(a, 0.0, 1.0, scale, half, ro)
+    b = np.zeros_like(a)
+    rg = mvs.JavaRandom(seed)
+    n_g = ctx.draw_spheres(b, 0.0, 1.0, scale, half, rg)
+    assert n_g == n_o and n_o > 10
+    assert rg._s == int(ro.st.s)
+    assert np.array_equal(a, b)
+    # a second call continues the same random stream and composites on top (Math.max)
+    n_o2 = orc.draw_spheres(a, 0.25, 0.75, scale, half, ro)
+    n_g2 = ctx.draw_spheres(b, 0.25, 0.75, scale, half, rg)
+    assert n_g2 == n_o2 and rg._s == int(ro.st.s) and np.array_equal(a, b)
+
+
+def test_draw_spheres_non_cubic_and_negative_canvas(ctx, mvs, orc):
+    a = np.full((140, 150, 170), -0.5, np.float32)          # mixed signs exercise both branches of the atomic max
+    b = a.copy()
+    ro, rg = orc.JRandom(7), mvs.JavaRandom(7)
+    assert orc.draw_spheres(a, -1.0, 1.0, 1, False, ro) == ctx.draw_spheres(b, -1.0, 1.0, 1, False, rg)
+    assert np.array_equal(a, b) and (b > 0).any() and (b[b != -0.5] > -0.5).all()
+    with pytest.raises(ValueError):
+        ctx.draw_spheres(np.zeros((64, 64, 64), np.float32), 0.0, 1.0, 1, False, mvs.JavaRandom(1))   # radius < 0
+
+
+@pytest.mark.parametrize("shape", [(10, 13, 16), (9, 8, 21), (64, 64, 64)])
+def test_downsample2x_bit_exact(ctx, orc, shape):
+    v = np.random.default_rng(31).random(shape, dtype=np.float32)
+    got = ctx.downsample2x(v)
+    assert got.shape == tuple(s // 2 - 1 for s in shape)
+    assert np.array_equal(got, orc.downsample2x(v))
+
+
+def test_golden_phantom_fixture(ctx, mvs, golden_dir):
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(golden_dir, "phantom_vectors.json")))
+    img = np.zeros((g["canvas"],) * 3, np.float32)
+    r = mvs.JavaRandom(g["seed"])
+    assert ctx.draw_spheres(img, 0.0, 1.0, g["scale"], False, r) == g["n_spheres"]
+    assert r._s == g["rnd_state_after"]
+    assert hashlib.sha256(img.tobytes()).hexdigest() == g["canvas_sha256"]
+    assert hashlib.sha256(ctx.downsample2x(img).tobytes()).hexdigest() == g["downsampled_sha256"]
+
+
+def test_simulate_phantom_full_size(mvs, orc):
+    """`simulate()` (SMVD:366-392) at the reference's size: 580^3 canvas in HBM, 289^3 result; bit-exact against
+    the oracle, and the facade's static generator continues like the reference's static `rnd`."""
+    S = mvs.SimulateMultiViewDataset
+    r = mvs.JavaRandom(464232194)
+    got = S.simulate(False, r)
+    assert got.shape == (289, 289, 289) and got.dtype == np.float32
+    ro = orc.JRandom(464232194)
+    ref = orc.simulate_phantom(rnd=ro)
+    assert r._s == int(ro.st.s)
+    assert np.array_equal(got, ref)
+    assert 0.1 < float((got > 0).mean()) < 0.3 and float(got.max()) < 1.0
+
+
 # ------------------------------------------------------------------------------------------------ fused view + golden
 def test_golden_view_fixture(ctx, golden_dir):
     g = np.load(os.path.join(golden_dir, "view_24.npz"))

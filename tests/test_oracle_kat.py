@@ -339,3 +339,93 @@ def test_normalize_weights_kats(orc):
         s = s + x
     for a, b in zip(ws, ref):
         assert np.array_equal(a, np.minimum(np.float32(1), np.float32(3.0) * (b / s)))
+
+
+# ------------------------------------------------------------------------------------------------ phantom (8f rank 3)
+def _nested_sphere_count(R):
+    import math
+    n = 0
+    for dz in range(-R, R + 1):
+        r1 = math.isqrt(R * R - dz * dz)
+        for dy in range(-r1, r1 + 1):
+            n += 2 * math.isqrt(r1 * r1 - dy * dy) + 1
+    return n
+
+
+def test_hypersphere_cursor_counts(orc):
+    """HyperSphereCursor restated as a state machine == closed form of the nested truncated radii."""
+    assert [orc.hypersphere_size(r) for r in (0, 1, 2)] == [1, 7, 25]
+    for r in (3, 5, 10, 20, 33):
+        assert orc.hypersphere_size(r) == _nested_sphere_count(r)
+
+
+def test_draw_spheres_random_stream_and_geometry(orc, mvs):
+    """SMVD:436-522: per voxel of the large sphere nextInt(10*scale) and nextDouble, a third draw only for the
+    voxels that become centres; replayed with the independent pure-Python java.util.Random of the facade."""
+    n, scale, seed = 128, 1, 464232194
+    img = np.zeros((n, n, n), np.float32)
+    r = orc.JRandom(seed)
+    drawn = orc.draw_spheres(img, 0.0, 1.0, scale, False, r)
+    R = n // 2 - 47 * scale - 1
+    j = mvs.JavaRandom(seed)
+    expect, vmax = 0, 0.0
+    for _ in range(_nested_sphere_count(R)):
+        j.nextInt(10 * scale)
+        rv = j.nextDouble()
+        if int(np.floor(rv * 10000 + 0.5)) % (7 * scale) ** 3 == 0:
+            vmax = max(vmax, j.nextDouble())
+            expect += 1
+    assert drawn == expect and drawn > 20
+    assert r.st.s == j._s                                   # both generators consumed the same number of draws
+    assert img.max() == np.float32(vmax) and img.min() == 0.0
+    zz, yy, xx = np.nonzero(img)
+    c = n // 2
+    assert max(np.abs(zz - c).max(), np.abs(yy - c).max(), np.abs(xx - c).max()) <= R + 10 * scale
+    # halfPixelOffset moves every small sphere by (+1, +1, 0) and nothing else
+    img2 = np.zeros_like(img)
+    orc.draw_spheres(img2, 0.0, 1.0, scale, True, orc.JRandom(seed))
+    assert np.array_equal(img2[:, 1:, 1:], img[:, :-1, :-1])
+
+
+def test_draw_spheres_single_sphere_is_a_hypersphere(orc):
+    """Exactly one small sphere of radius r covers hypersphere_size(r) voxels: use a canvas whose large sphere has
+    radius 0 (one voxel, one draw) and search seeds until that voxel becomes a centre."""
+    n = 2 * (47 + 1)          # radius_large = n/2 - 47 - 1 = 0
+    for seed in range(5000):
+        img = np.zeros((n, n, n), np.float32)
+        r = orc.JRandom(seed)
+        if orc.draw_spheres(img, 0.0, 1.0, 1, False, r) == 1:
+            rad = orc.JRandom(seed).nextInt(10) + 1
+            assert int((img > 0).sum()) == orc.hypersphere_size(rad)
+            zz, yy, xx = np.nonzero(img)
+            assert zz.min() == n // 2 - rad and zz.max() == n // 2 + rad
+            assert len(np.unique(img[img > 0])) == 1
+            return
+    raise AssertionError("no seed drew the single sphere")
+
+
+def test_downsample2x_kats(orc):
+    """SMVD:394-424: dims N/2-1, samples at 2l+0.5 (mean of the 2x2x2 block starting at 2l)."""
+    rng = np.random.default_rng(5)
+    v = rng.random((10, 13, 16), dtype=np.float32)
+    d = orc.downsample2x(v)
+    assert d.shape == (4, 5, 7)
+    blk = v[:8, :10, :14].reshape(4, 2, 5, 2, 7, 2).astype(np.float64).mean(axis=(1, 3, 5))
+    assert np.allclose(d, blk, rtol=0, atol=2e-7)
+    assert np.array_equal(orc.downsample2x(np.full((8, 8, 8), 3.0, np.float32)), np.full((3, 3, 3), 3.0, np.float32))
+    ramp = np.broadcast_to(np.arange(12, dtype=np.float32), (6, 6, 12)).copy()
+    assert np.array_equal(orc.downsample2x(ramp)[0, 0], 2 * np.arange(5, dtype=np.float32) + 0.5)
+
+
+def test_golden_phantom_fixture_reproduces(orc, golden_dir):
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(golden_dir, "phantom_vectors.json")))
+    img = np.zeros((g["canvas"],) * 3, np.float32)
+    r = orc.JRandom(g["seed"])
+    assert orc.draw_spheres(img, 0.0, 1.0, g["scale"], False, r) == g["n_spheres"]
+    assert int(r.st.s) == g["rnd_state_after"]
+    assert hashlib.sha256(img.tobytes()).hexdigest() == g["canvas_sha256"]
+    ds = orc.downsample2x(img)
+    assert hashlib.sha256(ds.tobytes()).hexdigest() == g["downsampled_sha256"]
+    assert int((ds > 0).sum()) == g["downsampled_nonzero"]
