@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
-"""The whole driver loop of SimulateMultiViewDataset.main (:554-663) on the GPU path, with synthetic inputs
-instead of the reference's phantom generator and TIFF PSFs (both out of scope):
+"""The whole driver of SimulateMultiViewDataset.main (:524-663) on the GPU path:
 
     ground truth -> for each angle: rotate, attenuate, weights, convolve, adjust, extractSlices,
     makeIsotropic, rotate back (view, weights, PSF) -> cross-view weight normalisation -> sum of weights
 
-    python examples/simulate_dataset.py --size 64 --views 7 --out /tmp/mvsim_out
+    python examples/simulate_dataset.py --size 64 --views 7 --out /tmp/mvsim_out        # small synthetic inputs
+    python examples/simulate_dataset.py --reference-inputs DIR --out DIR_OUT --tiff     # the reference's own run
+
+With --reference-inputs the ground truth is the reference's 289^3 sphere phantom (`simulate()`, :366-392, drawn
+from the shared static generator exactly as `main` does) and the PSF of every view is `DIR/Angle<angle>.tif`
+(`Tools.open(file, true)`, :579) -- the files shipped in the reference's src/main/resources; --tiff writes the same
+ImageJ TIFF files `main` writes (:563-564, :598-604, :642-662) instead of one .npz.
 """
 import argparse
 import importlib
@@ -26,19 +31,25 @@ def main():
     ap.add_argument("--views", type=int, default=7)           # angleIncrement = 52 -> 7 views (:540)
     ap.add_argument("--psf", type=int, default=15)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--reference-inputs", default=None, metavar="DIR",
+                    help="directory holding the reference's Angle<angle>.tif PSFs; uses simulate() as ground truth")
+    ap.add_argument("--tiff", action="store_true", help="write ImageJ TIFF files named as the reference names them")
     a = ap.parse_args()
 
     poissonSNR, lightsheetSpacing, attenuation, osem, angleOffset = 25.0, 3, 0.01, 3.0, 15   # :531-548
-    angleIncrement = 360 // a.views
-    rendered = synth.sphere_phantom(a.size)
+    angleIncrement = 52 if a.reference_inputs else 360 // a.views      # seven angles (:540)
+    rendered = S.simulate() if a.reference_inputs else synth.sphere_phantom(a.size)
     obj = S.rotateAroundAxis(rendered, 0, angleOffset)        # ground truth (:557)
-    rnd = mvs.JavaRandom(464232194)
+    rnd = S.rnd                                               # the static generator simulate() drew from (:76)
     weights, out = [], {"rendered": rendered, "groundtruth": obj}
-    for angle in range(0, 360, angleIncrement)[: a.views]:
+    for angle in list(range(0, 360, angleIncrement))[: None if a.reference_inputs else a.views]:
         rot = S.rotateAroundAxis(rendered, 0, angle + angleOffset)
         att = S.attenuate3d(rot, attenuation)
         w = S.computeWeightImage(rot, attenuation)
-        psf = synth.gaussian_psf(a.psf, sigma=(2.0, 2.2, 4.0))
+        if a.reference_inputs:
+            psf = T.open(os.path.join(a.reference_inputs, f"Angle{angle}.tif"), True)      # :579
+        else:
+            psf = synth.gaussian_psf(a.psf, sigma=(2.0, 2.2, 4.0))
         con = S.convolve(att, psf, None)                      # normalises psf in place
         T.adjustImage(con, S.minValue, S.avgIntensity)
         acq = S.extractSlices(con, lightsheetSpacing, poissonSNR, rnd)
@@ -60,8 +71,13 @@ def main():
     print(f"sum of weights: min {sumWeights.min():.3f} max {sumWeights.max():.3f}")
     if a.out:
         os.makedirs(a.out, exist_ok=True)
-        np.savez_compressed(os.path.join(a.out, "dataset.npz"), **out)
-        print("written", os.path.join(a.out, "dataset.npz"))
+        if a.tiff:
+            for name, img in out.items():
+                T.save(img, os.path.join(a.out, name + ".tif"))
+            print("written", len(out), "TIFF files to", a.out)
+        else:
+            np.savez_compressed(os.path.join(a.out, "dataset.npz"), **out)
+            print("written", os.path.join(a.out, "dataset.npz"))
 
 
 if __name__ == "__main__":

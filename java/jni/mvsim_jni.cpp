@@ -134,6 +134,27 @@ JNIEXPORT void JNICALL JNI_FN(axisRotation)(JNIEnv* env, jclass, jlongArray dim,
     env->SetDoubleArrayRegion(m12, 0, 12, m);
 }
 
+JNIEXPORT jlong JNICALL JNI_FN(drawSpheres)(JNIEnv* env, jclass, jlong h, jobject img, jlongArray dim, jdouble min_value,
+                                            jdouble max_value, jint scale, jboolean half_pixel_offset, jlongArray rnd_state)
+{
+    Dim d(env, dim);
+    jlong st = 0;
+    env->GetLongArrayRegion(rnd_state, 0, 1, &st);
+    uint64_t state = static_cast<uint64_t>(st);
+    int64_t n = 0;
+    throw_for(env, mvsim_draw_spheres(ctx_of(h), fptr(env, img), d.d, min_value, max_value, scale, half_pixel_offset ? 1 : 0,
+                                      &state, &n));
+    st = static_cast<jlong>(state);
+    env->SetLongArrayRegion(rnd_state, 0, 1, &st);
+    return static_cast<jlong>(n);
+}
+
+JNIEXPORT void JNICALL JNI_FN(downSample2x)(JNIEnv* env, jclass, jlong h, jobject in, jlongArray dim, jobject out)
+{
+    Dim d(env, dim);
+    throw_for(env, mvsim_downsample2x(ctx_of(h), fptr(env, in), d.d, fptr(env, out)));
+}
+
 JNIEXPORT void JNICALL JNI_FN(normalizeWeights)(JNIEnv* env, jclass, jlong h, jobjectArray weights, jlong n, jfloat osem)
 {
     const jsize nv = env->GetArrayLength(weights);

@@ -31,6 +31,12 @@ final class MvsimNative
 	static native void computeWeightImage( long ctx, long[] dim, FloatBuffer out );
 	static native void axisRotation( long[] dim, int axis, int degrees, double[] m12 );
 
+	/** drawSpheres (:436-522), in place; rndState[0] is the 48-bit java.util.Random state, advanced on return; returns the sphere count. */
+	static native long drawSpheres( long ctx, FloatBuffer img, long[] dim, double minValue, double maxValue, int scale,
+			boolean halfPixelOffset, long[] rndState );
+	/** downSample2x (:394-424): out has dim/2 - 1 samples per dimension. */
+	static native void downSample2x( long ctx, FloatBuffer in, long[] dim, FloatBuffer out );
+
 	/** Cross-view weight normalisation (:615-640), in place on every buffer. */
 	static native void normalizeWeights( long ctx, FloatBuffer[] weights, long n, float osem );
 

@@ -8,6 +8,7 @@ import mpicbg.models.AffineModel3D;
 import net.imglib2.Interval;
 import net.imglib2.RandomAccessibleInterval;
 import net.imglib2.img.Img;
+import net.imglib2.img.array.ArrayImgFactory;
 import net.imglib2.type.numeric.real.FloatType;
 import net.imglib2.view.Views;
 
@@ -103,6 +104,40 @@ public class SimulateMultiViewDatasetGPU
 		final FloatBuffer out = Buffers.direct( Buffers.size( d ) );
 		MvsimNative.computeWeightImage( GpuContextPool.get(), d, out );
 		return Buffers.toImg( out, d );
+	}
+
+	/** simulate (:366-392): sphere cloud at 2x resolution, then 2x down-sampling; rnd must be a {@link GpuRandom}. */
+	public static Img< FloatType > simulate( final boolean halfPixelOffset, final Random rnd )
+	{
+		final int scale = 2;
+		final long n = ( 289 + 1 ) * scale;
+		Img< FloatType > img = new ArrayImgFactory< FloatType >().create( new long[] { n, n, n }, new FloatType() );
+		drawSpheres( img, 0, 1, scale, halfPixelOffset, rnd );
+		return downSample2x( img );
+	}
+
+	/** drawSpheres (:436-522), in place: the walk over the large sphere on the host, the small spheres on the GPU. */
+	public static void drawSpheres( final Img< FloatType > img, final double minValue, final double maxValue, final int scale,
+			final boolean halfPixelOffset, final Random rnd )
+	{
+		if ( !( rnd instanceof GpuRandom ) )
+			throw new IllegalArgumentException( "drawSpheres on the GPU continues the caller's random stream: pass a GpuRandom" );
+		final GpuRandom g = ( GpuRandom ) rnd;
+		final long[] state = new long[] { g.getState() };
+		final FloatBuffer b = Buffers.toBuffer( img );
+		MvsimNative.drawSpheres( GpuContextPool.get(), b, Buffers.dims( img ), minValue, maxValue, scale, halfPixelOffset, state );
+		g.setState( state[ 0 ] );
+		Buffers.copyBack( b, img );
+	}
+
+	/** downSample2x (:394-424) */
+	public static Img< FloatType > downSample2x( final RandomAccessibleInterval< FloatType > in )
+	{
+		final long[] d = Buffers.dims( in );
+		final long[] o = new long[] { d[ 0 ] / 2 - 1, d[ 1 ] / 2 - 1, d[ 2 ] / 2 - 1 };
+		final FloatBuffer out = Buffers.direct( Buffers.size( o ) );
+		MvsimNative.downSample2x( GpuContextPool.get(), Buffers.toBuffer( Views.zeroMin( in ) ), d, out );
+		return Buffers.toImg( out, o );
 	}
 
 	/**

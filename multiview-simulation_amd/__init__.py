@@ -435,6 +435,25 @@ class Tools:
         default_context().poisson_process(img, SNR, _seed_from(rnd))
 
     @staticmethod
+    def save(img, file: str) -> None:
+        """Tools.java:88-105 -- ImageJ big-endian float32 TIFF (stack for 3-D images)."""
+        from . import tiffio
+        tiffio.save_tiff(img, file)
+
+    @staticmethod
+    def open(file: str, square: bool = False) -> np.ndarray:
+        """Tools.java:162-232, :290-300 -- float32 TIFF stack -> (Nz,Ny,Nx); ``square`` pads to a cube (makeSquare)."""
+        from . import tiffio
+        img = tiffio.open_tiff(file)
+        return tiffio.make_square(img) if square else img
+
+    @staticmethod
+    def makeSquare(img) -> np.ndarray:
+        """Tools.java:313-349"""
+        from . import tiffio
+        return tiffio.make_square(img)
+
+    @staticmethod
     def normImage(img: np.ndarray) -> None:
         """Tools.java:112-118 -- in place, sum -> 1."""
         default_context().norm_image(img)

@@ -258,6 +258,31 @@ def test_simulate_phantom_full_size(mvs, orc):
     assert 0.1 < float((got > 0).mean()) < 0.3 and float(got.max()) < 1.0
 
 
+def test_reference_configuration_view(ctx, mvs, orc, golden_dir):
+    """BASELINE configs[0], the reference's own run: 289^3 sphere phantom from `simulate()`, the shipped 51^3 PSF
+    `Angle0.tif` through Tools.open(file, true), first view of `main` (angle 0 + offset 15, spacing 3, SNR 25)."""
+    S, T = mvs.SimulateMultiViewDataset, mvs.Tools
+    rendered = S.simulate(False, mvs.JavaRandom(464232194))
+    psf_raw = T.open(os.path.join(golden_dir, "Angle0.tif"), True)
+    assert rendered.shape == (289, 289, 289) and psf_raw.shape == (51, 51, 51)
+    p = ctx.view_params(degrees=15, delta=0.01, inc=3, snr=25.0, seed=464232194, stream=0)
+    psf_g = psf_raw.copy()
+    got = ctx.simulate_view(rendered, psf_g, p, want=("rot", "att", "con", "acq"))
+    psf_o = psf_raw.copy()
+    ref = orc.simulate_view(rendered, psf_o, 15, delta=0.01, inc=3, snr=25.0, seed=464232194, stream=0, conv="fft")
+    assert np.array_equal(psf_g, psf_o)                                   # normalised in place, identically
+    assert np.array_equal(got["rot"], ref["rot"]) and np.array_equal(got["att"], ref["att"])
+    assert rel_to_max(got["con"], ref["con"]) <= CONV_TOL
+    assert got["acq"].shape == ref["acq"].shape == (97, 289, 289)
+    # counts differ only where the 1e-7 wobble of `con` crosses a decision boundary of the sampler (a flipped
+    # rejection test draws a fresh candidate, so a differing count may differ by a whole Poisson deviation)
+    diff = got["acq"] != ref["acq"]
+    assert diff.mean() < 0.01
+    lam = np.maximum(ref["acq"][diff], 1.0)
+    assert np.all(np.abs(got["acq"][diff] - ref["acq"][diff]) <= 8.0 * np.sqrt(lam) + 8.0)
+    assert abs(float(got["acq"].mean()) - float(ref["acq"].mean())) < 0.02
+
+
 # ------------------------------------------------------------------------------------------------ fused view + golden
 def test_golden_view_fixture(ctx, golden_dir):
     g = np.load(os.path.join(golden_dir, "view_24.npz"))
