@@ -36,7 +36,8 @@ def main():
     ap.add_argument("--tiff", action="store_true", help="write ImageJ TIFF files named as the reference names them")
     a = ap.parse_args()
 
-    poissonSNR, lightsheetSpacing, attenuation, osem, angleOffset = 25.0, 3, 0.01, 3.0, 15   # :531-548
+    poissonSNR, lightsheetSpacing, osem, angleOffset = 25.0, 3, 3.0, 15   # :531-548
+    attenuation = float(np.float32(0.01))                     # `final float attenuation = 0.01f` widened to double
     angleIncrement = 52 if a.reference_inputs else 360 // a.views      # seven angles (:540)
     rendered = S.simulate() if a.reference_inputs else synth.sphere_phantom(a.size)
     obj = S.rotateAroundAxis(rendered, 0, angleOffset)        # ground truth (:557)

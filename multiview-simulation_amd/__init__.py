@@ -538,3 +538,84 @@ class SimulateMultiViewDataset:
     def computeWeightImage(img, delta: float = 0.0) -> np.ndarray:
         """:280-316 -- only the interval of ``img`` is used; ``delta`` is ignored as in the reference."""
         return default_context().compute_weight_image(np.shape(img))
+
+
+class SimulateTileStitching:
+    """Mirror of ``net.preibisch.simulation.SimulateTileStitching`` (SimulateTileStitching.java:43-189), the second
+    caller of the per-view operators: two overlapping tiles cut out of one convolved phantom (optionally with a
+    half-pixel shift between them), each run through ``extractSlices`` with its own seeded generator.
+
+    Differences from the reference, all host-side: the two phantoms/convolutions of ``init`` run one after the other
+    on the GPU instead of on two pool threads (in the reference both threads normalise the shared PSF in place at
+    the same time); ``service`` is accepted and ignored; ``psf`` may be passed in instead of being read from
+    ``dir + "Angle0.tif"``.
+    """
+
+    dir = "src/main/resources/"
+
+    def __init__(self, rnd=None, halfPixelOffset: bool = False, overlapRatio=(0.2, 0.2, 0.2), service=None,
+                 psf: np.ndarray | None = None):
+        self.rnd = rnd if rnd is not None else JavaRandom(464232194)          # :66-69
+        self.service = service
+        self.lightsheetSpacing = 3                                              # :48
+        self.attenuation = float(np.float32(0.01))                              # :49, a Java float widened to double
+        self.psf = psf if psf is not None else Tools.open(self.dir + "Angle0.tif", True)
+        self.init(overlapRatio, halfPixelOffset)
+
+    def init(self, overlapRatio, halfPixelOffset: bool) -> None:
+        """:77-129"""
+        S = SimulateMultiViewDataset
+        self.halfPixelOffset = bool(halfPixelOffset)
+        seed = self.rnd.nextInt()                                               # same phantom for both variants
+
+        def rendered(half: bool) -> np.ndarray:
+            gt = S.simulate(half, JavaRandom(seed))
+            att = S.attenuate3d(gt, self.attenuation)
+            con = S.convolve(att, self.psf, self.service)
+            Tools.adjustImage(con, S.minValue, S.avgIntensity)
+            return con
+
+        self.con = rendered(False)
+        self.conHalfPixel = rendered(True)
+        nz, ny, nx = self.con.shape
+        dims = (nx, ny, nz)
+        self.overlap = [int(np.floor(dims[d] * overlapRatio[d] / 2 + 0.5)) for d in range(3)]     # Math.round
+        self.min = [0, 0, 0]
+        self.max = [0, 0, 0]
+
+    def getInterval(self, tile: int):
+        """:226-246 -- inclusive (min, max) per dimension, x first.  Tile 1 starts at dimension(0)/2 - overlap in
+        every dimension, as in the reference."""
+        nz, ny, nx = self.con.shape
+        dims = (nx, ny, nz)
+        lo, hi = [0, 0, 0], [d - 1 for d in dims]
+        if tile == 0:
+            hi = [dims[d] // 2 + self.overlap[d] for d in range(3)]
+        else:
+            lo = [dims[0] // 2 - self.overlap[d] for d in range(3)]
+        return lo, hi
+
+    def _tile(self, img: np.ndarray, tile: int) -> np.ndarray:
+        lo, hi = self.getInterval(tile)
+        return np.ascontiguousarray(img[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1])
+
+    def getNextPair(self, snr: float):
+        """:133-198 -- (left, right) tiles; each draws its extractSlices seed from ``new Random(seedN)``."""
+        S = SimulateMultiViewDataset
+        seed0 = self.rnd.nextInt()
+        seed1 = self.rnd.nextInt()
+        split0 = S.extractSlices(self._tile(self.con, 0), self.lightsheetSpacing, snr, JavaRandom(seed0))
+        src1 = self.conHalfPixel if self.halfPixelOffset else self.con
+        split1 = S.extractSlices(self._tile(src1, 1), self.lightsheetSpacing, snr, JavaRandom(seed1))
+        return split0, split1
+
+    def getCorrectTranslation(self):
+        """:200-224 -- shift of the right tile relative to the left one, (x, y, z) with z in acquired planes."""
+        lo, hi = self.getInterval(1)
+        self.min, self.max = lo, hi
+        t = [float(v) for v in lo]
+        if self.halfPixelOffset:
+            t[0] -= 0.5
+            t[1] -= 0.5
+        t[2] /= self.lightsheetSpacing
+        return t

@@ -283,6 +283,38 @@ def test_reference_configuration_view(ctx, mvs, orc, golden_dir):
     assert abs(float(got["acq"].mean()) - float(ref["acq"].mean())) < 0.02
 
 
+def test_simulate_tile_stitching_pair(mvs, orc, golden_dir):
+    """SimulateTileStitching.java:43-246 at the reference's size: phantom from `new Random(rnd.nextInt())`, no
+    rotation, 51^3 PSF; tiles are sub-intervals of the convolved volume run through extractSlices."""
+    S, T = mvs.SimulateMultiViewDataset, mvs.Tools
+    psf = T.open(os.path.join(golden_dir, "Angle0.tif"), True)
+    sts = mvs.SimulateTileStitching(mvs.JavaRandom(5), True, (0.2, 0.2, 0.2), None, psf=psf.copy())
+    assert sts.con.shape == sts.conHalfPixel.shape == (289, 289, 289)
+    assert sts.overlap == [29, 29, 29]                                   # round(289 * 0.2 / 2)
+    assert sts.getInterval(0) == ([0, 0, 0], [173, 173, 173]) and sts.getInterval(1) == ([115, 115, 115], [288, 288, 288])
+    assert sts.getCorrectTranslation() == [114.5, 114.5, 115 / 3]
+    # the convolved phantom against the oracle's composition of the same calls
+    j = mvs.JavaRandom(5)
+    seed = j.nextInt()
+    gt = orc.simulate_phantom(rnd=orc.JRandom(seed))
+    po = psf.copy()
+    con = orc.convolve_fft(orc.attenuate3d(gt, float(np.float32(0.01))), po)
+    orc.adjust_image(con, 1e-4, 1.0)
+    assert rel_to_max(sts.con, con) <= CONV_TOL
+    # half-pixel variant: every small sphere moved by (+1, +1, 0) on the 2x canvas
+    assert not np.array_equal(sts.con, sts.conHalfPixel)
+    left, right = sts.getNextPair(-1.0)                                  # snr < 0: plain strided copies of the tiles
+    assert left.shape == (58, 174, 174) and right.shape == (58, 174, 174)
+    assert np.array_equal(left, sts.con[0:174:3, 0:174, 0:174])
+    assert np.array_equal(right, sts.conHalfPixel[115:289:3, 115:289, 115:289])
+    l8, r8 = sts.getNextPair(8.0)                                        # the reference's main(): snr = 8
+    mul = (8.0 / np.sqrt(5.0)) ** 2
+    assert l8.shape == left.shape and np.all(l8 == np.round(l8)) and abs(l8.mean() / (left.mean() * mul) - 1) < 0.01
+    assert abs(r8.mean() / (right.mean() * mul) - 1) < 0.01
+    l8b, _ = sts.getNextPair(8.0)                                        # next pair: new seeds from the same generator
+    assert not np.array_equal(l8, l8b)
+
+
 # ------------------------------------------------------------------------------------------------ fused view + golden
 def test_golden_view_fixture(ctx, golden_dir):
     g = np.load(os.path.join(golden_dir, "view_24.npz"))
