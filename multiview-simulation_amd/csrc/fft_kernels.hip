@@ -342,9 +342,12 @@ struct LinesArgs {
     int           dst_tile_major;   // FWD: store tile (bx,by) as NL contiguous lines of L: dst[((by*gridDim.x+bx)*NL + c)*L + n]
 };
 
-// second launch bound: two blocks per CU must stay resident (w = 2*T/256 waves per SIMD, rounded up)
+// second launch bound: as many blocks as the LDS lets a CU hold (two, or one for the long lines) must stay resident
+// (w = blocks*T/256 waves per SIMD, rounded up) -- the register budget follows from that
+template <int L> constexpr int lines_blocks_per_cu() { return 2 * Cfg<L>::LDS <= 160 * 1024 ? 2 : 1; }
 template <class PLAN, int MODE, bool SPARSE>
-__global__ __launch_bounds__(Cfg<PLAN::len>::T, (2 * Cfg<PLAN::len>::T + 255) / 256) void k_fft_lines(LinesArgs p)
+__global__ __launch_bounds__(Cfg<PLAN::len>::T, (lines_blocks_per_cu<PLAN::len>() * Cfg<PLAN::len>::T + 255) / 256)
+void k_fft_lines(LinesArgs p)
 {
     constexpr int L = PLAN::len;
     using C = Cfg<L>;
@@ -755,7 +758,14 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     X(896, 7, 8, 4, 4)     \
     X(1024, 4, 8, 8, 4)    \
     X(1120, 7, 8, 5, 4)    \
-    X(1152, 9, 8, 4, 4)
+    X(1152, 9, 8, 4, 4)    \
+    X(1280, 5, 8, 8, 4)    \
+    X(1440, 9, 8, 5, 4)    \
+    X(1536, 3, 8, 8, 8)    \
+    X(1792, 7, 8, 8, 4)    \
+    X(2048, 8, 8, 8, 4)    \
+    X(2160, 10, 8, 9, 3)   \
+    X(2240, 7, 8, 8, 5)
 
 struct PlanDesc {
     int len;
