@@ -720,6 +720,149 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------- z pass without transforms
+// Pass C as a DIRECT convolution along z in the mixed domain.  After the x and y transforms every z line (kx, ky) of
+// the image spectrum has to be convolved with the z line of the PSF's (x,y) spectrum, which has only Kz taps:
+//     out(z) = sum_j g[j] * f(mirror(z + c - j)),   g[j] = G2[j][ky][kx],  c = Kz/2.
+// For the PSF depths of this workload (Kz <= 64) that is fewer, and far better shaped, flops than a forward
+// transform, a product and an inverse transform of the padded length (4 FMAs per tap against add-heavy butterflies),
+// and it removes whole pieces of the FFT formulation: no z padding (the mirrored halo planes are the SAME planes,
+// re-read through an index map, so passes A and B run on Nz planes instead of Nz+Kz-1), no expansion of the PSF
+// spectrum to Pz planes (one launch and 2 C bytes of HBM traffic), no zero-gap planes.
+// Tile: NLZ = 16 adjacent kx columns (128-B rows) x a z chunk with its halo, staged in LDS row by row exactly as it
+// lies in HBM (pitch 17 to spread the banks); taps of the 16 lines in LDS.  A lane owns one line and ZU consecutive
+// outputs; taps are consumed in chunks of ZJ with a sliding register window over the inputs, so each LDS word is
+// read once per lane and chunk.  Out of place (chunks read each other's halo).
+constexpr int NLZ = 16, ZU = 8, ZJ = 8, ZT = 256, ZPITCH = NLZ + 1;
+constexpr int ZLPR = NLZ / 2;                    // lanes per staged row (16 B each)
+constexpr int ZRPI = ZT / ZLPR;                  // rows per staging iteration
+constexpr int ZNIT = 7;                          // staged rows <= ZNIT * ZRPI = 224 (zconv_chunk keeps the tile below that)
+constexpr int ZBLOCKS_PER_CU = 4;
+constexpr size_t ZLDS_TARGET = 39 * 1024;       // four resident blocks per CU
+// float2 elements of the staged input region (rounded to 16 bytes: the tap region behind it is accessed as float4)
+__host__ __device__ constexpr size_t zconv_frows(int zc, int kz, int kzp)
+{
+    return (((size_t)(kzp - kz + zc + kz - 1) * ZPITCH) + 1) & ~(size_t)1;
+}
+
+struct ZConvArgs {
+    const float2* src;      // [Nz][Py][Hxp]
+    float2*       dst;      // [Nz][Py][Hxp]
+    const float2* taps;     // [Kz][Py][Hxp]
+    long long     plane;    // Hxp * Py
+    int           hxp, nz, kz, c, zc;   // zc: outputs per tile along z (multiple of ZU)
+};
+
+__device__ __forceinline__ int mirror_index(int i, int n)
+{
+    if (n == 1) return 0;
+    const int p = 2 * n - 2;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - i;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int TNIT = 64 / ZRPI;                       // kzp <= 64 rows of taps
+
+// One block per tile = (16-column group, row ky, z chunk): grid (Hxp/16, Py, chunks).
+// (A persistent variant that prefetches the next tile into registers was measured and is not faster: the FMA loop
+// and the two memory phases each take ~0.2-0.3 ms of this kernel and already overlap across the resident blocks.)
+__global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
+{
+    extern __shared__ __align__(16) float2 lds[];
+    const int kzp = (p.kz + ZJ - 1) / ZJ * ZJ;            // taps padded with zeros to whole chunks
+    const int padf = kzp - p.kz;                          // leading zero rows the padded taps may touch
+    const int zc0 = (int)blockIdx.z * p.zc;
+    const int zn = min(p.zc, p.nz - zc0);                 // outputs of this block
+    const int rows = padf + zn + p.kz - 1;                // staged input rows
+    float2* f = lds;                                      // [rows][ZPITCH]
+    float2* g = lds + zconv_frows(p.zc, p.kz, kzp);      // [kzp][NLZ]
+    const int tid = threadIdx.x;
+    const long long col = (long long)blockIdx.y * p.hxp + (long long)blockIdx.x * NLZ;
+    const int c2 = (tid % ZLPR) * 2;                      // staging: ZLPR lanes x 16 B per row
+    const int hl = p.kz - 1 - p.c;                        // halo below z = 0
+    // all global loads of the tile are issued before anything waits
+    float4 v[ZNIT], tv[TNIT];
+#pragma unroll
+    for (int it = 0; it < ZNIT; ++it) {
+        const int r = (tid / ZLPR) + it * ZRPI;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= padf && r < rows) {
+            int z = zc0 + (r - padf) - hl;
+            if ((unsigned)z >= (unsigned)p.nz) z = mirror_index(z, p.nz);
+            v[it] = *reinterpret_cast<const float4*>(p.src + (long long)z * p.plane + col + c2);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < TNIT; ++it) {
+        const int r = (tid / ZLPR) + it * ZRPI;
+        tv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < p.kz) tv[it] = *reinterpret_cast<const float4*>(p.taps + (long long)r * p.plane + col + c2);
+    }
+#pragma unroll
+    for (int it = 0; it < ZNIT; ++it) {
+        const int r = (tid / ZLPR) + it * ZRPI;
+        if (r < rows) {
+            f[r * ZPITCH + c2] = make_float2(v[it].x, v[it].y);
+            f[r * ZPITCH + c2 + 1] = make_float2(v[it].z, v[it].w);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < TNIT; ++it) {
+        const int r = (tid / ZLPR) + it * ZRPI;
+        if (r < kzp) *reinterpret_cast<float4*>(g + r * NLZ + c2) = tv[it];
+    }
+    __syncthreads();
+    const int line = tid & (NLZ - 1);
+    const int nzb = (zn + ZU - 1) / ZU;
+    for (int zb = tid / NLZ; zb < nzb; zb += ZT / NLZ) {
+        const int z0 = zb * ZU;
+        v2f acc[ZU];
+#pragma unroll
+        for (int u = 0; u < ZU; ++u) acc[u] = v2f{0.f, 0.f};
+        // window w[i] = f[base + i]; output u, tap j0 + t reads w[u - t + ZJ - 1]
+        float2 w[ZU + ZJ - 1];
+        int base = padf + z0 + p.kz - 1 - (ZJ - 1);       // j0 = 0
+        // rows above the staged range (the last z block of a chunk may be partial) are clamped: their products only
+        // feed outputs that are not stored
+        const int rmax = rows - 1;
+#pragma unroll
+        for (int i = 0; i < ZU + ZJ - 1; ++i) w[i] = f[min(base + i, rmax) * ZPITCH + line];
+#pragma unroll 1
+        for (int j0 = 0; j0 < kzp; j0 += ZJ) {
+            float2 gg[ZJ];
+#pragma unroll
+            for (int t = 0; t < ZJ; ++t) gg[t] = g[(j0 + t) * NLZ + line];
+#pragma unroll
+            for (int t = 0; t < ZJ; ++t) {
+#pragma unroll
+                for (int u = 0; u < ZU; ++u) {
+                    // complex multiply-accumulate as two packed FMAs: (gr, gr) * (xr, xi), then (-gi, gi) * (xi, xr)
+                    const float2 x = w[u - t + ZJ - 1];
+                    acc[u] = __builtin_elementwise_fma(v2f{gg[t].x, gg[t].x}, v2f{x.x, x.y}, acc[u]);
+                    acc[u] = __builtin_elementwise_fma(v2f{-gg[t].y, gg[t].y}, v2f{x.y, x.x}, acc[u]);
+                }
+            }
+            if (j0 + ZJ < kzp) {
+                // next chunk of taps looks ZJ rows further down
+#pragma unroll
+                for (int i = ZU + ZJ - 2; i >= ZJ; --i) w[i] = w[i - ZJ];
+                base -= ZJ;
+#pragma unroll
+                for (int i = 0; i < ZJ; ++i) w[i] = f[max(base + i, 0) * ZPITCH + line];
+            }
+        }
+        float2* d = p.dst + (long long)(zc0 + z0) * p.plane + col + line;
+#pragma unroll
+        for (int u = 0; u < ZU; ++u) {
+            if (z0 + u < zn) *d = make_float2(acc[u].x, acc[u].y);
+            d += p.plane;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- size table
 #define MVSIM_FFT_SIZES(X) \
     X(16, 4, 4)            \
@@ -789,6 +932,34 @@ template <class K> static int set_lds(K kernel, size_t bytes)
     if (bytes > 64 * 1024)
         MVSIM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MVSIM_OK;
+}
+
+static size_t zconv_lds(int zc, int kz)
+{
+    const int kzp = (kz + ZJ - 1) / ZJ * ZJ;
+    return (zconv_frows(zc, kz, kzp) + (size_t)kzp * NLZ) * sizeof(float2);
+}
+
+// outputs per block along z: as many as fit a quarter of a CU's LDS (four resident blocks), at most Nz rounded up to ZU
+static int zconv_chunk(int nz, int kz)
+{
+    int zc = (nz + ZU - 1) / ZU * ZU;
+    const int kzp = (kz + ZJ - 1) / ZJ * ZJ;
+    while (zc > ZU && (zconv_lds(zc, kz) > ZLDS_TARGET || (kzp - kz) + zc + kz - 1 > ZNIT * ZRPI)) zc -= ZU;
+    // balance the chunks
+    const int nchunks = (nz + zc - 1) / zc;
+    const int even = ((nz + nchunks - 1) / nchunks + ZU - 1) / ZU * ZU;
+    return even < zc ? even : zc;
+}
+
+static int launch_zconv(hipStream_t s, const ZConvArgs& a, int py)
+{
+    const size_t lds = zconv_lds(a.zc, a.kz);
+    dim3 grid(a.hxp / NLZ, py, (a.nz + a.zc - 1) / a.zc);
+    MVSIM_TRY(set_lds(k_zconv, lds));
+    hipLaunchKernelGGL(k_zconv, grid, dim3(ZT), lds, s, a);
+    MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
 
@@ -975,9 +1146,14 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
     const int kx = (int)kdim[0], ky = (int)kdim[1], kz = (int)kdim[2];
     const int M = px / 2;
     const int tile_y = lines_per_tile(py), tile_z = lines_per_tile(pz);
-    const int tw_max = tile_y > tile_z ? tile_y : tile_z;
+    // z pass: direct convolution with the Kz taps (k_zconv) unless the PSF is deep or the FFT formulation is asked for
+    bool zdirect = kz <= 64;
+    if (const char* e = getenv("MVSIM_FFT_ZPASS")) zdirect = std::strcmp(e, "fft") == 0 ? false : (std::strcmp(e, "direct") == 0 ? true : zdirect);
+    const int nzs = (int)dim[2];                                  // planes the image spectrum holds when zdirect
+    int tw_max = tile_y > tile_z ? tile_y : tile_z;
+    if (zdirect) tw_max = tile_y > NLZ ? tile_y : NLZ;
     const int hxp = ((M + 1 + tw_max - 1) / tw_max) * tw_max;
-    const size_t cbytes = (size_t)hxp * py * pz * sizeof(float2);
+    const size_t cbytes = (size_t)hxp * py * (zdirect ? nzs : pz) * sizeof(float2);
     const long long rows_out_early = (long long)dim[1] * dim[2];
     MVSIM_TRY(ctx->cfft_f.reserve(cbytes));
     MVSIM_TRY(ctx->cfft_g.reserve(cbytes));
@@ -992,7 +1168,8 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
     MVSIM_TRY(ensure_twiddles(ctx, M, 0, &tw_m));
     MVSIM_TRY(ensure_twiddles(ctx, px, 1, &tw_px));
     MVSIM_TRY(ensure_twiddles(ctx, py, 0, &tw_py));
-    MVSIM_TRY(ensure_twiddles(ctx, pz, 0, &tw_pz));
+    tw_pz = nullptr;
+    if (!zdirect) MVSIM_TRY(ensure_twiddles(ctx, pz, 0, &tw_pz));
 
     float2* F = ctx->cfft_f.as<float2>();
     float2* G = ctx->cfft_g.as<float2>();
@@ -1020,13 +1197,15 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
         a.dst_es = hxp; a.dst_outer = plane;
         a.lmap = DimMap{ky, py, ky - ky / 2, ky / 2, 1, ky / 2};
         MVSIM_TRY(launch_lines(s, py, FWD, true, a, hxp / tile_y, kz));
-        LinesArgs c{};
-        c.src = G2; c.dst = G; c.spec = nullptr; c.tw = tw_pz;
-        c.src_es = plane; c.src_outer = hxp;                         // per ky row
-        c.dst_es = plane; c.dst_outer = hxp;
-        c.lmap = DimMap{kz, pz, kz - kz / 2, kz / 2, 1, kz / 2};
-        c.dst_tile_major = 1;                                         // consumed line by line in pass C
-        MVSIM_TRY(launch_lines(s, pz, FWD, true, c, hxp / tile_z, py));
+        if (!zdirect) {
+            LinesArgs c{};
+            c.src = G2; c.dst = G; c.spec = nullptr; c.tw = tw_pz;
+            c.src_es = plane; c.src_outer = hxp;                         // per ky row
+            c.dst_es = plane; c.dst_outer = hxp;
+            c.lmap = DimMap{kz, pz, kz - kz / 2, kz / 2, 1, kz / 2};
+            c.dst_tile_major = 1;                                         // consumed line by line in pass C
+            MVSIM_TRY(launch_lines(s, pz, FWD, true, c, hxp / tile_z, py));
+        }
     }
     ev_end(ctx, ST_PSF);
 
@@ -1042,7 +1221,8 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
             const int left = (int)(kdim[d] - 1 - kdim[d] / 2);
             *dm[d] = DimMap{n[d], Pd[d], n[d] + c, left, 0, 0};
         }
-        MVSIM_TRY(launch_r2c(s, M, img, m, F, tw_m, tw_px, hxp, rows_all));
+        if (zdirect) m.z = DimMap{nzs, nzs, nzs, 0, 0, 0};           // no z padding: k_zconv mirrors through an index map
+        MVSIM_TRY(launch_r2c(s, M, img, m, F, tw_m, tw_px, hxp, zdirect ? (long long)py * nzs : rows_all));
         // zero gap of the padded volume: y in [Ny + cy, Py - lefty), z in [Nz + cz, Pz - leftz).  Pass A does not
         // transform (or write) rows there, pass B skips the gap planes and does not load gap rows, pass C does
         // not load gap planes.
@@ -1052,8 +1232,17 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
         b.lmap = ident_none;
         b.gap_lo = ygap_lo; b.gap_hi = ygap_hi;
         b.outer_skip_lo = zgap_lo; b.outer_skip_len = zgap_hi > zgap_lo ? zgap_hi - zgap_lo : 0;
-        MVSIM_TRY(launch_lines(s, py, FWD, false, b, hxp / tile_y, pz - b.outer_skip_len));
+        if (zdirect) { b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0; }
+        MVSIM_TRY(launch_lines(s, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
+        float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
+        if (zdirect) {
+            ZConvArgs z{};
+            z.src = F; z.dst = G; z.taps = G2; z.plane = plane; z.hxp = hxp; z.nz = nzs; z.kz = kz; z.c = kz / 2;
+            z.zc = zconv_chunk(nzs, kz);
+            MVSIM_TRY(launch_zconv(s, z, py));
+            Fz = G;
+        } else {
         LinesArgs c{};
         c.src = F; c.dst = F; c.spec = G; c.tw = tw_pz;
         c.src_es = c.dst_es = c.spec_es = plane; c.src_outer = c.dst_outer = c.spec_outer = hxp;
@@ -1062,13 +1251,15 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
         c.outer_skip_lo = 1 << 30;
         c.store_limit = (int)dim[2];                                  // pass D only reads planes z < Nz
         MVSIM_TRY(launch_lines(s, pz, CONV, false, c, hxp / tile_z, py));
+        }
+        b.src = b.dst = Fz;
         b.tw = tw_py;
         b.store_limit = (int)dim[1];                                  // pass E only reads rows y < Ny
         MVSIM_TRY(launch_lines(s, py, INV, false, b, hxp / tile_y, (int)dim[2]));   // planes z >= Nz are never read
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
-        const float scale = (float)(0.25 / ((double)px * (double)py * (double)pz));
+        const float scale = (float)(0.25 / ((double)px * (double)py * (zdirect ? 1.0 : (double)pz)));
         int nblk = 0;
-        MVSIM_TRY(launch_c2r(s, M, F, out, tw_m, tw_px, hxp, py, (int)dim[0], (int)dim[1], rows_out, scale,
+        MVSIM_TRY(launch_c2r(s, M, Fz, out, tw_m, tw_px, hxp, py, (int)dim[0], (int)dim[1], rows_out, scale,
                              ctx->partials_e.as<double>(), &nblk));
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal);
         MVSIM_HIP(hipGetLastError());
