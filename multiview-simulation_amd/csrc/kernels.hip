@@ -484,9 +484,10 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
 }
 
 // Noise form for production sizes, two launches.
-//   k_extract4_noise : every lane busy -- adjust, the low-lambda inversion and the attempt-0 squeeze of PTRS for
-//                      the lane's 4 voxels.  The ~1/3 of bright voxels that still need the exact test or a retry
-//                      are appended to a work queue in HBM (wave-aggregated atomic append).
+//   k_extract4_noise : every lane busy -- adjust, the "count is 0" shortcut of the low-lambda inversion and the
+//                      attempt-0 squeeze of PTRS for the lane's 4 voxels.  The ~1/3 of bright voxels that still need
+//                      the exact test or a retry, and the few low-lambda voxels whose count may be >= 1, are
+//                      appended to a work queue in HBM (per-block segments, LDS append counter).
 //   k_poisson_resolve: one queue item per lane, looped until resolved; no LDS, no barriers, full occupancy, and
 //                      every lane starts with real work -- the divergent fp64 code (logs, divisions) no longer
 //                      runs once per voxel slot with 1-in-7 lanes active.
@@ -498,6 +499,8 @@ struct PItem {
     unsigned int attempt;         // first attempt still to evaluate (0: exact test of attempt 0 pending)
 };
 
+constexpr unsigned int kSmallLambdaItem = 0xFFFFFFFFu;   // PItem::attempt of an inversion (lambda < 10) work item
+
 template <bool ADJUST>
 __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict__ in, float* __restrict__ out,
                                                         long long plane4, long long nzo, int inc,
@@ -508,8 +511,10 @@ __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict_
 {
     // every block appends to its OWN queue segment: the append counter lives in LDS (one global counter would
     // serialise at ~88 atomics/us chip-wide)
-    __shared__ unsigned int nq;
-    if (threadIdx.x == 0) nq = 0u;
+    // bright (PTRS) items grow from the front of the segment, inversion items from its back: the resolver walks two
+    // homogeneous ranges instead of one mixed one (every voxel queues at most one item, so the ends cannot meet)
+    __shared__ unsigned int nq, nqs;
+    if (threadIdx.x == 0) { nq = 0u; nqs = 0u; }
     __syncthreads();
     PItem* __restrict__ seg = queue + (unsigned long long)blockIdx.x * segcap;
     double corr = 1.0;
@@ -551,7 +556,22 @@ __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict_
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (lam[c] > 0.0 && lam[c] < 10.0) ov[c] = poisson_small(lam[c], w[c]);
+                if (lam[c] > 0.0 && lam[c] < 10.0) {
+                    // Inversion returns 0 iff u < exp(-lambda) (poisson_small).  exp(-lambda) >= 1 - lambda, and the
+                    // bit-defined exponential is within 1e-15 of the true one, so u < 1 - lambda - 1e-12 decides
+                    // "0" without evaluating it: 98.8 % of the background voxels (lambda = minValue * mul) end here.
+                    // Everything else -- a count >= 1 is possible -- joins the work queue, so that no wave of this
+                    // kernel runs the exponential and the search loop for a handful of its lanes.
+                    if (!(lam[c] < 1.0 && u32_open(w[c]) < (1.0 - lam[c]) - 1e-12)) {
+                        const unsigned int pos = atomicAdd(&nqs, 1u);
+                        PItem it;
+                        it.index = index4 + (unsigned long long)c;
+                        it.out = 4ull * (unsigned long long)o + (unsigned long long)c;
+                        it.v = vv[c];
+                        it.attempt = kSmallLambdaItem;
+                        seg[segcap - 1u - pos] = it;
+                    }
+                }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -584,7 +604,10 @@ __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict_
         out4[o] = make_float4(ov[0], ov[1], ov[2], ov[3]);
     }
     __syncthreads();
-    if (threadIdx.x == 0) qcount[blockIdx.x] = nq < segcap ? nq : segcap;
+    if (threadIdx.x == 0) {
+        qcount[2 * blockIdx.x] = nq;
+        qcount[2 * blockIdx.x + 1] = nqs;
+    }
 }
 
 // One block per queue segment (same grid as k_extract4_noise; the grid-stride walk of that kernel spreads the
@@ -593,8 +616,16 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out
                                                          const unsigned int* __restrict__ qcount, unsigned int segcap,
                                                          double mul, uint32_t k0, uint32_t k1, uint32_t stream)
 {
-    const unsigned int n = qcount[blockIdx.x];
+    const unsigned int n = qcount[2 * blockIdx.x], ns = qcount[2 * blockIdx.x + 1];
     const PItem* __restrict__ seg = queue + (unsigned long long)blockIdx.x * segcap;
+    // inversion items (0 < lambda < 10 that the shortcut of k_extract4_noise could not settle), from the back
+    for (unsigned int i = threadIdx.x; i < ns; i += 256u) {
+        const PItem it = seg[segcap - 1u - i];
+        const unsigned long long g = it.index >> 2;                  // the voxel's word of its group block
+        const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream, 0u, k0, k1);
+        const uint32_t lane = (uint32_t)it.index & 3u;
+        out[it.out] = poisson_small((double)it.v * mul, lane == 0 ? r.x : (lane == 1 ? r.y : (lane == 2 ? r.z : r.w)));
+    }
     for (unsigned int i = threadIdx.x; i < n; i += 256u) {
         const PItem it = seg[i];
         const double lam = (double)it.v * mul;
@@ -635,7 +666,7 @@ size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)
     unsigned int segcap;
     poisson_geometry(n_out, &blocks, &segcap);
     if (capacity) *capacity = (unsigned long long)blocks * segcap;
-    return (size_t)POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);   // [counts][segments]
+    return (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);   // [counts][segments]
 }
 
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
@@ -659,7 +690,7 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
             unsigned int segcap;
             poisson_geometry(total, &qblocks, &segcap);
             unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
-            PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)POISSON_MAX_BLOCKS * sizeof(unsigned int));
+            PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int));
             if (adjust)
                 hipLaunchKernelGGL((k_extract4_noise<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
                                    scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
