@@ -35,9 +35,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 # HBM bytes per view and stage measured with rocprofv3 PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes) for
-# the default workload; key = (volume edge, PSF edge, inc).  Source: profiles/r01_d_pmc_hbm_traffic.txt
+# the default workload; key = (volume edge, PSF edge, inc).  Source: profiles/r01_e_pmc_hbm_traffic.txt
 MEASURED_TRAFFIC = {
-    (512, 31, 1): {"rotate_attenuate": 1.06e9, "convolve": 7.96e9, "extract_poisson": 1.52e9},
+    (512, 31, 1): {"rotate_attenuate": 1.06e9, "convolve": 6.49e9, "extract_poisson": 1.73e9},
 }
 
 
@@ -257,7 +257,7 @@ def main():
                                    f"device-resident; BASELINE configs[1] per view, configs[2] sharding",
                        "volume": [n, n, n], "psf": [args.psf] * 3, "views_total": total_views,
                        "views_per_gpu": views_per_gpu, "inc": args.inc, "snr": args.snr,
-                       "conv_method": "fft (hand-written LDS FFT passes; rocFFT only for unsupported sizes)" if args.conv_method == 1 else "direct stencil",
+                       "conv_method": "fft (hand-written LDS FFT passes in x and y, direct Kz-tap convolution in z; rocFFT only for unsupported sizes)" if args.conv_method == 1 else "direct stencil",
                        "streams_per_gpu": len(ctxs),
                        "collective": ("none" if world == 1 else "RCCL broadcast of the ground truth, one per step, "
                                       + ("serial" if args.serial_broadcast else "issued one dataset ahead"))},
@@ -269,7 +269,7 @@ def main():
             # writes its output once; adjustImage costs nothing extra on the fused path.
             alg = {
                 "rotate_attenuate": 16 * nvox,               # rotate 8N + attenuate 8N (one fused kernel)
-                "convolve": 8 * nvox + 4 * k3,               # + PSF spectrum, 9 launches
+                "convolve": 8 * nvox + 4 * k3,               # + PSF spectrum, 8 launches
                 "extract_poisson": 8 * nprime,               # 2 launches
             }
             ms = {
@@ -285,8 +285,9 @@ def main():
             b_cn = 8 * nvox + 8 * nprime
             cn_ms = ms["convolve"] + ms["extract_poisson"]
             names = {
-                "convolve": "convolve stage = 9 launches: PSF spectrum (k_fft_x_r2c, 2x k_fft_lines<FWD,sparse>), "
-                            "k_fft_x_r2c, k_fft_lines<FWD>, k_fft_lines<CONV>, k_fft_lines<INV>, k_fft_x_c2r, k_reduce_partials",
+                "convolve": "convolve stage = 8 launches: PSF (x,y) spectrum (k_fft_x_r2c, k_fft_lines<FWD,sparse>), "
+                            "k_fft_x_r2c, k_fft_lines<FWD>, k_zconv (direct z convolution), k_fft_lines<INV>, k_fft_x_c2r, "
+                            "k_reduce_partials",
                 "extract_poisson": "extract stage = k_extract4_noise + k_poisson_resolve",
                 "rotate_attenuate": "k_rotate_attenuate_axis0",
             }
