@@ -766,7 +766,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int TNIT = 64 / ZRPI;                       // kzp <= 64 rows of taps
 
-// One block per tile = (16-column group, row ky, z chunk): grid (Hxp/16, Py, chunks).
+// One block per tile = (z chunk, 16-column group, row ky): grid (chunks, Hxp/16, Py) -- the chunks of a column are
+// dispatched together, so a chunk's halo rows are usually still in L2 / Infinity Cache from its neighbour.
 // (A persistent variant that prefetches the next tile into registers was measured and is not faster: the FMA loop
 // and the two memory phases each take ~0.2-0.3 ms of this kernel and already overlap across the resident blocks.)
 __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
@@ -774,13 +775,13 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     extern __shared__ __align__(16) float2 lds[];
     const int kzp = (p.kz + ZJ - 1) / ZJ * ZJ;            // taps padded with zeros to whole chunks
     const int padf = kzp - p.kz;                          // leading zero rows the padded taps may touch
-    const int zc0 = (int)blockIdx.z * p.zc;
+    const int zc0 = (int)blockIdx.x * p.zc;
     const int zn = min(p.zc, p.nz - zc0);                 // outputs of this block
     const int rows = padf + zn + p.kz - 1;                // staged input rows
     float2* f = lds;                                      // [rows][ZPITCH]
     float2* g = lds + zconv_frows(p.zc, p.kz, kzp);      // [kzp][NLZ]
     const int tid = threadIdx.x;
-    const long long col = (long long)blockIdx.y * p.hxp + (long long)blockIdx.x * NLZ;
+    const long long col = (long long)blockIdx.z * p.hxp + (long long)blockIdx.y * NLZ;
     const int c2 = (tid % ZLPR) * 2;                      // staging: ZLPR lanes x 16 B per row
     const int hl = p.kz - 1 - p.c;                        // halo below z = 0
     // all global loads of the tile are issued before anything waits
@@ -956,7 +957,7 @@ static int zconv_chunk(int nz, int kz)
 static int launch_zconv(hipStream_t s, const ZConvArgs& a, int py)
 {
     const size_t lds = zconv_lds(a.zc, a.kz);
-    dim3 grid(a.hxp / NLZ, py, (a.nz + a.zc - 1) / a.zc);
+    dim3 grid((a.nz + a.zc - 1) / a.zc, a.hxp / NLZ, py);
     MVSIM_TRY(set_lds(k_zconv, lds));
     hipLaunchKernelGGL(k_zconv, grid, dim3(ZT), lds, s, a);
     MVSIM_HIP(hipGetLastError());
