@@ -564,6 +564,67 @@ def test_invalid_arguments_are_rejected(ctx):
         ctx.simulate_view(v, np.ones((3, 3, 3), np.float32), ctx.view_params(inc=0))
 
 
+# ------------------------------------------------------------------------------------------------ alternative conv paths
+@pytest.fixture
+def env_override():
+    """Set environment switches the library reads per call (getenv inside the C entry points); restored afterwards."""
+    saved = {}
+
+    def setenv(**kw):
+        for k, v in kw.items():
+            saved.setdefault(k, os.environ.get(k))
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    yield setenv
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("shape,kshape", [((40, 48, 56), (9, 7, 5)), ((64, 64, 64), (15, 15, 15)), ((33, 70, 45), (31, 5, 11))])
+def test_convolve_fft_z_pass_and_rocfft_fallback_agree(ctx, orc, env_override, shape, kshape):
+    """The three transform-domain formulations -- direct z pass (default for Kz <= 64), FFT z pass with the expanded
+    PSF spectrum (deep PSFs), rocFFT (sizes outside the pass table) -- all meet the 1e-5 contract."""
+    rng = np.random.default_rng(44)
+    v = rng.random(shape, dtype=np.float32)
+    psf = rng.random(kshape, dtype=np.float32) + 0.1
+    ref = orc.convolve_fft(v, psf.copy())
+    env_override(MVSIM_FFT_ZPASS=None, MVSIM_FFT_BACKEND=None)
+    direct = ctx.convolve(v, psf.copy(), method=1)
+    env_override(MVSIM_FFT_ZPASS="fft")
+    zfft = ctx.convolve(v, psf.copy(), method=1)
+    env_override(MVSIM_FFT_ZPASS=None, MVSIM_FFT_BACKEND="rocfft")
+    roc = ctx.convolve(v, psf.copy(), method=1)
+    for got in (direct, zfft, roc):
+        assert rel_to_max(got, ref) <= CONV_TOL
+    assert rel_to_max(direct, zfft) <= 2e-6 and rel_to_max(direct, roc) <= 2e-6
+
+
+def test_convolve_deep_psf_takes_the_fft_z_pass(ctx, orc, synth):
+    """Kz > 64 taps: the direct z pass is not offered, the FFT z pass runs (and agrees with the oracle)."""
+    v = synth.sphere_phantom(72)
+    psf = synth.gaussian_psf(7, 7, 71, sigma=(1.2, 1.3, 14.0))
+    got = ctx.convolve(v, psf.copy(), method=1)
+    assert rel_to_max(got, orc.convolve_fft(v, psf.copy())) <= CONV_TOL
+
+
+def test_view_with_fft_z_pass_is_a_valid_view(ctx, orc, synth, env_override):
+    """The fused view on the FFT z pass: rot/att bit-exact, con within tolerance, same acquisition statistics."""
+    gt = synth.sphere_phantom(48)
+    psf = synth.gaussian_psf(9, sigma=(1.2, 1.4, 2.5))
+    p = ctx.view_params(degrees=33, delta=0.01, inc=2, snr=25.0, seed=SEED, stream=2)
+    a = ctx.simulate_view(gt, psf.copy(), p, want=("att", "con", "acq"))
+    env_override(MVSIM_FFT_ZPASS="fft")
+    b = ctx.simulate_view(gt, psf.copy(), p, want=("att", "con", "acq"))
+    assert np.array_equal(a["att"], b["att"])
+    assert rel_to_max(a["con"], b["con"]) <= 2e-6
+    assert (a["acq"] != b["acq"]).mean() < 0.02
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE configs[3], [4]
 def _window_volume(nz, ny, nx):
     """Compactly supported, non-separable enough: product of (1 - t^2)^2 windows plus a few isolated bright voxels."""
