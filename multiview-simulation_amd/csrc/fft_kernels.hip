@@ -733,12 +733,12 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
 // lies in HBM (pitch 17 to spread the banks); taps of the 16 lines in LDS.  A lane owns one line and ZU consecutive
 // outputs; taps are consumed in chunks of ZJ with a sliding register window over the inputs, so each LDS word is
 // read once per lane and chunk.  Out of place (chunks read each other's halo).
-constexpr int NLZ = 16, ZU = 8, ZJ = 8, ZT = 256, ZPITCH = NLZ + 1;
+constexpr int NLZ = 16, ZU = 16, ZJ = 8, ZT = 256, ZPITCH = NLZ + 1;
 constexpr int ZLPR = NLZ / 2;                    // lanes per staged row (16 B each)
 constexpr int ZRPI = ZT / ZLPR;                  // rows per staging iteration
-constexpr int ZNIT = 7;                          // staged rows <= ZNIT * ZRPI = 224 (zconv_chunk keeps the tile below that)
-constexpr int ZBLOCKS_PER_CU = 4;
-constexpr size_t ZLDS_TARGET = 39 * 1024;       // four resident blocks per CU
+constexpr int ZNIT = 9;                          // staged rows <= ZNIT * ZRPI = 224 (zconv_chunk keeps the tile below that)
+constexpr int ZBLOCKS_PER_CU = 3;
+constexpr size_t ZLDS_TARGET = 44 * 1024;       // four resident blocks per CU
 // float2 elements of the staged input region (rounded to 16 bytes: the tap region behind it is accessed as float4)
 __host__ __device__ constexpr size_t zconv_frows(int zc, int kz, int kzp)
 {
