@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 # HBM bytes per view and stage measured with rocprofv3 PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes) for
 # the default workload; key = (volume edge, PSF edge, inc).  Source: profiles/r01_e_pmc_hbm_traffic.txt
 MEASURED_TRAFFIC = {
-    (512, 31, 1): {"rotate_attenuate": 1.06e9, "convolve": 6.49e9, "extract_poisson": 1.73e9},
+    (512, 31, 1): {"rotate_attenuate": 1.06e9, "convolve": 6.41e9, "extract_poisson": 1.73e9},
 }
 
 
