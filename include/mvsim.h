@@ -203,10 +203,33 @@ int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, i
 /* In-place sum over ranks (RCCL all-reduce) of a device float buffer: the per-voxel weight sums of SMVD:625-628
  * when the views live on different GPUs.  Summation order differs from the sequential reference (<= 1 ulp). */
 int mvsim_comm_allreduce_sum(mvsim_ctx* ctx, float* buf_dev, int64_t count);
+/* Sum over ranks of ONE double held on the host (in place; synchronises): the adjustImage sum of a view whose
+ * z slabs live on different GPUs. */
+int mvsim_comm_allreduce_sum_f64(mvsim_ctx* ctx, double* value_host);
 int mvsim_comm_destroy(mvsim_ctx* ctx);
 /* view v of n_views belongs to rank v % nranks; returns how many views `rank` owns and writes
  * their indices (capacity max_out). */
 int mvsim_shard_views(int n_views, int nranks, int rank, int* view_idx, int max_out);
+
+
+/* ---- z-slab tiling of ONE view across GPUs (BASELINE configs[3]/[4]) ----------------------------
+ * For volumes whose views should be split over several GPUs: rank r owns the planes [z0, z1) of the view
+ * (mvsim_slab_range gives a balanced partition).  Every rank holds the whole ground truth (broadcast); rotation and
+ * attenuation of the slab and of the Kz/2 halo planes the PSF reaches are recomputed locally (attenuation runs along
+ * y inside a plane, SMVD:335-359), the mirror boundary acts at the global faces only, and the only exchange is the
+ * sum of the convolved voxels that adjustImage needs.  Per view and rank:
+ *     mvsim_view_slab_convolve_dev(...,&slab_sum)      rotate, attenuate, convolve the slab (kept in the context)
+ *     total = sum of slab_sum over ranks               e.g. mvsim_comm_allreduce_sum_f64
+ *     mvsim_view_slab_finish_dev(..., total, acq)      adjust with the global mean, extract, Poisson
+ * acq receives the acquired planes k with z0 <= k*inc < z1, in order (*n_planes of them); Poisson counters use the
+ * global voxel index, so the tiling is invisible in the counts.  Needs rotation about x (axis 0), the hand-written
+ * convolution path and a PSF depth <= 64. */
+int mvsim_slab_range(int64_t nz, int nranks, int rank, int64_t* z0, int64_t* z1);
+int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host,
+                                 const int64_t kdim[3], const mvsim_view_params* params, int64_t z0, int64_t z1,
+                                 double* slab_sum);
+int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim_view_params* params, int64_t z0,
+                               int64_t z1, double total_sum, float* acq, int64_t* n_planes);
 
 #ifdef __cplusplus
 }

@@ -338,6 +338,33 @@ class Context:
             C.byref(o), C.byref(corr) if want_corr else None))
         return corr.value if want_corr else None
 
+    # -- z-slab tiling of one view across GPUs (BASELINE configs[3]/[4])
+    def slab_range(self, nz: int, nranks: int, rank: int):
+        z0, z1 = C.c_int64(), C.c_int64()
+        _lib.check(self._L.mvsim_slab_range(int(nz), int(nranks), int(rank), C.byref(z0), C.byref(z1)))
+        return int(z0.value), int(z1.value)
+
+    def view_slab_convolve_dev(self, gt_dptr: int, dim_xyz, psf: np.ndarray, params: ViewParams, z0: int, z1: int) -> float:
+        """Rotate, attenuate and convolve the planes [z0, z1) of the view (kept in this context); returns their sum."""
+        _check_inplace(psf, "psf")
+        s = C.c_double()
+        _lib.check(self._L.mvsim_view_slab_convolve_dev(self._h, C.c_void_p(gt_dptr), (C.c_int64 * 3)(*dim_xyz),
+                                                        _ptr(psf), _dim(psf), C.byref(params), int(z0), int(z1),
+                                                        C.byref(s)))
+        return float(s.value)
+
+    def view_slab_finish_dev(self, dim_xyz, params: ViewParams, z0: int, z1: int, total_sum: float, acq_dptr: int) -> int:
+        """Adjust with the global mean, extract the acquired planes of the slab, Poisson; returns their number."""
+        n = C.c_int64()
+        _lib.check(self._L.mvsim_view_slab_finish_dev(self._h, (C.c_int64 * 3)(*dim_xyz), C.byref(params), int(z0),
+                                                      int(z1), float(total_sum), C.c_void_p(acq_dptr), C.byref(n)))
+        return int(n.value)
+
+    def comm_allreduce_sum_f64(self, value: float) -> float:
+        v = C.c_double(value)
+        _lib.check(self._L.mvsim_comm_allreduce_sum_f64(self._h, C.byref(v)))
+        return float(v.value)
+
     # -- device-resident stage operators (raw addresses)
     def rotate_around_axis_dev(self, in_dptr, dim_xyz, axis, degrees, out_dptr):
         _lib.check(self._L.mvsim_rotate_around_axis_dev(self._h, C.c_void_p(in_dptr), (C.c_int64 * 3)(*dim_xyz), axis,

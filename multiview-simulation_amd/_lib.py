@@ -102,6 +102,12 @@ SIGNATURES = {
     "mvsim_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "mvsim_comm_broadcast_volume": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
     "mvsim_comm_allreduce_sum": (C.c_int, [_vp, _vp, C.c_int64]),
+    "mvsim_comm_allreduce_sum_f64": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "mvsim_slab_range": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mvsim_view_slab_convolve_dev": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, _vp, C.c_int64, C.c_int64,
+                                               C.POINTER(C.c_double)]),
+    "mvsim_view_slab_finish_dev": (C.c_int, [_vp, _i64p, _vp, C.c_int64, C.c_int64, C.c_double, _vp,
+                                             C.POINTER(C.c_int64)]),
     "mvsim_comm_destroy": (C.c_int, [_vp]),
     "mvsim_shard_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
 }

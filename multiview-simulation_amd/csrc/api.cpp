@@ -3,6 +3,8 @@
 // arithmetic happens in the HIP kernels (kernels.hip, fftconv.hip, stencil.hip).
 #include "common.h"
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstring>
 
@@ -557,6 +559,96 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
         MVSIM_HIP(hipStreamSynchronize(ctx->stream));
     }
     return MVSIM_OK;
+}
+
+// ---- z-slab tiling of one view (BASELINE configs[3]/[4]) ------------------------------------------------
+int mvsim_slab_range(int64_t nz, int nranks, int rank, int64_t* z0, int64_t* z1)
+{
+    if (nz < 1 || nranks < 1 || rank < 0 || rank >= nranks || !z0 || !z1) {
+        set_error("invalid argument: slab range");
+        return MVSIM_EINVAL;
+    }
+    *z0 = nz * rank / nranks;
+    *z1 = nz * (rank + 1) / nranks;
+    return MVSIM_OK;
+}
+
+int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host,
+                                 const int64_t kdim[3], const mvsim_view_params* p, int64_t z0, int64_t z1,
+                                 double* slab_sum)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(gt && p && slab_sum, "null pointer");
+    MVSIM_CHECK_ARG(p->axis == 0, "slab tiling supports rotation about x (axis 0)");
+    MVSIM_CHECK_ARG(dim[0] <= dim[1], "attenuate3d: Nx > Ny walks outside the interval in the reference");
+    MVSIM_CHECK_ARG(0 <= z0 && z0 < z1 && z1 <= dim[2], "slab must satisfy 0 <= z0 < z1 <= Nz");
+    MVSIM_CHECK_ARG(kdim && kdim[2] >= 1 && kdim[2] <= 64, "slab tiling needs a PSF depth <= 64 (direct z pass)");
+    const int64_t nz = dim[2], kz = kdim[2], c = kz / 2, hl = kz - 1 - c;
+    // planes the taps of the slab's outputs reach: [z0 - hl, z1 - 1 + c], folded back at the global faces
+    int64_t za = z0 - hl, zb = z1 + c;                     // [za, zb)
+    if (za < 0) { zb = std::max<int64_t>(zb, std::min<int64_t>(nz, -za + 1)); za = 0; }
+    if (zb > nz) { za = std::min<int64_t>(za, std::max<int64_t>(0, 2 * nz - 1 - zb)); zb = nz; }
+    if (kz >= nz) { za = 0; zb = nz; }
+    int64_t P[3];
+    if (!custom_fft_sizes(dim, kdim, P)) {
+        set_error("slab tiling: no hand-written FFT size for this volume / PSF");
+        return MVSIM_EINVAL;
+    }
+    const size_t pbytes = (size_t)dim[0] * dim[1] * sizeof(float);
+    MVSIM_TRY(ctx->vol_b.reserve(pbytes * (size_t)(zb - za)));
+    MVSIM_TRY(ctx->vol_a.reserve(pbytes * (size_t)(z1 - z0)));
+    MVSIM_TRY(psf_prepare(ctx, psf_host, kdim, dim));
+    double m[12];
+    Affine inv;
+    axis_rotation_host(dim, p->axis, p->degrees, m);
+    affine_invert_host(m, inv.m);
+    bool fused = false;
+    MVSIM_TRY(launch_rotate_attenuate_planes(ctx->stream, gt, nullptr, ctx->vol_b.as<float>(), dim, inv, p->delta,
+                                             (int)za, (int)(zb - za), &fused));
+    if (!fused) {
+        set_error("slab tiling needs the fused rotate+attenuate kernel");
+        return MVSIM_EINVAL;
+    }
+    const SlabRange slab{(int)za, (int)(zb - za), (int)z0, (int)(z1 - z0)};
+    MVSIM_TRY(custom_fft_convolve_slab(ctx, ctx->vol_b.as<float>(), dim, ctx->psf_dev.as<float>(), kdim, P, slab,
+                                       ctx->vol_a.as<float>()));
+    double *partial, *scal;
+    MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
+    MVSIM_HIP(hipMemcpyAsync(slab_sum, scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    return MVSIM_OK;
+}
+
+int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim_view_params* p, int64_t z0,
+                               int64_t z1, double total_sum, float* acq, int64_t* n_planes)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(p && acq, "null pointer");
+    MVSIM_CHECK_ARG(0 <= z0 && z0 < z1 && z1 <= dim[2], "slab must satisfy 0 <= z0 < z1 <= Nz");
+    MVSIM_CHECK_ARG(p->inc >= 1, "inc must be >= 1");
+    const int64_t plane = dim[0] * dim[1];
+    MVSIM_CHECK_ARG(ctx->vol_a.bytes >= (size_t)(plane * (z1 - z0)) * sizeof(float), "no convolved slab in this context");
+    double *partial, *scal;
+    MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
+    MVSIM_HIP(hipMemcpyAsync(scal, &total_sum, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));          // total_sum lives on the caller's stack
+    MVSIM_TRY(launch_adjust_corr(ctx->stream, scal, nvox(dim), p->min_value, p->target_average));
+    const int64_t k0 = (z0 + p->inc - 1) / p->inc, k1 = (z1 + p->inc - 1) / p->inc;     // acquired planes k: z0 <= k*inc < z1
+    if (n_planes) *n_planes = k1 - k0;
+    if (k1 <= k0) return MVSIM_OK;
+    const int64_t first = k0 * p->inc;                      // global index of the first acquired source plane
+    const int64_t ldim[3] = {dim[0], dim[1], z1 - first};
+    const bool noise = p->snr >= 0.0f;
+    void* qws = nullptr;
+    if (noise) {
+        MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(plane * (k1 - k0), nullptr)));
+        qws = ctx->pqueue.p;
+    }
+    return launch_extract(ctx->stream, ctx->vol_a.as<float>() + plane * (first - z0), acq, ldim, p->inc, true, scal,
+                          p->min_value, noise, mvsim_poisson_mul((double)p->snr), p->seed, p->stream,
+                          (uint64_t)(first * plane), qws);
 }
 
 // ---- host-buffer entry points (JNI boundary) ---------------------------------------------------------

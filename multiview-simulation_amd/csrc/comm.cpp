@@ -67,6 +67,20 @@ int mvsim_comm_allreduce_sum(mvsim_ctx* ctx, float* buf_dev, int64_t count)
     return MVSIM_OK;
 }
 
+int mvsim_comm_allreduce_sum_f64(mvsim_ctx* ctx, double* value_host)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr && value_host != nullptr, "null pointer");
+    MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
+    MVSIM_HIP(hipSetDevice(ctx->device));
+    MVSIM_TRY(ctx->partials.reserve((mvsim::SUM_BLOCKS + 8) * sizeof(double)));
+    double* slot = ctx->partials.as<double>() + mvsim::SUM_BLOCKS + 4;        // scratch behind [sum, corr]
+    MVSIM_HIP(hipMemcpyAsync(slot, value_host, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MVSIM_NCCL(ncclAllReduce(slot, slot, 1, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    MVSIM_HIP(hipMemcpyAsync(value_host, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    return MVSIM_OK;
+}
+
 int mvsim_comm_destroy(mvsim_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return MVSIM_OK;

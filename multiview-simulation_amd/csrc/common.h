@@ -136,6 +136,8 @@ int launch_rotate(hipStream_t s, const float* in, float* out, const int64_t dim[
 int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta);
 int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
                             const Affine& inv, double delta, bool* fused);
+int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
+                                   const Affine& inv, double delta, int z_begin, int z_count, bool* fused);
 // sum -> scal[0]; partial workspace must hold >= SUM_BLOCKS doubles
 constexpr int SUM_BLOCKS = 2048;
 int launch_sum(hipStream_t s, const float* in, int64_t n, double* partial, double* scal);
@@ -177,6 +179,14 @@ void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3]);
 bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3]);
 int  custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                          const int64_t kdim[3], const int64_t P[3], float* out);
+// z-slab form (direct z pass only): `img` holds the planes [z_in0, z_in0 + nz_in) of a volume with dim[2] planes,
+// `out` receives the planes [z_out0, z_out0 + nz_out); every plane the Kz taps reach (mirrored at the global faces)
+// must lie inside the input range.  The sum left in the context's scalar slot is the sum of the output planes.
+struct SlabRange {
+    int z_in0, nz_in, z_out0, nz_out;
+};
+int  custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
+                              const int64_t kdim[3], const int64_t P[3], const SlabRange& slab, float* out);
 void custom_fft_release(mvsim_ctx* ctx);
 
 // stage timing helpers (events are recorded on the stream the kernels run on)

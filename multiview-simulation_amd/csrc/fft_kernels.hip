@@ -750,7 +750,10 @@ struct ZConvArgs {
     float2*       dst;      // [Nz][Py][Hxp]
     const float2* taps;     // [Kz][Py][Hxp]
     long long     plane;    // Hxp * Py
-    int           hxp, nz, kz, c, zc;   // zc: outputs per tile along z (multiple of ZU)
+    int           hxp, nz, kz, c, zc;   // nz: output planes; zc: outputs per tile along z (multiple of ZU)
+    // z-slab tiling: the mirror boundary acts on the GLOBAL plane index; src holds the global planes from z_in0 on,
+    // dst plane 0 is global plane z_out0 (whole volume: nz_global = nz, both offsets 0)
+    int           nz_global, z_in0, z_out0;
 };
 
 __device__ __forceinline__ int mirror_index(int i, int n)
@@ -791,9 +794,9 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
         const int r = (tid / ZLPR) + it * ZRPI;
         v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r >= padf && r < rows) {
-            int z = zc0 + (r - padf) - hl;
-            if ((unsigned)z >= (unsigned)p.nz) z = mirror_index(z, p.nz);
-            v[it] = *reinterpret_cast<const float4*>(p.src + (long long)z * p.plane + col + c2);
+            int z = p.z_out0 + zc0 + (r - padf) - hl;
+            if ((unsigned)z >= (unsigned)p.nz_global) z = mirror_index(z, p.nz_global);
+            v[it] = *reinterpret_cast<const float4*>(p.src + (long long)(z - p.z_in0) * p.plane + col + c2);
         }
     }
 #pragma unroll
@@ -1142,7 +1145,15 @@ void custom_fft_release(mvsim_ctx* ctx)
 int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                         const int64_t kdim[3], const int64_t P[3], float* out)
 {
+    const SlabRange whole{0, (int)dim[2], 0, (int)dim[2]};
+    return custom_fft_convolve_slab(ctx, img, dim, psf, kdim, P, whole, out);
+}
+
+int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
+                             const int64_t kdim[3], const int64_t P[3], const SlabRange& slab, float* out)
+{
     using namespace fft;
+    const bool is_slab = slab.nz_in != (int)dim[2] || slab.nz_out != (int)dim[2];
     const int px = (int)P[0], py = (int)P[1], pz = (int)P[2];
     const int kx = (int)kdim[0], ky = (int)kdim[1], kz = (int)kdim[2];
     const int M = px / 2;
@@ -1150,12 +1161,17 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
     // z pass: direct convolution with the Kz taps (k_zconv) unless the PSF is deep or the FFT formulation is asked for
     bool zdirect = kz <= 64;
     if (const char* e = getenv("MVSIM_FFT_ZPASS")) zdirect = std::strcmp(e, "fft") == 0 ? false : (std::strcmp(e, "direct") == 0 ? true : zdirect);
-    const int nzs = (int)dim[2];                                  // planes the image spectrum holds when zdirect
+    if (is_slab && !zdirect) {
+        set_error("z-slab tiling needs the direct z pass (PSF depth %d > 64 or MVSIM_FFT_ZPASS=fft)", kz);
+        return MVSIM_EINVAL;
+    }
+    const int nzs = slab.nz_in;                                   // planes the image spectrum holds when zdirect
+    const int nzo = slab.nz_out;                                  // planes that leave the z pass
     int tw_max = tile_y > tile_z ? tile_y : tile_z;
     if (zdirect) tw_max = tile_y > NLZ ? tile_y : NLZ;
     const int hxp = ((M + 1 + tw_max - 1) / tw_max) * tw_max;
     const size_t cbytes = (size_t)hxp * py * (zdirect ? nzs : pz) * sizeof(float2);
-    const long long rows_out_early = (long long)dim[1] * dim[2];
+    const long long rows_out_early = (long long)dim[1] * nzo;
     MVSIM_TRY(ctx->cfft_f.reserve(cbytes));
     MVSIM_TRY(ctx->cfft_g.reserve(cbytes));
     // compact PSF intermediates: G1 [kz][ky][hxp] (x transformed), G2 [kz][py][hxp] (x,y transformed)
@@ -1178,7 +1194,7 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
     float2* G2 = ctx->cfft_g2.as<float2>();
     hipStream_t s = ctx->stream;
     const long long rows_all = (long long)py * pz;
-    const long long rows_out = (long long)dim[1] * dim[2];
+    const long long rows_out = (long long)dim[1] * nzo;
     const long long plane = (long long)hxp * py;
     const DimMap ident_none = DimMap{0, 0, 0, 0, 1, 0};
 
@@ -1239,8 +1255,9 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
         float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
         if (zdirect) {
             ZConvArgs z{};
-            z.src = F; z.dst = G; z.taps = G2; z.plane = plane; z.hxp = hxp; z.nz = nzs; z.kz = kz; z.c = kz / 2;
-            z.zc = zconv_chunk(nzs, kz);
+            z.src = F; z.dst = G; z.taps = G2; z.plane = plane; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
+            z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
+            z.zc = zconv_chunk(nzo, kz);
             MVSIM_TRY(launch_zconv(s, z, py));
             Fz = G;
         } else {
@@ -1256,7 +1273,7 @@ int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], 
         b.src = b.dst = Fz;
         b.tw = tw_py;
         b.store_limit = (int)dim[1];                                  // pass E only reads rows y < Ny
-        MVSIM_TRY(launch_lines(s, py, INV, false, b, hxp / tile_y, (int)dim[2]));   // planes z >= Nz are never read
+        MVSIM_TRY(launch_lines(s, py, INV, false, b, hxp / tile_y, zdirect ? nzo : (int)dim[2]));   // planes z >= Nz are never read
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
         const float scale = (float)(0.25 / ((double)px * (double)py * (zdirect ? 1.0 : (double)pz)));
         int nblk = 0;

@@ -185,15 +185,17 @@ int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t d
 template <int U, bool WRITE_ROT>
 __global__ __launch_bounds__(64) void k_rotate_attenuate_axis0(const float* __restrict__ in, float* __restrict__ rot_out,
                                                                float* __restrict__ att_out, int nx, int ny, int nz,
-                                                               int steps, Affine a, double delta)
+                                                               int steps, Affine a, double delta, int z_off)
 {
+    // blockIdx.y counts the planes of the OUTPUT buffers, which start at plane z_off of the view (z-slab tiling; 0
+    // for a whole view); the source volume is always the whole ground truth
     const int x = blockIdx.x * 64 + threadIdx.x;
-    const int z = blockIdx.y;
+    const int z = blockIdx.y + z_off;
     if (x >= nx) return;
     const long long row = (long long)nx;
     const long long plane = row * ny;
-    float* __restrict__ patt = att_out + plane * z + x;
-    float* __restrict__ prot = WRITE_ROT ? rot_out + plane * z + x : nullptr;
+    float* __restrict__ patt = att_out + plane * blockIdx.y + x;
+    float* __restrict__ prot = WRITE_ROT ? rot_out + plane * blockIdx.y + x : nullptr;
     const float* __restrict__ pin = in + x;
     const double l2 = (double)z;
     double n = 1.0;
@@ -273,6 +275,13 @@ __global__ __launch_bounds__(64) void k_rotate_attenuate_axis0(const float* __re
 int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
                             const Affine& inv, double delta, bool* fused)
 {
+    return launch_rotate_attenuate_planes(s, in, rot_or_null, att, dim, inv, delta, 0, (int)dim[2], fused);
+}
+
+// planes [z_begin, z_begin + z_count) of the view into buffers that start at plane z_begin
+int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
+                                   const Affine& inv, double delta, int z_begin, int z_count, bool* fused)
+{
     const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
     const bool x_identity = inv.m[0] == 1.0 && inv.m[1] == 0.0 && inv.m[2] == 0.0 && inv.m[3] == 0.0 &&
                             inv.m[4] == 0.0 && inv.m[8] == 0.0;
@@ -281,11 +290,11 @@ int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, 
     (void)al;
     *fused = x_identity && !getenv("MVSIM_NO_FUSED_ROTATE");
     if (!*fused) return MVSIM_OK;
-    dim3 grid((nx + 63) / 64, nz);
+    dim3 grid((nx + 63) / 64, z_count);
     if (rot_or_null)
-        hipLaunchKernelGGL((k_rotate_attenuate_axis0<8, true>), grid, dim3(64), 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta);
+        hipLaunchKernelGGL((k_rotate_attenuate_axis0<8, true>), grid, dim3(64), 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin);
     else
-        hipLaunchKernelGGL((k_rotate_attenuate_axis0<8, false>), grid, dim3(64), 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta);
+        hipLaunchKernelGGL((k_rotate_attenuate_axis0<8, false>), grid, dim3(64), 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }

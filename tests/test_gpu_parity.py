@@ -625,6 +625,69 @@ def test_view_with_fft_z_pass_is_a_valid_view(ctx, orc, synth, env_override):
     assert (a["acq"] != b["acq"]).mean() < 0.02
 
 
+# ------------------------------------------------------------------------------------------------ z-slab tiling
+@pytest.mark.parametrize("n,kz,inc,nslabs", [(64, 9, 1, 2), (72, 15, 3, 3), (48, 31, 2, 4), (40, 5, 4, 5)])
+def test_view_slab_tiling_matches_the_whole_view(mvs, synth, n, kz, inc, nslabs):
+    """One view split into z slabs, one context per slab as one GPU per rank would have it: rotate and
+    attenuate recompute the halo, the mirror boundary acts at the global faces only, the adjustImage sum is the only
+    exchange, Poisson counters are global -- the stitched acquisition equals the untiled one."""
+    gt = synth.sphere_phantom(n)
+    psf = synth.gaussian_psf(7, 9, kz, sigma=(1.3, 1.5, max(1.0, kz / 5)))
+    dims = (n, n, n)
+    nzo = (n - 1) // inc + 1
+    with mvs.Context(0) as whole:
+        p = whole.view_params(degrees=50, delta=0.01, inc=inc, snr=25.0, seed=SEED, stream=5, conv_method=1)
+        ref = whole.simulate_view(gt, psf.copy(), p, want=("con", "acq"))
+        ref_noise_free = whole.simulate_view(gt, psf.copy(), whole.view_params(degrees=50, delta=0.01, inc=inc, snr=-1.0,
+                                                                              conv_method=1), want=("acq",))["acq"]
+    ctxs = [mvs.Context(0) for _ in range(nslabs)]
+    try:
+        ranges = [ctxs[0].slab_range(n, nslabs, r) for r in range(nslabs)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        d_gt = [_dev_volume(c, gt) for c in ctxs]                      # every "rank" holds the broadcast ground truth
+        sums = [c.view_slab_convolve_dev(d, dims, psf.copy(), p, z0, z1) for c, d, (z0, z1) in zip(ctxs, d_gt, ranges)]
+        total = float(np.sum(np.array(sums, dtype=np.float64)))       # what the all-reduce delivers
+        for noise in (False, True):
+            pp = p if noise else ctxs[0].view_params(degrees=50, delta=0.01, inc=inc, snr=-1.0, conv_method=1)
+            parts = []
+            for c, (z0, z1) in zip(ctxs, ranges):
+                d_acq = c.dev_alloc(max(1, ((z1 - z0) // inc + 2)) * n * n * 4)
+                try:
+                    k = c.view_slab_finish_dev(dims, pp, z0, z1, total, d_acq)
+                    parts.append(c.download(d_acq, (k, n, n)) if k else np.zeros((0, n, n), np.float32))
+                finally:
+                    c.dev_free(d_acq)
+            got = np.concatenate(parts, axis=0)
+            assert got.shape == (nzo, n, n)
+            if not noise:
+                # same per-plane transforms, same z taps in the same order: only the order of the global sum differs
+                assert rel_to_max(got, ref_noise_free) <= 1e-6
+            else:
+                assert np.all(got == np.round(got))
+                assert (got != ref["acq"]).mean() < 0.005
+                assert abs(got.mean() / ref["acq"].mean() - 1) < 1e-3
+        for c, d in zip(ctxs, d_gt):
+            c.dev_free(d)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_view_slab_rejects_what_it_cannot_tile(ctx, synth):
+    gt = synth.sphere_phantom(32)
+    d = _dev_volume(ctx, gt)
+    try:
+        p = ctx.view_params(degrees=10, inc=1, snr=25.0)
+        with pytest.raises(ValueError):
+            ctx.view_slab_convolve_dev(d, (32, 32, 32), synth.gaussian_psf(5), p, 8, 8)                 # empty slab
+        with pytest.raises(ValueError):
+            ctx.view_slab_convolve_dev(d, (32, 32, 32), synth.gaussian_psf(5, 5, 71), p, 0, 16)         # PSF too deep
+        with pytest.raises(ValueError):
+            ctx.view_slab_convolve_dev(d, (32, 32, 32), synth.gaussian_psf(5), ctx.view_params(axis=1), 0, 16)
+    finally:
+        ctx.dev_free(d)
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE configs[3], [4]
 def _window_volume(nz, ny, nx):
     """Compactly supported, non-separable enough: product of (1 - t^2)^2 windows plus a few isolated bright voxels."""

@@ -178,3 +178,20 @@ def test_make_square(mvs):
     assert np.all(sq[mask] == 1.0)
     cube = np.ones((4, 4, 4), np.float32)
     assert np.array_equal(mvs.Tools.makeSquare(cube), cube)
+
+
+def test_slab_range_partitions_the_planes(mvs):
+    """mvsim_slab_range (host only): contiguous, balanced, covering partition of [0, Nz)."""
+    L = importlib.import_module("multiview-simulation_amd._lib").load()
+    for nz, ranks in ((1024, 8), (513, 4), (7, 3), (5, 5), (100, 1)):
+        edges = []
+        for r in range(ranks):
+            z0, z1 = ctypes.c_int64(), ctypes.c_int64()
+            assert L.mvsim_slab_range(nz, ranks, r, ctypes.byref(z0), ctypes.byref(z1)) == 0
+            edges.append((z0.value, z1.value))
+        assert edges[0][0] == 0 and edges[-1][1] == nz
+        assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+        sizes = [b - a for a, b in edges]
+        assert max(sizes) - min(sizes) <= 1
+    z0, z1 = ctypes.c_int64(), ctypes.c_int64()
+    assert L.mvsim_slab_range(10, 2, 2, ctypes.byref(z0), ctypes.byref(z1)) != 0
