@@ -63,6 +63,10 @@ int  mvsim_dev_alloc(mvsim_ctx* ctx, size_t bytes, void** dptr);
 int  mvsim_dev_free(mvsim_ctx* ctx, void* dptr);
 int  mvsim_upload(mvsim_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  mvsim_download(mvsim_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Page-locked host memory for the host-buffer entry points: transfers from/to such blocks run at PCIe speed (the
+ * JNI shim hands them to Java as direct ByteBuffers).  Ordinary pageable buffers work everywhere too, just slower. */
+int  mvsim_host_alloc(mvsim_ctx* ctx, size_t bytes, void** hptr);
+int  mvsim_host_free(mvsim_ctx* ctx_or_null, void* hptr);
 /* byte-wise fill, asynchronous on the context stream (e.g. the zero canvas of the phantom generator) */
 int  mvsim_dev_memset(mvsim_ctx* ctx, void* dptr, int value, size_t bytes);
 

@@ -134,6 +134,18 @@ JNIEXPORT void JNICALL JNI_FN(axisRotation)(JNIEnv* env, jclass, jlongArray dim,
     env->SetDoubleArrayRegion(m12, 0, 12, m);
 }
 
+JNIEXPORT jobject JNICALL JNI_FN(allocPinned)(JNIEnv* env, jclass, jlong h, jlong bytes)
+{
+    void* p = nullptr;
+    if (mvsim_host_alloc(ctx_of(h), static_cast<size_t>(bytes), &p) != MVSIM_OK || !p) return nullptr;
+    return env->NewDirectByteBuffer(p, bytes);
+}
+
+JNIEXPORT void JNICALL JNI_FN(freePinned)(JNIEnv* env, jclass, jobject block)
+{
+    if (block) (void)mvsim_host_free(nullptr, env->GetDirectBufferAddress(block));
+}
+
 JNIEXPORT jlong JNICALL JNI_FN(drawSpheres)(JNIEnv* env, jclass, jlong h, jobject img, jlongArray dim, jdouble min_value,
                                             jdouble max_value, jint scale, jboolean half_pixel_offset, jlongArray rnd_state)
 {

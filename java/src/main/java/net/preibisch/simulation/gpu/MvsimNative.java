@@ -31,6 +31,10 @@ final class MvsimNative
 	static native void computeWeightImage( long ctx, long[] dim, FloatBuffer out );
 	static native void axisRotation( long[] dim, int axis, int degrees, double[] m12 );
 
+	/** mvsim_host_alloc wrapped by NewDirectByteBuffer: a page-locked block (null if the allocation fails); freePinned releases it. */
+	static native java.nio.ByteBuffer allocPinned( long ctx, long bytes );
+	static native void freePinned( java.nio.ByteBuffer block );
+
 	/** drawSpheres (:436-522), in place; rndState[0] is the 48-bit java.util.Random state, advanced on return; returns the sphere count. */
 	static native long drawSpheres( long ctx, FloatBuffer img, long[] dim, double minValue, double maxValue, int scale,
 			boolean halfPixelOffset, long[] rndState );

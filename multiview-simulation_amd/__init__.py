@@ -155,6 +155,28 @@ class Context:
     def dev_free(self, dptr: int) -> None:
         _lib.check(self._L.mvsim_dev_free(self._h, C.c_void_p(dptr)))
 
+    def pinned_empty(self, shape, dtype=np.float32) -> np.ndarray:
+        """A numpy array in page-locked host memory (PCIe-speed transfers for the host-buffer entry points).  The
+        block is freed when the array -- and every view of it -- is garbage collected."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        _lib.check(self._L.mvsim_host_alloc(self._h, max(1, n * dt.itemsize), C.byref(p)))
+        L, addr = self._L, p.value
+
+        class _Block(C.Array):
+            _type_ = C.c_char
+            _length_ = max(1, n * dt.itemsize)
+
+            def __del__(self):
+                try:
+                    L.mvsim_host_free(None, C.c_void_p(addr))      # no context needed: arrays may outlive it
+                except Exception:
+                    pass
+
+        blk = _Block.from_address(addr)
+        return np.frombuffer(blk, dtype=dt, count=n).reshape(shape)
+
     def upload(self, dptr: int, host: np.ndarray) -> None:
         host = np.ascontiguousarray(host)
         _lib.check(self._L.mvsim_upload(self._h, C.c_void_p(dptr), _ptr(host), host.nbytes))
@@ -307,19 +329,29 @@ class Context:
             setattr(p, k, v)
         return p
 
-    def simulate_view(self, gt, psf: np.ndarray, params: ViewParams, want=("acq",)) -> dict:
+    def simulate_view(self, gt, psf: np.ndarray, params: ViewParams, want=("acq",), out: dict | None = None) -> dict:
         """Host buffers in/out.  ``want`` is a subset of {'rot','att','con','acq'}; returns a dict with the
-        requested stages plus 'corr'.  ``psf`` is normalised in place (reference behaviour)."""
+        requested stages plus 'corr'.  ``psf`` is normalised in place (reference behaviour).  ``out`` may carry
+        preallocated destination arrays by stage name -- e.g. page-locked ones from pinned_empty, which (with a
+        pinned ``gt``) make the transfers run at PCIe speed; allocate them once, page-locking is slow."""
         v = _as_volume(gt, "ground truth")
         _check_inplace(psf, "psf")
         nz, ny, nx = v.shape
         res = {}
         o = ViewOutputs()
+
+        def alloc(name, shape):
+            a = (out or {}).get(name)
+            if a is None:
+                return np.empty(shape, dtype=np.float32)
+            if a.shape != tuple(shape) or a.dtype != np.float32 or not a.flags.c_contiguous:
+                raise ValueError(f"out[{name!r}] must be a contiguous float32 array of shape {tuple(shape)}")
+            return a
         for name in ("rot", "att", "con"):
             if name in want:
-                res[name] = np.empty_like(v)
+                res[name] = alloc(name, v.shape)
                 setattr(o, name, res[name].ctypes.data)
-        res["acq"] = np.empty((self._L.mvsim_extract_nz(nz, params.inc), ny, nx), dtype=np.float32)
+        res["acq"] = alloc("acq", (self._L.mvsim_extract_nz(nz, params.inc), ny, nx))
         o.acq = res["acq"].ctypes.data
         corr = C.c_double()
         _lib.check(self._L.mvsim_simulate_view(self._h, _ptr(v), _dim(v), _ptr(psf), _dim(psf), C.byref(params),

@@ -61,6 +61,8 @@ SIGNATURES = {
     "mvsim_dev_free": (C.c_int, [_vp, _vp]),
     "mvsim_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "mvsim_dev_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
+    "mvsim_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mvsim_host_free": (C.c_int, [_vp, _vp]),
     "mvsim_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "mvsim_axis_rotation": (C.c_int, [_i64p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mvsim_extract_nz": (C.c_int64, [C.c_int64, C.c_int]),

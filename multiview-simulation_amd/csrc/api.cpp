@@ -251,6 +251,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
     ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release();
+    ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
         for (int k = 0; k < mvsim_ctx::TIMING_SLOTS; ++k)
@@ -297,6 +298,30 @@ int mvsim_dev_free(mvsim_ctx* ctx, void* dptr)
 {
     MVSIM_TRY(set_device(ctx));
     if (dptr) MVSIM_HIP(hipFree(dptr));
+    return MVSIM_OK;
+}
+
+// Page-locked host memory: copies between it and HBM run at PCIe speed instead of through the runtime's staging of
+// pageable memory.  The JNI shim wraps such blocks in direct ByteBuffers (NewDirectByteBuffer), numpy wraps them through
+// the buffer protocol.
+int mvsim_host_alloc(mvsim_ctx* ctx, size_t bytes, void** hptr)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(hptr != nullptr, "hptr is null");
+    *hptr = nullptr;
+    if (bytes == 0) return MVSIM_OK;
+    hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? MVSIM_ENOMEM : MVSIM_EHIP;
+    }
+    return MVSIM_OK;
+}
+
+int mvsim_host_free(mvsim_ctx* ctx, void* hptr)
+{
+    if (ctx) MVSIM_TRY(set_device(ctx));               // ctx may be NULL: blocks can outlive their context
+    if (hptr) MVSIM_HIP(hipHostFree(hptr));
     return MVSIM_OK;
 }
 
@@ -838,8 +863,9 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], f
     const int64_t n = nvox(dim);
     const size_t vbytes = (size_t)n * sizeof(float);
     const size_t obytes = (size_t)(dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc)) * sizeof(float);
-    // ground truth goes to its own buffer; requested intermediates get device twins
-    DevBuf gt_d, rot_d, att_d, con_d;
+    // ground truth goes to its own buffer; requested intermediates get device twins (kept by the context: a driver
+    // that calls this once per view must not pay a 0.5 GB hipMalloc/hipFree pair per buffer and call)
+    DevBuf &gt_d = ctx->host_gt, &rot_d = ctx->host_rot, &att_d = ctx->host_att, &con_d = ctx->host_con;
     int rc = up(ctx, gt_d, gt, vbytes);
     mvsim_view_outputs dev = {nullptr, nullptr, nullptr, nullptr};
     if (rc == MVSIM_OK && o->rot) { rc = rot_d.reserve(vbytes); dev.rot = rot_d.as<float>(); }
@@ -853,7 +879,6 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], f
     if (rc == MVSIM_OK && o->con) rc = down(ctx, o->con, dev.con, vbytes);
     if (rc == MVSIM_OK) rc = down(ctx, o->acq, dev.acq, obytes);
     (void)hipStreamSynchronize(ctx->stream);
-    gt_d.release(); rot_d.release(); att_d.release(); con_d.release();
     return rc;
 }
 

@@ -105,6 +105,7 @@ struct mvsim_ctx {
     mvsim::DevBuf fft_work;
     mvsim::DevBuf pqueue;                   // Poisson work queue: [count][items]
     mvsim::DevBuf sphere_list;              // phantom generator: (centre, radius, value) items
+    mvsim::DevBuf host_gt, host_rot, host_att, host_con;   // device twins of the host-buffer simulate_view (grow-only)
     mvsim::DevBuf partials;                 // doubles: block partial sums + [sum, corr]
     mvsim::DevBuf partials_e;               // per-block sums of the c2r/crop pass
     mvsim::DevBuf cfft_f, cfft_g;           // custom FFT: image / PSF half spectra [Pz][Py][Hxp]

@@ -625,6 +625,28 @@ def test_view_with_fft_z_pass_is_a_valid_view(ctx, orc, synth, env_override):
     assert (a["acq"] != b["acq"]).mean() < 0.02
 
 
+def test_page_locked_buffers_and_preallocated_outputs(ctx, synth):
+    """mvsim_host_alloc blocks as numpy arrays: same results as pageable buffers; `out=` reuses destinations."""
+    gt = synth.sphere_phantom(40)
+    psf = synth.gaussian_psf(7, sigma=(1.1, 1.2, 1.8))
+    p = ctx.view_params(degrees=25, inc=2, snr=25.0, seed=SEED, stream=1)
+    ref = ctx.simulate_view(gt, psf.copy(), p, want=("con", "acq"))
+    g = ctx.pinned_empty(gt.shape)
+    g[...] = gt
+    dst = {"acq": ctx.pinned_empty(ref["acq"].shape), "con": ctx.pinned_empty(gt.shape)}
+    for _ in range(2):
+        got = ctx.simulate_view(g, psf.copy(), p, want=("con", "acq"), out=dst)
+        assert got["acq"] is dst["acq"] and got["con"] is dst["con"]
+        assert np.array_equal(got["acq"], ref["acq"]) and np.array_equal(got["con"], ref["con"])
+    with pytest.raises(ValueError):
+        ctx.simulate_view(g, psf.copy(), p, out={"acq": np.empty((3, 3, 3), np.float32)})
+    view = dst["acq"][1:3]            # a view keeps the block alive after the owner is dropped
+    del dst, got
+    import gc
+    gc.collect()
+    assert np.array_equal(view, ref["acq"][1:3])
+
+
 # ------------------------------------------------------------------------------------------------ z-slab tiling
 @pytest.mark.parametrize("n,kz,inc,nslabs", [(64, 9, 1, 2), (72, 15, 3, 3), (48, 31, 2, 4), (40, 5, 4, 5)])
 def test_view_slab_tiling_matches_the_whole_view(mvs, synth, n, kz, inc, nslabs):
