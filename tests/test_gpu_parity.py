@@ -604,6 +604,20 @@ def test_convolve_fft_z_pass_and_rocfft_fallback_agree(ctx, orc, env_override, s
     assert rel_to_max(direct, zfft) <= 2e-6 and rel_to_max(direct, roc) <= 2e-6
 
 
+@pytest.mark.parametrize("shape,kshape", [((17, 20, 24), (2, 3, 4)), ((5, 6, 7), (1, 1, 1)), ((70, 18, 22), (64, 3, 3)),
+                                          ((16, 21, 19), (33, 5, 5)), ((3, 9, 40), (7, 4, 6)), ((257, 10, 12), (9, 1, 2))])
+def test_direct_z_pass_odd_geometries(ctx, orc, shape, kshape):
+    """Direct z pass at its edges: even PSF sizes (centre K/2), single planes, 64 taps, a halo longer than the volume
+    (repeated reflections), plane counts that do not fill the last tile."""
+    rng = np.random.default_rng(sum(shape) + sum(kshape))
+    v = rng.random(shape, dtype=np.float32)
+    psf = rng.random(kshape, dtype=np.float32) + 0.05
+    got = ctx.convolve(v, psf.copy(), method=1)
+    assert rel_to_max(got, orc.convolve_fft(v, psf.copy())) <= CONV_TOL
+    if np.prod(shape) * np.prod(kshape) < 4e8:
+        assert rel_to_max(got, orc.convolve_direct(v, psf.copy())) <= CONV_TOL
+
+
 def test_convolve_deep_psf_takes_the_fft_z_pass(ctx, orc, synth):
     """Kz > 64 taps: the direct z pass is not offered, the FFT z pass runs (and agrees with the oracle)."""
     v = synth.sphere_phantom(72)
