@@ -661,6 +661,16 @@ def test_page_locked_buffers_and_preallocated_outputs(ctx, synth):
     assert np.array_equal(view, ref["acq"][1:3])
 
 
+@pytest.mark.gpu
+def test_c_abi_plain_c_consumer_runs(tmp_path):
+    """tests/c_abi/smoke.c: a C99 program drives a whole view through the C ABI, no Python or torch in the process."""
+    import subprocess
+    from .test_host_logic import _build_c_smoke
+    r = subprocess.run([_build_c_smoke(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c-abi smoke ok" in r.stdout
+
+
 # ------------------------------------------------------------------------------------------------ z-slab tiling
 @pytest.mark.parametrize("n,kz,inc,nslabs", [(64, 9, 1, 2), (72, 15, 3, 3), (48, 31, 2, 4), (40, 5, 4, 5)])
 def test_view_slab_tiling_matches_the_whole_view(mvs, synth, n, kz, inc, nslabs):

@@ -195,3 +195,30 @@ def test_slab_range_partitions_the_planes(mvs):
         assert max(sizes) - min(sizes) <= 1
     z0, z1 = ctypes.c_int64(), ctypes.c_int64()
     assert L.mvsim_slab_range(10, 2, 2, ctypes.byref(z0), ctypes.byref(z1)) != 0
+
+
+# ------------------------------------------------------------------------------------------------ plain-C consumer
+def _build_c_smoke(tmp_path):
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "multiview-simulation_amd")
+    exe = str(tmp_path / "c_abi_smoke")
+    cmd = [shutil.which("gcc") or "gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "tests", "c_abi", "smoke.c"), "-L" + pkg, "-lmvsim", "-Wl,-rpath," + pkg,
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lm", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_c_abi_compiles_as_plain_c_and_fails_loudly_without_gpu(tmp_path):
+    """include/mvsim.h is a C header (gcc -std=c99 -Werror), the library links without Python or torch, and a host
+    without a GPU gets MVSIM_ENODEV -- not a CPU fallback."""
+    import subprocess
+    import torch
+    exe = _build_c_smoke(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr
+    else:
+        assert r.returncode == 3 and "no HIP device" in r.stderr
