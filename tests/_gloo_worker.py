@@ -31,10 +31,20 @@ def main():
     uid = [bytes(range(128))] if rank == 0 else [None]
     dist.broadcast_object_list(uid, src=0)
 
+    # z-slab tiling of one view (mvsim_slab_range is host-only): every rank's slab, and the one-double exchange that
+    # adjustImage needs -- here the "slab sum" is the sum of the rank's planes of the broadcast volume
+    import ctypes
+    L = importlib.import_module("multiview-simulation_amd._lib").load()
+    z0, z1 = ctypes.c_int64(), ctypes.c_int64()
+    assert L.mvsim_slab_range(16, world, rank, ctypes.byref(z0), ctypes.byref(z1)) == 0
+    slab_sum = torch.tensor([float(gt.reshape(16, 16, 16)[z0.value:z1.value].double().sum())], dtype=torch.float64)
+    dist.all_reduce(slab_sum)
+
     # every rank reports its shard; the union must be a partition of the views
     gathered = [None] * world
     dist.all_gather_object(gathered, {"rank": rank, "views": mine, "angles": [angles[v] for v in mine],
-                                      "gt_sum": float(gt.double().sum()), "uid_len": len(uid[0])})
+                                      "gt_sum": float(gt.double().sum()), "uid_len": len(uid[0]),
+                                      "slab": [z0.value, z1.value], "slab_total": float(slab_sum.item())})
     # max-over-ranks timing reduction as bench.py does it
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -25,6 +25,9 @@ def test_two_rank_sharding_and_broadcast(tmp_path):
     assert g[0]["views"] == list(range(0, 16, 2)) and g[1]["views"] == list(range(1, 16, 2))
     assert len(g[0]["views"]) == len(g[1]["views"]) == 8           # weak scaling: 8 views per rank
     assert g[0]["gt_sum"] == g[1]["gt_sum"] and g[0]["gt_sum"] > 0  # broadcast delivered the same volume
+    # z slabs of one view partition the planes; the all-reduced slab sums equal the sum of the whole volume
+    assert g[0]["slab"][0] == 0 and g[0]["slab"][1] == g[1]["slab"][0] and g[1]["slab"][1] == 16
+    assert g[0]["slab_total"] == g[1]["slab_total"] and abs(g[0]["slab_total"] / g[0]["gt_sum"] - 1) < 1e-12
     assert g[0]["uid_len"] == g[1]["uid_len"] == 128
     assert res["tmax"] == 2.0
     angs = sorted(a for d in g for a in d["angles"])
