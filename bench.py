@@ -91,6 +91,9 @@ def cpu_baseline(gt: np.ndarray, psf_raw: np.ndarray, degrees: int, inc: int, sn
     vox = sub.size
     return {
         "value": vox / total / 1e6, "unit": "Mvoxel/s", "cores": os.cpu_count(), "kind": "port",
+        # the reference's own threading: only FFTConvolution gets the executor service (SMVD:257,527), every other
+        # stage -- the Poisson loop that dominates included -- is a single-threaded cursor loop
+        "threads": {"convolve_fft": os.cpu_count(), "rotate": 1, "attenuate": 1, "adjust": 1, "extract_poisson": 1},
         "sample": (f"{sub.shape[2]}x{sub.shape[1]}x{slab} z-slab of the same view, {psf_raw.shape[0]}^3 PSF; "
                    f"single-threaded C restatement except scipy float32 FFT convolution on all cores; "
                    f"reference-exact Poisson timed on {nsl} slices and scaled to {n_extract}"),
