@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line (schema in the task contract) including
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import importlib
 import json
 import os
@@ -294,6 +295,20 @@ def main():
                 "extract_poisson": "extract stage = k_extract4_noise + k_poisson_resolve",
                 "rotate_attenuate": "k_rotate_attenuate_axis0",
             }
+            # the five passes of the convolution, each against ITS OWN compulsory traffic (read its input once, write its
+            # output once): HIP events nested inside the convolve stage, same timed region
+            passes = None
+            geo = (C.c_int64 * 5)()
+            if args.conv_method == 1 and mvs._lib.load().mvsim_fft_geometry((C.c_int64 * 3)(n, n, n), (C.c_int64 * 3)(args.psf, args.psf, args.psf), geo) == 0:
+                px, py_, planes, hxp, zdirect = (int(v) for v in geo)
+                cplx = 8 * hxp * py_ * planes
+                pb = {"A k_fft_x_r2c": (4 * nvox + cplx, stage["pass_a_ms"]),
+                      "B k_fft_lines<FWD>": (2 * cplx, stage["pass_b_ms"]),
+                      ("C k_zconv" if zdirect else "C k_fft_lines<CONV>"): (2 * cplx + (0 if zdirect else cplx), stage["pass_c_ms"]),
+                      "D k_fft_lines<INV>": (2 * cplx, stage["pass_d_ms"]),
+                      "E k_fft_x_c2r": (cplx + 4 * nvox, stage["pass_e_ms"])}
+                passes = {k: {"bytes": b, "ms": round(t, 4), "GBps": b / (t * 1e-3) / 1e9, "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                          for k, (b, t) in pb.items() if t > 0}
             out["roofline"] = {
                 "bound": "hbm", "kernel": names[dom],
                 "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stages[dom]["frac"],
@@ -306,6 +321,7 @@ def main():
                                "frac": b_view / (stage["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "convolve_noise": {"bytes": b_cn, "ms": cn_ms, "frac": b_cn / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+                "passes": passes,
             }
         if not args.no_cpu_baseline:
             try:

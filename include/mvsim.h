@@ -192,7 +192,14 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3],
 /* ---- per-stage device timings of the last simulate_view / stage call (milliseconds) ------ */
 typedef struct mvsim_timings {
     float rotate_ms, attenuate_ms, psf_ms, convolve_ms, adjust_ms, extract_ms, total_ms;
+    /* the passes of the hand-written convolution, nested inside convolve_ms (0 on other paths): x real->complex,
+     * y forward, z (direct convolution or FFT + product + inverse FFT), y inverse, x complex->real + crop + sum */
+    float pass_a_ms, pass_b_ms, pass_c_ms, pass_d_ms, pass_e_ms;
 } mvsim_timings;
+/* Geometry of the hand-written convolution for this volume / PSF: {Px, Py, planes of the spectrum, Hxp (complex row
+ * pitch), 1 if the z pass is the direct convolution}.  A pass moves 8 * Hxp * Py * planes bytes each way (the x passes
+ * 4 N on their real side).  MVSIM_EINVAL when the sizes fall outside the pass table (rocFFT path). */
+int mvsim_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t geometry[5]);
 int mvsim_enable_timing(mvsim_ctx* ctx, int enable);
 int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t);
 

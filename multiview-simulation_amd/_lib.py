@@ -38,7 +38,8 @@ class ViewOutputs(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in
-                ("rotate_ms", "attenuate_ms", "psf_ms", "convolve_ms", "adjust_ms", "extract_ms", "total_ms")]
+                ("rotate_ms", "attenuate_ms", "psf_ms", "convolve_ms", "adjust_ms", "extract_ms", "total_ms",
+                 "pass_a_ms", "pass_b_ms", "pass_c_ms", "pass_d_ms", "pass_e_ms")]
 
     def as_dict(self):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
@@ -98,6 +99,7 @@ SIGNATURES = {
                                           C.POINTER(ViewOutputs), C.POINTER(C.c_double)]),
     "mvsim_simulate_view": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams),
                                       C.POINTER(ViewOutputs), C.POINTER(C.c_double)]),
+    "mvsim_fft_geometry": (C.c_int, [_i64p, _i64p, _i64p]),
     "mvsim_enable_timing": (C.c_int, [_vp, C.c_int]),
     "mvsim_get_timings": (C.c_int, [_vp, C.POINTER(Timings)]),
     "mvsim_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),

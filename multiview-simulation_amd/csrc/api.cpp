@@ -882,6 +882,17 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], f
     return rc;
 }
 
+int mvsim_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t geometry[5])
+{
+    if (!dim || !kdim || !geometry) { set_error("invalid argument: null pointer"); return MVSIM_EINVAL; }
+    MVSIM_TRY(check_dim(dim));
+    if (!custom_fft_geometry(dim, kdim, geometry)) {
+        set_error("no hand-written FFT size for this volume / PSF");
+        return MVSIM_EINVAL;
+    }
+    return MVSIM_OK;
+}
+
 // ---- timings ---------------------------------------------------------------------------------------
 int mvsim_enable_timing(mvsim_ctx* ctx, int enable)
 {
@@ -925,10 +936,15 @@ int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t)
     }
     float ms[ST_COUNT];
     float total = 0.f;
-    for (int s = 0; s < ST_COUNT; ++s) { ms[s] = cnt[s] ? (float)(sum[s] / cnt[s]) : 0.f; total += ms[s]; }
+    for (int s = 0; s < ST_COUNT; ++s) {
+        ms[s] = cnt[s] ? (float)(sum[s] / cnt[s]) : 0.f;
+        if (s < ST_PASS_A) total += ms[s];              // the passes are nested inside ST_CONVOLVE
+    }
     t->rotate_ms = ms[ST_ROTATE]; t->attenuate_ms = ms[ST_ATTENUATE]; t->psf_ms = ms[ST_PSF];
     t->convolve_ms = ms[ST_CONVOLVE]; t->adjust_ms = ms[ST_ADJUST]; t->extract_ms = ms[ST_EXTRACT];
     t->total_ms = total;
+    t->pass_a_ms = ms[ST_PASS_A]; t->pass_b_ms = ms[ST_PASS_B]; t->pass_c_ms = ms[ST_PASS_C];
+    t->pass_d_ms = ms[ST_PASS_D]; t->pass_e_ms = ms[ST_PASS_E];
     ctx->last = *t;
     ctx->ev_cur = 0;
     ctx->ev_calls = 0;

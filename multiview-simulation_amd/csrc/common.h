@@ -85,7 +85,9 @@ struct PinnedRing {
     void release_all();
 };
 
-enum Stage { ST_ROTATE = 0, ST_ATTENUATE, ST_PSF, ST_CONVOLVE, ST_ADJUST, ST_EXTRACT, ST_COUNT };
+// ST_PASS_*: the five passes of the hand-written convolution, nested inside ST_CONVOLVE (not part of the stage sum)
+enum Stage { ST_ROTATE = 0, ST_ATTENUATE, ST_PSF, ST_CONVOLVE, ST_ADJUST, ST_EXTRACT, ST_PASS_A, ST_PASS_B, ST_PASS_C, ST_PASS_D,
+             ST_PASS_E, ST_COUNT };
 
 }  // namespace mvsim
 
@@ -189,6 +191,7 @@ struct SlabRange {
 int  custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                               const int64_t kdim[3], const int64_t P[3], const SlabRange& slab, float* out);
 void custom_fft_release(mvsim_ctx* ctx);
+bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[5]);
 
 // stage timing helpers (events are recorded on the stream the kernels run on)
 inline void ev_begin(mvsim_ctx* ctx, int st)

@@ -1142,6 +1142,24 @@ void custom_fft_release(mvsim_ctx* ctx)
     ctx->cfft_g2.release();
 }
 
+// {Px, Py, Pz, Hxp, direct z pass?} of the hand-written path for this volume / PSF (what the passes move through HBM)
+bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[5])
+{
+    using namespace fft;
+    int64_t P[3];
+    if (!custom_fft_sizes(dim, kdim, P)) return false;
+    bool zdirect = kdim[2] <= 64;
+    if (const char* e = getenv("MVSIM_FFT_ZPASS")) zdirect = std::strcmp(e, "fft") == 0 ? false : (std::strcmp(e, "direct") == 0 ? true : zdirect);
+    const int tile_y = lines_per_tile((int)P[1]), tile_z = lines_per_tile((int)P[2]);
+    int tw_max = tile_y > tile_z ? tile_y : tile_z;
+    if (zdirect) tw_max = tile_y > NLZ ? tile_y : NLZ;
+    const int M = (int)(P[0] / 2);
+    g[0] = P[0]; g[1] = P[1]; g[2] = zdirect ? dim[2] : P[2];
+    g[3] = ((M + 1 + tw_max - 1) / tw_max) * tw_max;
+    g[4] = zdirect ? 1 : 0;
+    return true;
+}
+
 int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                         const int64_t kdim[3], const int64_t P[3], float* out)
 {
@@ -1239,7 +1257,9 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             *dm[d] = DimMap{n[d], Pd[d], n[d] + c, left, 0, 0};
         }
         if (zdirect) m.z = DimMap{nzs, nzs, nzs, 0, 0, 0};           // no z padding: k_zconv mirrors through an index map
+        ev_begin(ctx, ST_PASS_A);
         MVSIM_TRY(launch_r2c(s, M, img, m, F, tw_m, tw_px, hxp, zdirect ? (long long)py * nzs : rows_all));
+        ev_end(ctx, ST_PASS_A);
         // zero gap of the padded volume: y in [Ny + cy, Py - lefty), z in [Nz + cz, Pz - leftz).  Pass A does not
         // transform (or write) rows there, pass B skips the gap planes and does not load gap rows, pass C does
         // not load gap planes.
@@ -1250,7 +1270,10 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         b.gap_lo = ygap_lo; b.gap_hi = ygap_hi;
         b.outer_skip_lo = zgap_lo; b.outer_skip_len = zgap_hi > zgap_lo ? zgap_hi - zgap_lo : 0;
         if (zdirect) { b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0; }
+        ev_begin(ctx, ST_PASS_B);
         MVSIM_TRY(launch_lines(s, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
+        ev_end(ctx, ST_PASS_B);
+        ev_begin(ctx, ST_PASS_C);
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
         float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
         if (zdirect) {
@@ -1270,10 +1293,14 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         c.store_limit = (int)dim[2];                                  // pass D only reads planes z < Nz
         MVSIM_TRY(launch_lines(s, pz, CONV, false, c, hxp / tile_z, py));
         }
+        ev_end(ctx, ST_PASS_C);
         b.src = b.dst = Fz;
         b.tw = tw_py;
         b.store_limit = (int)dim[1];                                  // pass E only reads rows y < Ny
+        ev_begin(ctx, ST_PASS_D);
         MVSIM_TRY(launch_lines(s, py, INV, false, b, hxp / tile_y, zdirect ? nzo : (int)dim[2]));   // planes z >= Nz are never read
+        ev_end(ctx, ST_PASS_D);
+        ev_begin(ctx, ST_PASS_E);
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
         const float scale = (float)(0.25 / ((double)px * (double)py * (zdirect ? 1.0 : (double)pz)));
         int nblk = 0;
@@ -1281,6 +1308,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
                              ctx->partials_e.as<double>(), &nblk));
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal);
         MVSIM_HIP(hipGetLastError());
+        ev_end(ctx, ST_PASS_E);
     }
     ev_end(ctx, ST_CONVOLVE);
     return MVSIM_OK;
