@@ -328,9 +328,11 @@ def test_golden_view_fixture(ctx, golden_dir):
     assert rel_to_max(res["con"], g["con"]) <= CONV_TOL
     assert abs(res["corr"] - float(g["corr"])) <= 1e-6 * float(g["corr"])
     assert np.allclose(psf, g["psf_norm"], rtol=0, atol=1e-9)
-    # Poisson is discontinuous in lambda: compare on identical lambda below; here bound the flips (H3)
+    # Poisson is discontinuous in lambda: compare on identical lambda below; here bound the flips (H3).  A flipped
+    # rejection test draws a fresh candidate, so a differing count may differ by a whole Poisson deviation.
     d = np.abs(res["acq"] - g["acq"])
-    assert d.max() <= 2 and np.mean(d > 0) < 5e-3
+    assert np.mean(d > 0) < 5e-3
+    assert np.all(d <= 8.0 * np.sqrt(np.maximum(g["acq"], 1.0)) + 8.0)
 
 
 @pytest.mark.parametrize("method", [1, 2])
