@@ -140,6 +140,13 @@ class Context:
     def set_stream(self, hip_stream: int | None) -> None:
         _lib.check(self._L.mvsim_set_stream(self._h, C.c_void_p(hip_stream or 0)))
 
+    def set_option(self, name: str, value) -> None:
+        """Run-time switch of this context (mvsim_set_option): fft_zpass, fft_backend, fft_pad, fused_rotate,
+        poisson_queue, early_sum, graph."""
+        if isinstance(value, bool):
+            value = "1" if value else "0"
+        _lib.check(self._L.mvsim_set_option(self._h, name.encode(), str(value).encode()))
+
     def synchronize(self) -> None:
         _lib.check(self._L.mvsim_synchronize(self._h))
 

@@ -6,7 +6,9 @@
 #include <algorithm>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace mvsim {
 
@@ -18,6 +20,62 @@ void set_error(const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- run-time switches ------------------------------------------------------------------------------
+int parse_option(Options& o, const char* name, const char* value)
+{
+    if (!name || !value) return MVSIM_EINVAL;
+    const std::string n(name), v(value);
+    auto flag = [&](bool* dst) { if (v == "1" || v == "on" || v == "true") *dst = true; else if (v == "0" || v == "off" || v == "false") *dst = false; else return MVSIM_EINVAL; return MVSIM_OK; };
+    if (n == "fft_zpass") {
+        if (v == "auto") o.zpass = 0; else if (v == "direct") o.zpass = 1; else if (v == "fft") o.zpass = 2; else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
+    if (n == "fft_backend") {
+        if (v == "custom" || v == "auto") o.rocfft = false; else if (v == "rocfft") o.rocfft = true; else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
+    if (n == "fused_rotate") return flag(&o.fused_rotate);
+    if (n == "poisson_queue") return flag(&o.poisson_queue);
+    if (n == "early_sum") return flag(&o.early_sum);
+    if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
+    if (n == "fft_pad") {
+        long long a = 0, b = 0, c = 0;
+        if (v == "auto" || v.empty()) { o.fft_pad[0] = o.fft_pad[1] = o.fft_pad[2] = 0; return MVSIM_OK; }
+        if (sscanf(v.c_str(), "%lld,%lld,%lld", &a, &b, &c) != 3 || a < 0 || b < 0 || c < 0) return MVSIM_EINVAL;
+        o.fft_pad[0] = a; o.fft_pad[1] = b; o.fft_pad[2] = c;
+        return MVSIM_OK;
+    }
+    return MVSIM_EINVAL;
+}
+
+// Process defaults, read from the environment exactly once (MVSIM_FFT_ZPASS=fft|direct, MVSIM_FFT_BACKEND=rocfft,
+// MVSIM_FFT_PAD=px,py,pz, MVSIM_NO_FUSED_ROTATE, MVSIM_POISSON_NOQUEUE, MVSIM_NO_EARLY_SUM, MVSIM_GRAPH).
+const Options& env_options()
+{
+    static Options o;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (const char* e = getenv("MVSIM_FFT_ZPASS")) (void)parse_option(o, "fft_zpass", e);
+        if (const char* e = getenv("MVSIM_FFT_BACKEND")) (void)parse_option(o, "fft_backend", e);
+        if (const char* e = getenv("MVSIM_FFT_PAD")) (void)parse_option(o, "fft_pad", e);
+        if (getenv("MVSIM_NO_FUSED_ROTATE")) o.fused_rotate = false;
+        if (getenv("MVSIM_POISSON_NOQUEUE")) o.poisson_queue = false;
+        if (getenv("MVSIM_NO_EARLY_SUM")) o.early_sum = false;
+        if (const char* e = getenv("MVSIM_GRAPH")) (void)parse_option(o, "graph", e);
+    });
+    return o;
+}
+
+int ensure_lds_attr(mvsim_ctx* ctx, const void* kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return MVSIM_OK;
+    if (bytes > 160 * 1024) { set_error("kernel needs %zu bytes of LDS (> 160 KiB)", bytes); return MVSIM_EINVAL; }
+    if (ctx->lds_attr_set.count(kernel)) return MVSIM_OK;
+    MVSIM_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->lds_attr_set.insert(kernel);
+    return MVSIM_OK;
 }
 
 int DevBuf::reserve(size_t need)
@@ -180,7 +238,7 @@ static int convolve_dev_impl(mvsim_ctx* ctx, const float* img, const int64_t dim
     MVSIM_CHECK_ARG(img != out, "convolve cannot run in place");
     if (pick_method(method, kdim) == 2) {
         ev_begin(ctx, ST_CONVOLVE);
-        MVSIM_TRY(launch_stencil(ctx->stream, img, dim, ctx->psf_dev.as<float>(), kdim, out));
+        MVSIM_TRY(launch_stencil(ctx, img, dim, ctx->psf_dev.as<float>(), kdim, out));
         ev_end(ctx, ST_CONVOLVE);
         return MVSIM_OK;
     }
@@ -235,6 +293,7 @@ int mvsim_create(int device, mvsim_ctx** out)
     if (!ctx) { set_error("out of host memory"); return MVSIM_ENOMEM; }
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
+    ctx->opt = env_options();
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return MVSIM_EHIP; }
     ctx->stream = ctx->own_stream;
@@ -268,6 +327,16 @@ int mvsim_set_stream(mvsim_ctx* ctx, void* hip_stream)
     return MVSIM_OK;
 }
 
+int mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
+    if (parse_option(ctx->opt, name, value) != MVSIM_OK) {
+        set_error("invalid argument: option %s = %s", name ? name : "(null)", value ? value : "(null)");
+        return MVSIM_EINVAL;
+    }
+    return MVSIM_OK;
+}
+
 int mvsim_synchronize(mvsim_ctx* ctx)
 {
     MVSIM_TRY(set_device(ctx));
@@ -281,6 +350,8 @@ int mvsim_release_caches(mvsim_ctx* ctx)
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
+    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->sphere_list.release();
+    ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     return MVSIM_OK;
 }
 
@@ -370,7 +441,7 @@ double  mvsim_poisson_mul(double snr) { return std::pow(snr / std::sqrt(5.0), 2.
 void mvsim_view_params_default(mvsim_view_params* p)
 {
     if (!p) return;
-    p->axis = 0; p->degrees = 15; p->delta = 0.01; p->min_value = 0.0001f; p->target_average = 1.0f;
+    p->axis = 0; p->degrees = 15; p->delta = (double)0.01f /* `final float attenuation = 0.01f` widened, SMVD:533,573 */; p->min_value = 0.0001f; p->target_average = 1.0f;
     p->inc = 3; p->snr = 25.0f; p->seed = 464232194ULL; p->stream = 0; p->conv_method = 0;
 }
 
@@ -446,7 +517,7 @@ int mvsim_extract_slices_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[
     if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(dim[0] * dim[1] * mvsim_extract_nz(dim[2], inc), nullptr))); qws = ctx->pqueue.p; }
     ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, in, out, dim, inc, false, nullptr, 0.0f, noise,
-                             mvsim_poisson_mul((double)snr), seed, stream, 0, qws));
+                             mvsim_poisson_mul((double)snr), seed, stream, 0, qws, ctx->opt.poisson_queue));
     ev_end(ctx, ST_EXTRACT);
     return MVSIM_OK;
 }
@@ -546,7 +617,7 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     // rotation about x: rotate and attenuate run as one kernel and `rot` is written only when requested
     bool fused = false;
     ev_begin(ctx, ST_ROTATE);
-    MVSIM_TRY(launch_rotate_attenuate(ctx->stream, gt, rot, att, dim, inv, p->delta, &fused));
+    MVSIM_TRY(launch_rotate_attenuate(ctx->stream, gt, rot, att, dim, inv, p->delta, ctx->opt.fused_rotate, &fused));
     if (!fused) {
         if (!rot) { MVSIM_TRY(ctx->vol_a.reserve(vbytes)); rot = ctx->vol_a.as<float>(); }
         MVSIM_TRY(launch_rotate(ctx->stream, gt, rot, dim, inv));
@@ -576,7 +647,7 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc), nullptr))); qws = ctx->pqueue.p; }
     ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, con, o->acq, dim, p->inc, !materialise, scal, p->min_value, noise,
-                             mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws));
+                             mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws, ctx->opt.poisson_queue));
     ev_end(ctx, ST_EXTRACT);
 
     if (correction) {
@@ -616,7 +687,7 @@ int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t 
     if (zb > nz) { za = std::min<int64_t>(za, std::max<int64_t>(0, 2 * nz - 1 - zb)); zb = nz; }
     if (kz >= nz) { za = 0; zb = nz; }
     int64_t P[3];
-    if (!custom_fft_sizes(dim, kdim, P)) {
+    if (!custom_fft_sizes(dim, kdim, P, ctx->opt)) {
         set_error("slab tiling: no hand-written FFT size for this volume / PSF");
         return MVSIM_EINVAL;
     }
@@ -630,7 +701,7 @@ int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t 
     affine_invert_host(m, inv.m);
     bool fused = false;
     MVSIM_TRY(launch_rotate_attenuate_planes(ctx->stream, gt, nullptr, ctx->vol_b.as<float>(), dim, inv, p->delta,
-                                             (int)za, (int)(zb - za), &fused));
+                                             (int)za, (int)(zb - za), ctx->opt.fused_rotate, &fused));
     if (!fused) {
         set_error("slab tiling needs the fused rotate+attenuate kernel");
         return MVSIM_EINVAL;
@@ -673,7 +744,7 @@ int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim
     }
     return launch_extract(ctx->stream, ctx->vol_a.as<float>() + plane * (first - z0), acq, ldim, p->inc, true, scal,
                           p->min_value, noise, mvsim_poisson_mul((double)p->snr), p->seed, p->stream,
-                          (uint64_t)(first * plane), qws);
+                          (uint64_t)(first * plane), qws, ctx->opt.poisson_queue);
 }
 
 // ---- host-buffer entry points (JNI boundary) ---------------------------------------------------------
@@ -777,7 +848,7 @@ int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr, uin
     MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(n, nullptr)));
     ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, ctx->vol_a.as<float>(), ctx->out_buf.as<float>(), dim, 1, false, nullptr,
-                             0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset, ctx->pqueue.p));
+                             0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset, ctx->pqueue.p, ctx->opt.poisson_queue));
     ev_end(ctx, ST_EXTRACT);
     return down(ctx, img, ctx->out_buf.p, bytes);
 }
@@ -886,7 +957,7 @@ int mvsim_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t geom
 {
     if (!dim || !kdim || !geometry) { set_error("invalid argument: null pointer"); return MVSIM_EINVAL; }
     MVSIM_TRY(check_dim(dim));
-    if (!custom_fft_geometry(dim, kdim, geometry)) {
+    if (!custom_fft_geometry(dim, kdim, geometry, env_options())) {
         set_error("no hand-written FFT size for this volume / PSF");
         return MVSIM_EINVAL;
     }

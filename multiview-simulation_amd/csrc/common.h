@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/mvsim.h"
@@ -85,6 +86,20 @@ struct PinnedRing {
     void release_all();
 };
 
+// Run-time switches of a context.  Defaults come from the environment, read ONCE per process (env_options); the tests
+// reach every code path through mvsim_set_option.  Nothing on a launch path calls getenv.
+struct Options {
+    int     zpass = 0;                 // z pass of the hand-written convolution: 0 auto (direct for Kz <= 64), 1 direct, 2 FFT
+    bool    rocfft = false;            // library fallback instead of the hand-written passes
+    bool    fused_rotate = true;       // rotate+attenuate as one kernel when the rotation is about x
+    bool    poisson_queue = true;      // two-launch Poisson (streaming kernel + work-queue resolver)
+    bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
+    int     graph = 0;                 // replay simulate_view_dev from a captured hipGraph (small, launch-bound volumes)
+    int64_t fft_pad[3] = {0, 0, 0};    // explicit padded sizes on the rocFFT path (0: choose)
+};
+const Options& env_options();
+int parse_option(Options& o, const char* name, const char* value);   // MVSIM_OK / MVSIM_EINVAL
+
 // ST_PASS_*: the five passes of the hand-written convolution, nested inside ST_CONVOLVE (not part of the stage sum)
 enum Stage { ST_ROTATE = 0, ST_ATTENUATE, ST_PSF, ST_CONVOLVE, ST_ADJUST, ST_EXTRACT, ST_PASS_A, ST_PASS_B, ST_PASS_C, ST_PASS_D,
              ST_PASS_E, ST_COUNT };
@@ -112,6 +127,8 @@ struct mvsim_ctx {
     mvsim::DevBuf partials_e;               // per-block sums of the c2r/crop pass
     mvsim::DevBuf cfft_f, cfft_g;           // custom FFT: image / PSF half spectra [Pz][Py][Hxp]
     mvsim::DevBuf cfft_g1, cfft_g2;         // compact PSF intermediates [Kz][Ky][Hxp], [Kz][Py][Hxp]
+    mvsim::Options opt;
+    std::unordered_set<const void*> lds_attr_set;   // kernels whose dynamic-LDS limit has been raised on this device
     std::map<int, void*> twiddles;          // 2*length + kind -> device twiddle table (fft_kernels.hip)
     std::map<std::string, mvsim::FftPlan> plans;
     bool   fft_ready = false;
@@ -138,9 +155,9 @@ namespace mvsim {
 int launch_rotate(hipStream_t s, const float* in, float* out, const int64_t dim[3], const Affine& inv);
 int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta);
 int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
-                            const Affine& inv, double delta, bool* fused);
+                            const Affine& inv, double delta, bool allow_fused, bool* fused);
 int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
-                                   const Affine& inv, double delta, int z_begin, int z_count, bool* fused);
+                                   const Affine& inv, double delta, int z_begin, int z_count, bool allow_fused, bool* fused);
 // sum -> scal[0]; partial workspace must hold >= SUM_BLOCKS doubles
 constexpr int SUM_BLOCKS = 2048;
 int launch_sum(hipStream_t s, const float* in, int64_t n, double* partial, double* scal);
@@ -151,7 +168,7 @@ int launch_norm_apply(hipStream_t s, float* img, int64_t n, const double* scal);
 // extract (+ optional adjust using scal[1]) (+ optional Poisson).  in: Nx*Ny*Nz, out: Nx*Ny*nzo
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                   uint32_t stream, uint64_t index_offset, void* queue_ws);
+                   uint32_t stream, uint64_t index_offset, void* queue_ws, bool use_queue);
 // bytes of the Poisson work queue (HBM) for n_out output voxels
 size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity);
 int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc);
@@ -171,15 +188,17 @@ int launch_cmul(hipStream_t s, float2* f, const float2* g, int64_t n);
 // out = crop(real) * scale; also accumulates block partial sums -> partial (SUM_BLOCKS doubles) and scal[0]
 int launch_crop_scale_sum(hipStream_t s, const float* real, const int64_t P[3], float* out,
                           const int64_t dim[3], float scale, double* partial, double* scal);
-int launch_stencil(hipStream_t s, const float* img, const int64_t dim[3], const float* psf,
+int launch_stencil(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                    const int64_t kdim[3], float* out);
+// raise a kernel's dynamic-LDS limit once per context (hipFuncSetAttribute is not free on a launch path)
+int ensure_lds_attr(mvsim_ctx* ctx, const void* kernel, size_t bytes);
 
 int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,
                  const int64_t kdim[3], float* out_dev, bool want_sum);
 void fft_release(mvsim_ctx* ctx);
-void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3]);
+void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3], const Options& opt);
 // hand-written LDS FFT path (fft_kernels.hip)
-bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3]);
+bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3], const Options& opt);
 int  custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                          const int64_t kdim[3], const int64_t P[3], float* out);
 // z-slab form (direct z pass only): `img` holds the planes [z_in0, z_in0 + nz_in) of a volume with dim[2] planes,
@@ -191,7 +210,7 @@ struct SlabRange {
 int  custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                               const int64_t kdim[3], const int64_t P[3], const SlabRange& slab, float* out);
 void custom_fft_release(mvsim_ctx* ctx);
-bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[5]);
+bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[5], const Options& opt);
 
 // stage timing helpers (events are recorded on the stream the kernels run on)
 inline void ev_begin(mvsim_ctx* ctx, int st)

@@ -931,12 +931,9 @@ static const int kSizes[] = {
 #undef X
 };
 
-template <class K> static int set_lds(K kernel, size_t bytes)
+template <class K> static int set_lds(mvsim_ctx* ctx, K kernel, size_t bytes)
 {
-    if (bytes > 64 * 1024)
-        MVSIM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return MVSIM_OK;
+    return ensure_lds_attr(ctx, reinterpret_cast<const void*>(kernel), bytes);
 }
 
 static size_t zconv_lds(int zc, int kz)
@@ -957,24 +954,26 @@ static int zconv_chunk(int nz, int kz)
     return even < zc ? even : zc;
 }
 
-static int launch_zconv(hipStream_t s, const ZConvArgs& a, int py)
+static int launch_zconv(mvsim_ctx* ctx, const ZConvArgs& a, int py)
 {
+    hipStream_t s = ctx->stream;
     const size_t lds = zconv_lds(a.zc, a.kz);
     dim3 grid((a.nz + a.zc - 1) / a.zc, a.hxp / NLZ, py);
-    MVSIM_TRY(set_lds(k_zconv, lds));
+    MVSIM_TRY(set_lds(ctx, k_zconv, lds));
     hipLaunchKernelGGL(k_zconv, grid, dim3(ZT), lds, s, a);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
 
 template <class PLAN>
-static int launch_lines_t(hipStream_t s, int mode, bool sparse, const LinesArgs& a, int tiles, int nouter)
+static int launch_lines_t(mvsim_ctx* ctx, int mode, bool sparse, const LinesArgs& a, int tiles, int nouter)
 {
+    hipStream_t s = ctx->stream;
     using C = Cfg<PLAN::len>;
     dim3 grid(tiles, nouter), block(C::T);
 #define MVSIM_LL(MODE_, SP_)                                                                 \
     do {                                                                                     \
-        MVSIM_TRY(set_lds(k_fft_lines<PLAN, MODE_, SP_>, C::LDS));                           \
+        MVSIM_TRY(set_lds(ctx, k_fft_lines<PLAN, MODE_, SP_>, C::LDS));                           \
         hipLaunchKernelGGL((k_fft_lines<PLAN, MODE_, SP_>), grid, block, C::LDS, s, a);      \
     } while (0)
     if (mode == FWD && sparse) MVSIM_LL(FWD, true);
@@ -987,33 +986,35 @@ static int launch_lines_t(hipStream_t s, int mode, bool sparse, const LinesArgs&
 }
 
 template <class PLAN>
-static int launch_r2c_t(hipStream_t s, const float* src, const SrcMap& map, float2* dst, const float2* tw,
+static int launch_r2c_t(mvsim_ctx* ctx, const float* src, const SrcMap& map, float2* dst, const float2* tw,
                         const float2* twx, int hxp, long long rows)
 {
     using C = CfgX<PLAN::len>;
+    hipStream_t s = ctx->stream;
     const long long blocks = (rows + C::NL - 1) / C::NL;
-    MVSIM_TRY(set_lds(k_fft_x_r2c<PLAN>, C::LDS));
+    MVSIM_TRY(set_lds(ctx, k_fft_x_r2c<PLAN>, C::LDS));
     hipLaunchKernelGGL((k_fft_x_r2c<PLAN>), dim3((unsigned)blocks), dim3(C::T), C::LDS, s, src, map, dst, tw, twx, hxp, rows);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
 
 template <class PLAN>
-static int launch_c2r_t(hipStream_t s, const float2* srcc, float* out, const float2* tw, const float2* twx, int hxp,
+static int launch_c2r_t(mvsim_ctx* ctx, const float2* srcc, float* out, const float2* tw, const float2* twx, int hxp,
                         int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks)
 {
     using C = CfgX<PLAN::len>;
     const long long groups = (rows + C::NL - 1) / C::NL;
     const int blocks = (int)groups;
     *nblocks = blocks;
-    MVSIM_TRY(set_lds(k_fft_x_c2r<PLAN>, C::LDS));
+    hipStream_t s = ctx->stream;
+    MVSIM_TRY(set_lds(ctx, k_fft_x_c2r<PLAN>, C::LDS));
     hipLaunchKernelGGL((k_fft_x_c2r<PLAN>), dim3((unsigned)blocks), dim3(C::T), C::LDS, s, srcc, out, tw, twx, hxp, py, nx, ny,
                        rows, scale, partial);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
 
-static int launch_lines(hipStream_t s, int L, int mode, bool sparse, const LinesArgs& a, int tiles, int nouter)
+static int launch_lines(mvsim_ctx* s, int L, int mode, bool sparse, const LinesArgs& a, int tiles, int nouter)
 {
     switch (L) {
 #define X(LL, ...) \
@@ -1025,7 +1026,7 @@ static int launch_lines(hipStream_t s, int L, int mode, bool sparse, const Lines
     return MVSIM_EINVAL;
 }
 
-static int launch_r2c(hipStream_t s, int M, const float* src, const SrcMap& map, float2* dst, const float2* tw,
+static int launch_r2c(mvsim_ctx* s, int M, const float* src, const SrcMap& map, float2* dst, const float2* tw,
                       const float2* twx, int hxp, long long rows)
 {
     switch (M) {
@@ -1038,7 +1039,7 @@ static int launch_r2c(hipStream_t s, int M, const float* src, const SrcMap& map,
     return MVSIM_EINVAL;
 }
 
-static int launch_c2r(hipStream_t s, int M, const float2* srcc, float* out, const float2* tw, const float2* twx, int hxp,
+static int launch_c2r(mvsim_ctx* s, int M, const float2* srcc, float* out, const float2* tw, const float2* twx, int hxp,
                       int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks)
 {
     switch (M) {
@@ -1072,10 +1073,9 @@ static int pick_size(int64_t need)
 }  // namespace fft
 
 // Padded sizes for the custom path, or false if some dimension has no supported size.
-bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3])
+bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3], const Options& opt)
 {
-    if (const char* e = getenv("MVSIM_FFT_BACKEND"))
-        if (std::strcmp(e, "rocfft") == 0) return false;
+    if (opt.rocfft) return false;
     for (int d = 0; d < 3; ++d) {
         const int64_t need = dim[d] + kdim[d] - 1;
         if (d == 0) {
@@ -1143,13 +1143,12 @@ void custom_fft_release(mvsim_ctx* ctx)
 }
 
 // {Px, Py, Pz, Hxp, direct z pass?} of the hand-written path for this volume / PSF (what the passes move through HBM)
-bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[5])
+bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[5], const Options& opt)
 {
     using namespace fft;
     int64_t P[3];
-    if (!custom_fft_sizes(dim, kdim, P)) return false;
-    bool zdirect = kdim[2] <= 64;
-    if (const char* e = getenv("MVSIM_FFT_ZPASS")) zdirect = std::strcmp(e, "fft") == 0 ? false : (std::strcmp(e, "direct") == 0 ? true : zdirect);
+    if (!custom_fft_sizes(dim, kdim, P, opt)) return false;
+    const bool zdirect = opt.zpass == 2 ? false : kdim[2] <= 64;
     const int tile_y = lines_per_tile((int)P[1]), tile_z = lines_per_tile((int)P[2]);
     int tw_max = tile_y > tile_z ? tile_y : tile_z;
     if (zdirect) tw_max = tile_y > NLZ ? tile_y : NLZ;
@@ -1177,10 +1176,9 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     const int M = px / 2;
     const int tile_y = lines_per_tile(py), tile_z = lines_per_tile(pz);
     // z pass: direct convolution with the Kz taps (k_zconv) unless the PSF is deep or the FFT formulation is asked for
-    bool zdirect = kz <= 64;
-    if (const char* e = getenv("MVSIM_FFT_ZPASS")) zdirect = std::strcmp(e, "fft") == 0 ? false : (std::strcmp(e, "direct") == 0 ? true : zdirect);
+    const bool zdirect = ctx->opt.zpass == 2 ? false : kz <= 64;
     if (is_slab && !zdirect) {
-        set_error("z-slab tiling needs the direct z pass (PSF depth %d > 64 or MVSIM_FFT_ZPASS=fft)", kz);
+        set_error("z-slab tiling needs the direct z pass (PSF depth %d > 64 or option fft_zpass=fft)", kz);
         return MVSIM_EINVAL;
     }
     const int nzs = slab.nz_in;                                   // planes the image spectrum holds when zdirect
@@ -1225,13 +1223,13 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         m.x = DimMap{kx, px, kx - kx / 2, kx / 2, 1, kx / 2};   // embed along x with wrap-around
         m.y = DimMap{ky, ky, ky, 0, 1, 0};                       // compact: identity
         m.z = DimMap{kz, kz, kz, 0, 1, 0};
-        MVSIM_TRY(launch_r2c(s, M, psf, m, G1, tw_m, tw_px, hxp, (long long)ky * kz));
+        MVSIM_TRY(launch_r2c(ctx, M, psf, m, G1, tw_m, tw_px, hxp, (long long)ky * kz));
         LinesArgs a{};
         a.src = G1; a.dst = G2; a.spec = nullptr; a.tw = tw_py;
         a.src_es = hxp; a.src_outer = (long long)hxp * ky;          // per kz plane
         a.dst_es = hxp; a.dst_outer = plane;
         a.lmap = DimMap{ky, py, ky - ky / 2, ky / 2, 1, ky / 2};
-        MVSIM_TRY(launch_lines(s, py, FWD, true, a, hxp / tile_y, kz));
+        MVSIM_TRY(launch_lines(ctx, py, FWD, true, a, hxp / tile_y, kz));
         if (!zdirect) {
             LinesArgs c{};
             c.src = G2; c.dst = G; c.spec = nullptr; c.tw = tw_pz;
@@ -1239,7 +1237,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             c.dst_es = plane; c.dst_outer = hxp;
             c.lmap = DimMap{kz, pz, kz - kz / 2, kz / 2, 1, kz / 2};
             c.dst_tile_major = 1;                                         // consumed line by line in pass C
-            MVSIM_TRY(launch_lines(s, pz, FWD, true, c, hxp / tile_z, py));
+            MVSIM_TRY(launch_lines(ctx, pz, FWD, true, c, hxp / tile_z, py));
         }
     }
     ev_end(ctx, ST_PSF);
@@ -1258,7 +1256,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         }
         if (zdirect) m.z = DimMap{nzs, nzs, nzs, 0, 0, 0};           // no z padding: k_zconv mirrors through an index map
         ev_begin(ctx, ST_PASS_A);
-        MVSIM_TRY(launch_r2c(s, M, img, m, F, tw_m, tw_px, hxp, zdirect ? (long long)py * nzs : rows_all));
+        MVSIM_TRY(launch_r2c(ctx, M, img, m, F, tw_m, tw_px, hxp, zdirect ? (long long)py * nzs : rows_all));
         ev_end(ctx, ST_PASS_A);
         // zero gap of the padded volume: y in [Ny + cy, Py - lefty), z in [Nz + cz, Pz - leftz).  Pass A does not
         // transform (or write) rows there, pass B skips the gap planes and does not load gap rows, pass C does
@@ -1271,7 +1269,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         b.outer_skip_lo = zgap_lo; b.outer_skip_len = zgap_hi > zgap_lo ? zgap_hi - zgap_lo : 0;
         if (zdirect) { b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0; }
         ev_begin(ctx, ST_PASS_B);
-        MVSIM_TRY(launch_lines(s, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
+        MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
         ev_end(ctx, ST_PASS_B);
         ev_begin(ctx, ST_PASS_C);
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
@@ -1281,7 +1279,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             z.src = F; z.dst = G; z.taps = G2; z.plane = plane; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
             z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
             z.zc = zconv_chunk(nzo, kz);
-            MVSIM_TRY(launch_zconv(s, z, py));
+            MVSIM_TRY(launch_zconv(ctx, z, py));
             Fz = G;
         } else {
         LinesArgs c{};
@@ -1291,20 +1289,20 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         c.gap_lo = zgap_lo; c.gap_hi = zgap_hi;
         c.outer_skip_lo = 1 << 30;
         c.store_limit = (int)dim[2];                                  // pass D only reads planes z < Nz
-        MVSIM_TRY(launch_lines(s, pz, CONV, false, c, hxp / tile_z, py));
+        MVSIM_TRY(launch_lines(ctx, pz, CONV, false, c, hxp / tile_z, py));
         }
         ev_end(ctx, ST_PASS_C);
         b.src = b.dst = Fz;
         b.tw = tw_py;
         b.store_limit = (int)dim[1];                                  // pass E only reads rows y < Ny
         ev_begin(ctx, ST_PASS_D);
-        MVSIM_TRY(launch_lines(s, py, INV, false, b, hxp / tile_y, zdirect ? nzo : (int)dim[2]));   // planes z >= Nz are never read
+        MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, zdirect ? nzo : (int)dim[2]));   // planes z >= Nz are never read
         ev_end(ctx, ST_PASS_D);
         ev_begin(ctx, ST_PASS_E);
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
         const float scale = (float)(0.25 / ((double)px * (double)py * (zdirect ? 1.0 : (double)pz)));
         int nblk = 0;
-        MVSIM_TRY(launch_c2r(s, M, Fz, out, tw_m, tw_px, hxp, py, (int)dim[0], (int)dim[1], rows_out, scale,
+        MVSIM_TRY(launch_c2r(ctx, M, Fz, out, tw_m, tw_px, hxp, py, (int)dim[0], (int)dim[1], rows_out, scale,
                              ctx->partials_e.as<double>(), &nblk));
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal);
         MVSIM_HIP(hipGetLastError());

@@ -11,6 +11,8 @@
 // so the valid output occupies [0, N) and the crop is a plain sub-box copy.
 #include "common.h"
 
+#include <mutex>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -189,14 +191,10 @@ static bool smooth7(int64_t n)
     return n == 1;
 }
 
-void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3])
+void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3], const Options& opt)
 {
-    // optional override for experiments: MVSIM_FFT_PAD="px,py,pz"
-    int64_t ov[3] = {0, 0, 0};
-    if (const char* e = getenv("MVSIM_FFT_PAD")) {
-        long long a = 0, b = 0, c = 0;
-        if (sscanf(e, "%lld,%lld,%lld", &a, &b, &c) == 3) { ov[0] = a; ov[1] = b; ov[2] = c; }
-    }
+    // optional override for experiments: option fft_pad = "px,py,pz"
+    const int64_t* ov = opt.fft_pad;
     for (int d = 0; d < 3; ++d) {
         const int64_t need = dim[d] + kdim[d] - 1;
         int64_t p = need;
@@ -207,14 +205,14 @@ void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3])
 }
 
 // ---- rocFFT plan cache ---------------------------------------------------------------------------
-static bool g_rocfft_setup = false;
+// rocfft_setup() once per process, whatever thread gets here first (contexts live on different host threads)
+static std::once_flag g_rocfft_once;
+static rocfft_status g_rocfft_status = rocfft_status_success;
 
 static int get_plan(mvsim_ctx* ctx, const int64_t P[3], FftPlan** out)
 {
-    if (!g_rocfft_setup) {
-        MVSIM_FFT(rocfft_setup());
-        g_rocfft_setup = true;
-    }
+    std::call_once(g_rocfft_once, [] { g_rocfft_status = rocfft_setup(); });
+    MVSIM_FFT(g_rocfft_status);
     char key[96];
     snprintf(key, sizeof(key), "%lldx%lldx%lld", (long long)P[0], (long long)P[1], (long long)P[2]);
     auto it = ctx->plans.find(key);
@@ -256,8 +254,8 @@ int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], con
                  const int64_t kdim[3], float* out_dev, bool want_sum)
 {
     int64_t P[3];
-    if (custom_fft_sizes(dim, kdim, P)) return custom_fft_convolve(ctx, img_dev, dim, psf_dev, kdim, P, out_dev);
-    choose_padded(dim, kdim, P);
+    if (custom_fft_sizes(dim, kdim, P, ctx->opt)) return custom_fft_convolve(ctx, img_dev, dim, psf_dev, kdim, P, out_dev);
+    choose_padded(dim, kdim, P, ctx->opt);
     FftPlan* pl = nullptr;
     MVSIM_TRY(get_plan(ctx, P, &pl));
     const size_t nreal = (size_t)P[0] * P[1] * P[2];

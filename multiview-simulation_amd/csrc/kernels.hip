@@ -4,8 +4,6 @@
 #include "common.h"
 #include "poisson_dev.h"
 
-#include <cstdlib>
-
 namespace mvsim {
 
 // ------------------------------------------------------------------------------------------------
@@ -273,22 +271,19 @@ __global__ __launch_bounds__(64) void k_rotate_attenuate_axis0(const float* __re
 
 // returns MVSIM_OK and sets *fused = false when the fast-path conditions do not hold (caller runs the two kernels)
 int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
-                            const Affine& inv, double delta, bool* fused)
+                            const Affine& inv, double delta, bool allow_fused, bool* fused)
 {
-    return launch_rotate_attenuate_planes(s, in, rot_or_null, att, dim, inv, delta, 0, (int)dim[2], fused);
+    return launch_rotate_attenuate_planes(s, in, rot_or_null, att, dim, inv, delta, 0, (int)dim[2], allow_fused, fused);
 }
 
 // planes [z_begin, z_begin + z_count) of the view into buffers that start at plane z_begin
 int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
-                                   const Affine& inv, double delta, int z_begin, int z_count, bool* fused)
+                                   const Affine& inv, double delta, int z_begin, int z_count, bool allow_fused, bool* fused)
 {
     const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
     const bool x_identity = inv.m[0] == 1.0 && inv.m[1] == 0.0 && inv.m[2] == 0.0 && inv.m[3] == 0.0 &&
                             inv.m[4] == 0.0 && inv.m[8] == 0.0;
-    const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(att) |
-                         reinterpret_cast<uintptr_t>(rot_or_null);
-    (void)al;
-    *fused = x_identity && !getenv("MVSIM_NO_FUSED_ROTATE");
+    *fused = x_identity && allow_fused;
     if (!*fused) return MVSIM_OK;
     dim3 grid((nx + 63) / 64, z_count);
     if (rot_or_null)
@@ -680,7 +675,7 @@ size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)
 
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                   uint32_t stream, uint64_t index_offset, void* queue_ws)
+                   uint32_t stream, uint64_t index_offset, void* queue_ws, bool use_queue)
 {
     const long long plane = (long long)dim[0] * dim[1];
     const long long nzo = (dim[2] - 1) / inc + 1;
@@ -694,7 +689,7 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
 #define MVSIM_LAUNCH_EX4(A, N)                                                                               \
     hipLaunchKernelGGL((k_extract4<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, scal, \
                        min_value, mul, k0, k1, stream, (unsigned long long)index_offset)
-        if (noise && queue_ws && !getenv("MVSIM_POISSON_NOQUEUE")) {
+        if (noise && queue_ws && use_queue) {
             int qblocks;
             unsigned int segcap;
             poisson_geometry(total, &qblocks, &segcap);

@@ -97,9 +97,10 @@ __global__ __launch_bounds__(256) void k_stencil(const float* __restrict__ img, 
     }
 }
 
-int launch_stencil(hipStream_t s, const float* img, const int64_t dim[3], const float* psf,
+int launch_stencil(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                    const int64_t kdim[3], float* out)
 {
+    hipStream_t s = ctx->stream;
     const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
     const int kx = (int)kdim[0], ky = (int)kdim[1], kz = (int)kdim[2];
     const int W = TX + kx - 1;
@@ -120,10 +121,7 @@ int launch_stencil(hipStream_t s, const float* img, const int64_t dim[3], const 
     if (kc > kz) kc = kz;
     const size_t lds = slice * (size_t)(TZ + kc - 1) + 64;
     (void)budget;
-    if (lds > 64 * 1024) {
-        MVSIM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stencil),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    MVSIM_TRY(ensure_lds_attr(ctx, reinterpret_cast<const void*>(k_stencil), lds));
     dim3 grid((nx + TX - 1) / TX, (ny + TY - 1) / TY, (nz + TZ - 1) / TZ);
     hipLaunchKernelGGL(k_stencil, grid, dim3(256), lds, s, img, psf, out, nx, ny, nz, kx, ky, kz, kc, S, H);
     MVSIM_HIP(hipGetLastError());

@@ -69,6 +69,17 @@ def hourglass_psf(k: int = 63, sigma=(2.5, 2.5, 10.0), tilt_deg: float = 20.0) -
     return np.ascontiguousarray(np.maximum(g, 0.0), dtype=np.float32)
 
 
+def measured_like_psf(k: int = 51) -> np.ndarray:
+    """Stand-in for the reference's shipped PSF stacks (`Angle<k>.tif`: 51^3 float32, peak 0.99 at the centre, sigma about
+    (2.0, 2.2, 6.7) px, ~4 % of the voxels non-zero, not separable): a tilted hour-glass, scaled to peak 0.99 and
+    clipped to zero below 0.5 % of the peak like a background-subtracted measurement.  The GPL data files themselves
+    are not part of this repository."""
+    g = hourglass_psf(k, sigma=(2.0, 2.2, 6.7), tilt_deg=8.0)
+    g = g * np.float32(0.99 / g.max())
+    g[g < 0.005 * 0.99] = 0.0
+    return np.ascontiguousarray(g, dtype=np.float32)
+
+
 def view_angles(n_views: int, offset: int = 15) -> list[int]:
     """angleOffset + k * (360 / n_views) (SimulateMultiViewDataset.java:540-548,567-570)."""
     step = 360 // n_views

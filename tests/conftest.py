@@ -45,6 +45,15 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
+@pytest.fixture(scope="session")
+def psf51_tif(tmp_path_factory, mvs, synth):
+    """An ImageJ float32 stack like the reference's `Angle0.tif` (51 planes of 51 x 51, big-endian), synthesised and
+    written with Tools.save: the reference's PSF files are GPL data and are not copied into this repository."""
+    path = str(tmp_path_factory.mktemp("psf") / "Angle0.tif")
+    mvs.Tools.save(synth.measured_like_psf(51), path)
+    return path
+
+
 def rel_to_max(a, b):
     """max|a-b| / max|b| -- the range-normalised error of SURVEY.md H2."""
     a = np.asarray(a, dtype=np.float64)

@@ -259,18 +259,21 @@ def test_simulate_phantom_full_size(mvs, orc):
     assert 0.1 < float((got > 0).mean()) < 0.3 and float(got.max()) < 1.0
 
 
-def test_reference_configuration_view(ctx, mvs, orc, golden_dir):
-    """BASELINE configs[0], the reference's own run: 289^3 sphere phantom from `simulate()`, the shipped 51^3 PSF
-    `Angle0.tif` through Tools.open(file, true), first view of `main` (angle 0 + offset 15, spacing 3, SNR 25)."""
+def test_reference_configuration_view(ctx, mvs, orc, psf51_tif):
+    """The reference's own run (SimulateMultiViewDataset.main, :524-613): 289^3 sphere phantom from `simulate()`, a
+    51^3 PSF stack `Angle0.tif` through Tools.open(file, true) (synthesised: the shipped stacks are GPL data), first
+    view of `main` (angle 0 + offset 15, spacing 3, SNR 25, attenuation = 0.01f widened to double)."""
     S, T = mvs.SimulateMultiViewDataset, mvs.Tools
     rendered = S.simulate(False, mvs.JavaRandom(464232194))
-    psf_raw = T.open(os.path.join(golden_dir, "Angle0.tif"), True)
+    psf_raw = T.open(psf51_tif, True)
     assert rendered.shape == (289, 289, 289) and psf_raw.shape == (51, 51, 51)
-    p = ctx.view_params(degrees=15, delta=0.01, inc=3, snr=25.0, seed=464232194, stream=0)
+    delta = float(np.float32(0.01))                                       # SMVD:533,573
+    p = ctx.view_params(degrees=15, inc=3, snr=25.0, seed=464232194, stream=0)
+    assert p.delta == delta                                               # the C default is the reference's value
     psf_g = psf_raw.copy()
     got = ctx.simulate_view(rendered, psf_g, p, want=("rot", "att", "con", "acq"))
     psf_o = psf_raw.copy()
-    ref = orc.simulate_view(rendered, psf_o, 15, delta=0.01, inc=3, snr=25.0, seed=464232194, stream=0, conv="fft")
+    ref = orc.simulate_view(rendered, psf_o, 15, delta=delta, inc=3, snr=25.0, seed=464232194, stream=0, conv="fft")
     assert np.array_equal(psf_g, psf_o)                                   # normalised in place, identically
     assert np.array_equal(got["rot"], ref["rot"]) and np.array_equal(got["att"], ref["att"])
     assert rel_to_max(got["con"], ref["con"]) <= CONV_TOL
@@ -284,11 +287,11 @@ def test_reference_configuration_view(ctx, mvs, orc, golden_dir):
     assert abs(float(got["acq"].mean()) - float(ref["acq"].mean())) < 0.02
 
 
-def test_simulate_tile_stitching_pair(mvs, orc, golden_dir):
+def test_simulate_tile_stitching_pair(mvs, orc, psf51_tif):
     """SimulateTileStitching.java:43-246 at the reference's size: phantom from `new Random(rnd.nextInt())`, no
     rotation, 51^3 PSF; tiles are sub-intervals of the convolved volume run through extractSlices."""
     S, T = mvs.SimulateMultiViewDataset, mvs.Tools
-    psf = T.open(os.path.join(golden_dir, "Angle0.tif"), True)
+    psf = T.open(psf51_tif, True)
     sts = mvs.SimulateTileStitching(mvs.JavaRandom(5), True, (0.2, 0.2, 0.2), None, psf=psf.copy())
     assert sts.con.shape == sts.conHalfPixel.shape == (289, 289, 289)
     assert sts.overlap == [29, 29, 29]                                   # round(289 * 0.2 / 2)
@@ -568,39 +571,35 @@ def test_invalid_arguments_are_rejected(ctx):
 
 # ------------------------------------------------------------------------------------------------ alternative conv paths
 @pytest.fixture
-def env_override():
-    """Set environment switches the library reads per call (getenv inside the C entry points); restored afterwards."""
-    saved = {}
-
-    def setenv(**kw):
+def options(ctx):
+    """Run-time switches of the context (mvsim_set_option; nothing on a launch path reads the environment); the defaults
+    are restored afterwards."""
+    def set_(**kw):
         for k, v in kw.items():
-            saved.setdefault(k, os.environ.get(k))
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    yield setenv
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+            ctx.set_option(k, v)
+    yield set_
+    for k, v in (("fft_zpass", "auto"), ("fft_backend", "custom"), ("fft_pad", "auto"), ("fused_rotate", 1),
+                 ("poisson_queue", 1), ("early_sum", 1), ("graph", 0)):
+        ctx.set_option(k, v)
 
 
 @pytest.mark.parametrize("shape,kshape", [((40, 48, 56), (9, 7, 5)), ((64, 64, 64), (15, 15, 15)), ((33, 70, 45), (31, 5, 11))])
-def test_convolve_fft_z_pass_and_rocfft_fallback_agree(ctx, orc, env_override, shape, kshape):
+def test_convolve_fft_z_pass_and_rocfft_fallback_agree(ctx, orc, options, shape, kshape):
     """The three transform-domain formulations -- direct z pass (default for Kz <= 64), FFT z pass with the expanded
     PSF spectrum (deep PSFs), rocFFT (sizes outside the pass table) -- all meet the 1e-5 contract."""
     rng = np.random.default_rng(44)
     v = rng.random(shape, dtype=np.float32)
     psf = rng.random(kshape, dtype=np.float32) + 0.1
     ref = orc.convolve_fft(v, psf.copy())
-    env_override(MVSIM_FFT_ZPASS=None, MVSIM_FFT_BACKEND=None)
+    options(fft_zpass="auto", fft_backend="custom")
     direct = ctx.convolve(v, psf.copy(), method=1)
-    env_override(MVSIM_FFT_ZPASS="fft")
+    options(fft_zpass="fft")
     zfft = ctx.convolve(v, psf.copy(), method=1)
-    env_override(MVSIM_FFT_ZPASS=None, MVSIM_FFT_BACKEND="rocfft")
+    options(fft_zpass="auto", fft_backend="rocfft")
     roc = ctx.convolve(v, psf.copy(), method=1)
+    options(fft_backend="rocfft", fft_pad="64,72,80")        # explicit padded sizes on the library path
+    roc2 = ctx.convolve(v, psf.copy(), method=1) if max(s + k - 1 for s, k in zip(shape, kshape)) <= 64 else roc
+    assert rel_to_max(roc2, ref) <= CONV_TOL
     for got in (direct, zfft, roc):
         assert rel_to_max(got, ref) <= CONV_TOL
     assert rel_to_max(direct, zfft) <= 2e-6 and rel_to_max(direct, roc) <= 2e-6
@@ -628,13 +627,13 @@ def test_convolve_deep_psf_takes_the_fft_z_pass(ctx, orc, synth):
     assert rel_to_max(got, orc.convolve_fft(v, psf.copy())) <= CONV_TOL
 
 
-def test_view_with_fft_z_pass_is_a_valid_view(ctx, orc, synth, env_override):
+def test_view_with_fft_z_pass_is_a_valid_view(ctx, orc, synth, options):
     """The fused view on the FFT z pass: rot/att bit-exact, con within tolerance, same acquisition statistics."""
     gt = synth.sphere_phantom(48)
     psf = synth.gaussian_psf(9, sigma=(1.2, 1.4, 2.5))
     p = ctx.view_params(degrees=33, delta=0.01, inc=2, snr=25.0, seed=SEED, stream=2)
     a = ctx.simulate_view(gt, psf.copy(), p, want=("att", "con", "acq"))
-    env_override(MVSIM_FFT_ZPASS="fft")
+    options(fft_zpass="fft")
     b = ctx.simulate_view(gt, psf.copy(), p, want=("att", "con", "acq"))
     assert np.array_equal(a["att"], b["att"])
     assert rel_to_max(a["con"], b["con"]) <= 2e-6

@@ -108,23 +108,54 @@ def test_product_never_imports_the_oracle():
 
 
 # ------------------------------------------------------------------------------------------------ TIFF I/O (8f rank 4)
-def test_tiff_reader_and_imagej_writer_round_trip(mvs, golden_dir, tmp_path):
-    """Tools.open / Tools.save (Tools.java:88-105,162-232): the shipped PSF `Angle0.tif` (ImageJ 1.48o, big-endian
-    float32, 51 planes) is read, and writing it back reproduces the file byte for byte."""
+def test_tiff_reader_and_imagej_writer_round_trip(mvs, synth, tmp_path):
+    """Tools.open / Tools.save (Tools.java:88-105,162-232).  ImageJ's FileSaver writes a stack as: header, first IFD at
+    offset 8 (11 entries), the "ImageJ=" description, every plane contiguously, then one IFD per further plane.  The
+    expected bytes of a small stack are assembled here entry by entry (TIFF 6.0 tags, big-endian) and compared with
+    what the writer produces; the reader must return the planes from either."""
+    import struct
     tiffio = importlib.import_module("multiview-simulation_amd.tiffio")
-    src = os.path.join(golden_dir, "Angle0.tif")
-    psf = mvs.Tools.open(src)
-    assert psf.shape == (51, 51, 51) and psf.dtype == np.float32
-    assert psf.min() == 0.0 and psf.max() == np.float32(0.99)
+    img = (np.arange(3 * 2 * 3, dtype=np.float32).reshape(3, 2, 3) / 16).astype(np.float32)
+    nz, h, w = img.shape
+    desc = b"ImageJ=1.48o\nimages=3\nslices=3\nloop=false\nmin=0.0\nmax=1.0\n\x00"
+    ifd_len = 2 + 11 * 12 + 4
+    desc_off, plane = 8 + ifd_len, w * h * 4
+    data_off = desc_off + len(desc)
+    tail = data_off + nz * plane
+
+    def ifd(strip, nxt):
+        short = lambda v: v << 16                                             # a SHORT value sits left-justified in its field
+        ent = [(254, 4, 1, 0),                # NewSubfileType
+               (256, 4, 1, w), (257, 4, 1, h),
+               (258, 3, 1, short(32)),        # BitsPerSample
+               (262, 3, 1, short(1)),         # PhotometricInterpretation: BlackIsZero
+               (270, 2, len(desc), desc_off), # ImageDescription
+               (273, 4, 1, strip),            # StripOffsets
+               (277, 3, 1, short(1)),         # SamplesPerPixel
+               (278, 3, 1, short(h)),         # RowsPerStrip
+               (279, 4, 1, plane),            # StripByteCounts
+               (339, 3, 1, short(3))]         # SampleFormat: IEEE float
+        return struct.pack(">H", 11) + b"".join(struct.pack(">HHII", *e) for e in ent) + struct.pack(">I", nxt)
+    want = b"MM\x00\x2a" + struct.pack(">I", 8) + ifd(data_off, tail) + desc + img.astype(">f4").tobytes()
+    want += ifd(data_off + plane, tail + ifd_len) + ifd(data_off + 2 * plane, 0)
+    out = str(tmp_path / "stack.tif")
+    tiffio.save_tiff(img, out, display_range=(0.0, 1.0))
+    assert open(out, "rb").read() == want
+    assert np.array_equal(mvs.Tools.open(out), img)
+    # a stack with only the first IFD (what ImageJ writes beyond 4 GB): the planes follow the first strip
+    single = str(tmp_path / "single_ifd.tif")
+    open(single, "wb").write(b"MM\x00\x2a" + struct.pack(">I", 8) + ifd(data_off, 0) + desc + img.astype(">f4").tobytes())
+    assert np.array_equal(mvs.Tools.open(single), img)
+    # the PSF-sized stack the reference's callers load (51 planes of 51 x 51), default description = data range
+    psf = synth.measured_like_psf(51)
+    assert psf.shape == (51, 51, 51) and psf.max() == np.float32(0.99) and psf.min() == 0.0
     assert np.unravel_index(np.argmax(psf), psf.shape) == (25, 25, 25)          # the PSF peaks at its centre K/2
-    out = str(tmp_path / "resaved.tif")
-    tiffio.save_tiff(psf, out, display_range=(0.0, 1.0))
-    assert open(out, "rb").read() == open(src, "rb").read()
-    mvs.Tools.save(psf, out)                                                     # default description: data range
+    assert 0.01 < float((psf > 0).mean()) < 0.12
+    mvs.Tools.save(psf, out)
     assert np.array_equal(mvs.Tools.open(out), psf)
-    plane = str(tmp_path / "plane.tif")
-    mvs.Tools.save(psf[7], plane)                                                # 2-D image -> single-plane TIFF
-    assert np.array_equal(mvs.Tools.open(plane)[0], psf[7])
+    plane_f = str(tmp_path / "plane.tif")
+    mvs.Tools.save(psf[7], plane_f)                                              # 2-D image -> single-plane TIFF
+    assert np.array_equal(mvs.Tools.open(plane_f)[0], psf[7])
 
 
 def test_tiff_reader_little_endian_multi_strip_and_rejections(mvs, tmp_path):
@@ -222,3 +253,31 @@ def test_c_abi_compiles_as_plain_c_and_fails_loudly_without_gpu(tmp_path):
         assert r.returncode == 0, r.stderr
     else:
         assert r.returncode == 3 and "no HIP device" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------------ sanitizers (CPU side)
+def test_oracle_under_address_and_ub_sanitizer():
+    """`make -C oracle asan`: the C restatement under -fsanitize=address,undefined on exactly sized heap buffers."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout + b.stderr
+    r = subprocess.run([os.path.join(root, "oracle", "asan_check")], capture_output=True, text=True)
+    assert r.returncode == 0 and "oracle sanitizer run ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_c_abi_host_only_leg_under_sanitizers(tmp_path):
+    """tests/c_abi/host_only.c built with ASan + UBSan against libmvsim.so: the entry points that need no GPU."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "multiview-simulation_amd")
+    exe = str(tmp_path / "c_abi_host_only")
+    cmd = [shutil.which("gcc") or "gcc", "-std=c99", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "host_only.c"),
+           "-L" + pkg, "-lmvsim", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lm", "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout + b.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0")   # the ROCm runtime keeps process-lifetime blocks
+    r = subprocess.run([exe], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "host-only sanitizer run ok" in r.stdout, r.stdout + r.stderr
