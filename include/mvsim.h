@@ -59,7 +59,8 @@ int  mvsim_synchronize(mvsim_ctx* ctx);
  * variables of the same meaning, read once per process: "fft_zpass" = auto|direct|fft (MVSIM_FFT_ZPASS),
  * "fft_backend" = custom|rocfft (MVSIM_FFT_BACKEND), "fft_pad" = "px,py,pz"|auto (MVSIM_FFT_PAD), "fused_rotate" = 1|0
  * (MVSIM_NO_FUSED_ROTATE), "poisson_queue" = 1|0 (MVSIM_POISSON_NOQUEUE), "early_sum" = 1|0 (MVSIM_NO_EARLY_SUM),
- * "graph" = 0|1 (MVSIM_GRAPH).  Unknown names or values: MVSIM_EINVAL. */
+ * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST).  Unknown names or values:
+ * MVSIM_EINVAL. */
 int  mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value);
 /* Release cached FFT plans / workspaces / PSF spectra held by the context. */
 int  mvsim_release_caches(mvsim_ctx* ctx);
@@ -215,7 +216,9 @@ int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t);
 int mvsim_comm_unique_id(unsigned char id[MVSIM_UNIQUE_ID_BYTES]);
 int mvsim_comm_init(mvsim_ctx* ctx, int nranks, int rank, const unsigned char id[MVSIM_UNIQUE_ID_BYTES]);
 /* Broadcast the ground-truth volume (device pointer, count floats) from root; enqueued on
- * the context stream.  The only collective on the path (views are independent, SMVD:567). */
+ * the context stream.  The only collective on the path (views are independent, SMVD:567).
+ * Default form: scatter (root sends chunk r to rank r, nranks-1 concurrent ncclSend: one per xGMI link) followed by
+ * an in-place ncclAllGather, so that all links carry traffic; option "broadcast" = ring selects one ncclBroadcast. */
 int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, int root);
 /* In-place sum over ranks (RCCL all-reduce) of a device float buffer: the per-voxel weight sums of SMVD:625-628
  * when the views live on different GPUs.  Summation order differs from the sequential reference (<= 1 ulp). */
@@ -228,6 +231,19 @@ int mvsim_comm_destroy(mvsim_ctx* ctx);
  * their indices (capacity max_out). */
 int mvsim_shard_views(int n_views, int nranks, int rank, int* view_idx, int max_out);
 
+/* ---- one PROCESS driving several GPUs (what a JVM host is): a group owns one context per device and an RCCL
+ * communicator over them (ncclCommInitAll).  The ground truth goes host -> device 0 -> all devices (scatter +
+ * all-gather over xGMI), then view v of SimulateMultiViewDataset.main's loop (:567-613) runs on device v % ndev and
+ * its acquisition is copied to acq_host[v]; the call returns when every view has landed.  psf_host[v] is normalised in
+ * place like everywhere else.  devices == NULL means 0 .. ndev-1. */
+typedef struct mvsim_group mvsim_group;
+int        mvsim_group_create(int ndev, const int* devices, mvsim_group** group);
+int        mvsim_group_destroy(mvsim_group* group);
+int        mvsim_group_size(const mvsim_group* group);
+mvsim_ctx* mvsim_group_ctx(mvsim_group* group, int index);
+int        mvsim_group_broadcast_volume(mvsim_group* group, const float* gt_host, const int64_t dim[3]);
+int        mvsim_group_simulate_views(mvsim_group* group, float* const* psf_host, const int64_t kdim[3],
+                                      const mvsim_view_params* params, int n_views, float* const* acq_host);
 
 /* ---- z-slab tiling of ONE view across GPUs (BASELINE configs[3]/[4]) ----------------------------
  * For volumes whose views should be split over several GPUs: rank r owns the planes [z0, z1) of the view

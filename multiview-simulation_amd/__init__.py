@@ -25,7 +25,7 @@ import numpy as np
 from . import _lib
 from ._lib import MvsimError, MvsimNoDeviceError, Timings, ViewOutputs, ViewParams  # noqa: F401
 
-__all__ = ["Context", "JavaRandom", "SimulateMultiViewDataset", "Tools", "default_context", "MvsimError",
+__all__ = ["Context", "Group", "JavaRandom", "SimulateMultiViewDataset", "Tools", "default_context", "MvsimError",
            "MvsimNoDeviceError", "ViewParams", "shard_views", "version"]
 
 
@@ -458,6 +458,64 @@ class Context:
 
     def comm_destroy(self) -> None:
         _lib.check(self._L.mvsim_comm_destroy(self._h))
+
+
+class Group:
+    """``mvsim_group``: ONE process driving several GPUs (what a JVM host is) -- one context per device plus an RCCL
+    communicator over them.  ``broadcast_volume`` puts the ground truth on every device (host -> device 0 -> scatter +
+    all-gather over xGMI); ``simulate_views`` runs view v on device v % ndev and returns the acquisitions."""
+
+    def __init__(self, ndev: int, devices=None):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        arr = (C.c_int * ndev)(*devices) if devices is not None else None
+        _lib.check(self._L.mvsim_group_create(ndev, arr, C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.mvsim_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(self._L.mvsim_group_size(self._h))
+
+    def set_option(self, name: str, value) -> None:
+        for i in range(len(self)):
+            _lib.check(self._L.mvsim_set_option(C.c_void_p(self._L.mvsim_group_ctx(self._h, i)), name.encode(), str(value).encode()))
+
+    def broadcast_volume(self, gt) -> None:
+        v = _as_volume(gt, "ground truth")
+        self._shape = v.shape
+        _lib.check(self._L.mvsim_group_broadcast_volume(self._h, _ptr(v), _dim(v)))
+
+    def simulate_views(self, psfs: list, params: list) -> list:
+        """psfs[v]: float32 (Kz,Ky,Kx) arrays of one common shape, normalised in place; params[v]: ViewParams."""
+        n = len(psfs)
+        if n != len(params):
+            raise ValueError("one ViewParams per PSF")
+        for q in psfs:
+            _check_inplace(q, "psf")
+            if q.shape != psfs[0].shape:
+                raise ValueError("all PSFs must have the same shape")
+        nz, ny, nx = self._shape
+        acq = [np.empty((self._L.mvsim_extract_nz(nz, p.inc), ny, nx), dtype=np.float32) for p in params]
+        pa = (C.c_void_p * n)(*[q.ctypes.data for q in psfs])
+        oa = (C.c_void_p * n)(*[a.ctypes.data for a in acq])
+        pv = (ViewParams * n)(*params)
+        _lib.check(self._L.mvsim_group_simulate_views(self._h, pa, _dim(psfs[0]), pv, n, oa))
+        return acq
 
 
 def _check_inplace(a, name="image") -> None:

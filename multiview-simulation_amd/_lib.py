@@ -114,6 +114,12 @@ SIGNATURES = {
     "mvsim_view_slab_finish_dev": (C.c_int, [_vp, _i64p, _vp, C.c_int64, C.c_int64, C.c_double, _vp,
                                              C.POINTER(C.c_int64)]),
     "mvsim_comm_destroy": (C.c_int, [_vp]),
+    "mvsim_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "mvsim_group_destroy": (C.c_int, [_vp]),
+    "mvsim_group_size": (C.c_int, [_vp]),
+    "mvsim_group_ctx": (_vp, [_vp, C.c_int]),
+    "mvsim_group_broadcast_volume": (C.c_int, [_vp, _vp, _i64p]),
+    "mvsim_group_simulate_views": (C.c_int, [_vp, C.POINTER(_vp), _i64p, C.POINTER(ViewParams), C.c_int, C.POINTER(_vp)]),
     "mvsim_shard_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
 }
 

@@ -40,6 +40,10 @@ int parse_option(Options& o, const char* name, const char* value)
     if (n == "poisson_queue") return flag(&o.poisson_queue);
     if (n == "early_sum") return flag(&o.early_sum);
     if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
+    if (n == "broadcast") {
+        if (v == "scatter_allgather" || v == "auto") o.bcast_ring = false; else if (v == "ring") o.bcast_ring = true; else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
     if (n == "fft_pad") {
         long long a = 0, b = 0, c = 0;
         if (v == "auto" || v.empty()) { o.fft_pad[0] = o.fft_pad[1] = o.fft_pad[2] = 0; return MVSIM_OK; }
@@ -64,6 +68,7 @@ const Options& env_options()
         if (getenv("MVSIM_POISSON_NOQUEUE")) o.poisson_queue = false;
         if (getenv("MVSIM_NO_EARLY_SUM")) o.early_sum = false;
         if (const char* e = getenv("MVSIM_GRAPH")) (void)parse_option(o, "graph", e);
+        if (const char* e = getenv("MVSIM_BROADCAST")) (void)parse_option(o, "broadcast", e);
     });
     return o;
 }

@@ -6,6 +6,8 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <new>
+#include <vector>
 
 using namespace mvsim;
 
@@ -48,13 +50,58 @@ int mvsim_comm_init(mvsim_ctx* ctx, int nranks, int rank, const unsigned char id
     return MVSIM_OK;
 }
 
+// Broadcast of the ground truth.  xGMI is point-to-point (7 links per GPU): a ring/chain broadcast moves the whole
+// volume over ONE link of every GPU (0.54 GB at 512^3: ~3.5 ms, longer than a 2.4 ms view), so the default form is
+//   phase 0  scatter: root sends chunk r (count / nranks floats) to rank r -- nranks-1 concurrent sends, one per link
+//   phase 1  all-gather: every rank hands its chunk to all others (ncclAllGather, in place)
+//   phase 2  the few floats that do not divide into aligned chunks ride in a tiny ncclBroadcast
+// which keeps all links busy in both big steps (~2 * S / (nranks * link rate)).  Option broadcast=ring selects one
+// ncclBroadcast for A/B runs.  The phases are separate so that a single process driving several devices
+// (mvsim_group_*) can wrap each of them in one ncclGroupStart/End over all its ranks.
+static int bcast_phase(mvsim_ctx* ctx, float* vol, int64_t count, int root, int phase)
+{
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    const int n = ctx->nranks, me = ctx->rank;
+    const int64_t chunk = (count / n) & ~(int64_t)15;            // whole 64-byte units keep every transfer aligned
+    const bool ring = ctx->opt.bcast_ring || chunk == 0;
+    if (phase == 0) {
+        if (ring) {
+            MVSIM_NCCL(ncclBroadcast(vol, vol, (size_t)count, ncclFloat, root, comm, ctx->stream));
+            return MVSIM_OK;
+        }
+        ncclResult_t bad = ncclSuccess;
+        MVSIM_NCCL(ncclGroupStart());
+        if (me == root) {
+            for (int r = 0; r < n && bad == ncclSuccess; ++r)
+                if (r != root) bad = ncclSend(vol + (int64_t)r * chunk, (size_t)chunk, ncclFloat, r, comm, ctx->stream);
+        } else {
+            bad = ncclRecv(vol + (int64_t)me * chunk, (size_t)chunk, ncclFloat, root, comm, ctx->stream);
+        }
+        const ncclResult_t end = ncclGroupEnd();
+        if (bad != ncclSuccess || end != ncclSuccess) {
+            mvsim::set_error("scatter of the ground truth failed: %s", ncclGetErrorString(bad != ncclSuccess ? bad : end));
+            return MVSIM_ERCCL;
+        }
+        return MVSIM_OK;
+    }
+    if (ring) return MVSIM_OK;
+    if (phase == 1) {
+        MVSIM_NCCL(ncclAllGather(vol + (int64_t)me * chunk, vol, (size_t)chunk, ncclFloat, comm, ctx->stream));
+        return MVSIM_OK;
+    }
+    const int64_t tail = count - chunk * n;
+    if (tail > 0) MVSIM_NCCL(ncclBroadcast(vol + chunk * n, vol + chunk * n, (size_t)tail, ncclFloat, root, comm, ctx->stream));
+    return MVSIM_OK;
+}
+
 int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, int root)
 {
     MVSIM_CHECK_ARG(ctx != nullptr && vol_dev != nullptr && count >= 0, "null pointer or negative count");
     MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
     MVSIM_CHECK_ARG(root >= 0 && root < ctx->nranks, "root out of range");
     MVSIM_HIP(hipSetDevice(ctx->device));
-    MVSIM_NCCL(ncclBroadcast(vol_dev, vol_dev, (size_t)count, ncclFloat, root, (ncclComm_t)ctx->comm, ctx->stream));
+    if (count == 0) return MVSIM_OK;
+    for (int phase = 0; phase < 3; ++phase) MVSIM_TRY(bcast_phase(ctx, vol_dev, count, root, phase));
     return MVSIM_OK;
 }
 
@@ -104,6 +151,125 @@ int mvsim_shard_views(int n_views, int nranks, int rank, int* view_idx, int max_
         ++cnt;
     }
     return cnt;
+}
+
+// ---- one process driving several GPUs (a JVM is ONE process: SimulateMultiViewDataset.main's view loop, :567-613,
+//      fans out over the devices of the node from a single host thread) ---------------------------------------------
+struct mvsim_group {
+    std::vector<mvsim_ctx*> ctx;
+    std::vector<mvsim::DevBuf> gt, acq;
+    int64_t dim[3] = {0, 0, 0};
+    bool have_gt = false;
+};
+
+int mvsim_group_create(int ndev, const int* devices, mvsim_group** out)
+{
+    MVSIM_CHECK_ARG(out != nullptr, "group out pointer is null");
+    *out = nullptr;
+    MVSIM_CHECK_ARG(ndev >= 1 && ndev <= 64, "ndev must be in 1..64");
+    mvsim_group* g = new (std::nothrow) mvsim_group();
+    if (!g) { mvsim::set_error("out of host memory"); return MVSIM_ENOMEM; }
+    std::vector<int> devs((size_t)ndev);
+    int rc = MVSIM_OK;
+    for (int i = 0; i < ndev && rc == MVSIM_OK; ++i) {
+        devs[i] = devices ? devices[i] : i;
+        for (int j = 0; j < i; ++j)
+            if (devs[j] == devs[i]) { mvsim::set_error("invalid argument: device %d listed twice", devs[i]); rc = MVSIM_EINVAL; }
+        mvsim_ctx* c = nullptr;
+        if (rc == MVSIM_OK) rc = mvsim_create(devs[i], &c);
+        if (rc == MVSIM_OK) g->ctx.push_back(c);
+    }
+    if (rc == MVSIM_OK) {
+        std::vector<ncclComm_t> comms((size_t)ndev, nullptr);
+        const ncclResult_t r = ncclCommInitAll(comms.data(), ndev, devs.data());
+        if (r != ncclSuccess) { mvsim::set_error("ncclCommInitAll failed: %s", ncclGetErrorString(r)); rc = MVSIM_ERCCL; }
+        for (int i = 0; i < ndev && rc == MVSIM_OK; ++i) { g->ctx[i]->comm = comms[i]; g->ctx[i]->nranks = ndev; g->ctx[i]->rank = i; }
+    }
+    if (rc != MVSIM_OK) { mvsim_group_destroy(g); return rc; }
+    g->gt.resize((size_t)ndev);
+    g->acq.resize((size_t)ndev);
+    *out = g;
+    return MVSIM_OK;
+}
+
+int mvsim_group_destroy(mvsim_group* g)
+{
+    if (!g) return MVSIM_OK;
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        (void)hipSetDevice(g->ctx[i]->device);
+        (void)hipStreamSynchronize(g->ctx[i]->stream);
+        if (i < g->gt.size()) g->gt[i].release();
+        if (i < g->acq.size()) g->acq[i].release();
+        mvsim_destroy(g->ctx[i]);
+    }
+    delete g;
+    return MVSIM_OK;
+}
+
+int mvsim_group_size(const mvsim_group* g) { return g ? (int)g->ctx.size() : 0; }
+
+mvsim_ctx* mvsim_group_ctx(mvsim_group* g, int index)
+{
+    if (!g || index < 0 || index >= (int)g->ctx.size()) { mvsim::set_error("invalid argument: group context index"); return nullptr; }
+    return g->ctx[(size_t)index];
+}
+
+int mvsim_group_broadcast_volume(mvsim_group* g, const float* gt_host, const int64_t dim[3])
+{
+    MVSIM_CHECK_ARG(g != nullptr && gt_host != nullptr && dim != nullptr, "null pointer");
+    MVSIM_CHECK_ARG(dim[0] >= 1 && dim[1] >= 1 && dim[2] >= 1, "dimensions must be >= 1");
+    const int64_t count = dim[0] * dim[1] * dim[2];
+    const size_t bytes = (size_t)count * sizeof(float);
+    const int n = (int)g->ctx.size();
+    for (int i = 0; i < n; ++i) {
+        MVSIM_HIP(hipSetDevice(g->ctx[i]->device));
+        MVSIM_TRY(g->gt[i].reserve(bytes));
+    }
+    MVSIM_HIP(hipSetDevice(g->ctx[0]->device));
+    MVSIM_HIP(hipMemcpyAsync(g->gt[0].p, gt_host, bytes, hipMemcpyHostToDevice, g->ctx[0]->stream));
+    for (int phase = 0; phase < 3; ++phase) {
+        int rc = MVSIM_OK;
+        MVSIM_NCCL(ncclGroupStart());
+        for (int i = 0; i < n && rc == MVSIM_OK; ++i) {
+            if (hipSetDevice(g->ctx[i]->device) != hipSuccess) { mvsim::set_error("hipSetDevice failed"); rc = MVSIM_EHIP; break; }
+            rc = bcast_phase(g->ctx[i], g->gt[i].as<float>(), count, 0, phase);
+        }
+        const ncclResult_t end = ncclGroupEnd();
+        if (rc != MVSIM_OK) return rc;
+        MVSIM_NCCL(end);
+    }
+    for (int d = 0; d < 3; ++d) g->dim[d] = dim[d];
+    g->have_gt = true;
+    return MVSIM_OK;
+}
+
+int mvsim_group_simulate_views(mvsim_group* g, float* const* psf_host, const int64_t kdim[3],
+                               const mvsim_view_params* params, int n_views, float* const* acq_host)
+{
+    MVSIM_CHECK_ARG(g != nullptr && psf_host != nullptr && kdim != nullptr && params != nullptr && acq_host != nullptr, "null pointer");
+    MVSIM_CHECK_ARG(g->have_gt, "no ground truth: call mvsim_group_broadcast_volume first");
+    MVSIM_CHECK_ARG(n_views >= 0, "n_views must be >= 0");
+    const int n = (int)g->ctx.size();
+    int rc = MVSIM_OK;
+    for (int v = 0; v < n_views && rc == MVSIM_OK; ++v) {
+        const int i = v % n;                                                  // view v -> device v % ndev
+        mvsim_ctx* c = g->ctx[(size_t)i];
+        if (!psf_host[v] || !acq_host[v] || params[v].inc < 1) { mvsim::set_error("invalid argument: view %d", v); rc = MVSIM_EINVAL; break; }
+        const size_t obytes = (size_t)(g->dim[0] * g->dim[1] * mvsim_extract_nz(g->dim[2], params[v].inc)) * sizeof(float);
+        if (hipSetDevice(c->device) != hipSuccess) { mvsim::set_error("hipSetDevice failed"); rc = MVSIM_EHIP; break; }
+        rc = g->acq[(size_t)i].reserve(obytes);                               // stream order makes the reuse per device safe
+        mvsim_view_outputs o = {nullptr, nullptr, nullptr, g->acq[(size_t)i].as<float>()};
+        if (rc == MVSIM_OK) rc = mvsim_simulate_view_dev(c, g->gt[(size_t)i].as<float>(), g->dim, psf_host[v], kdim, &params[v], &o, nullptr);
+        if (rc == MVSIM_OK && hipMemcpyAsync(acq_host[v], o.acq, obytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+            mvsim::set_error("download of view %d failed", v);
+            rc = MVSIM_EHIP;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(g->ctx[(size_t)i]->device);
+        if (hipStreamSynchronize(g->ctx[(size_t)i]->stream) != hipSuccess && rc == MVSIM_OK) { mvsim::set_error("stream synchronise failed"); rc = MVSIM_EHIP; }
+    }
+    return rc;
 }
 
 }  // extern "C"
