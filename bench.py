@@ -3,19 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* simulates `--views-per-gpu` views (default 8: the "512^3 volume x 8 views" workload of
-BASELINE.json) of one ground-truth volume on every rank: rotate -> attenuate -> PSF convolve -> adjust
--> slice extraction -> Poisson, device-resident (ground truth and all acquisitions stay in HBM).
-With N > 1 ranks (one process per GPU, torch.distributed / RCCL) the views of a dataset shard
-round-robin over the ranks (view v -> rank v % N); every step contains one broadcast of a ground truth
-from rank 0 over xGMI -- the only collective on the path -- and the views of this rank.  The broadcast
-is issued one dataset ahead into the second of two ground-truth buffers on its own HIP stream, so it
-overlaps the views of the current dataset (`--serial-broadcast` puts it in front of them instead).
-Scaling is weak: per-GPU work (8 views) is fixed, the dataset has 8*N views.
+A *step* simulates ONE dataset: `--views-total` views (default 8: the "512^3 volume x 8 views" workload of
+BASELINE.json, configs[1] per view, configs[2] sharding) of one ground-truth volume -- rotate -> attenuate -> PSF
+convolve -> adjust -> slice extraction -> Poisson, device-resident (ground truth and all acquisitions stay in HBM).
+With N > 1 ranks (one process per GPU) the views shard round-robin, view v -> rank v % N
+(SimulateMultiViewDataset.java:567 iterates independent views), and every step contains one broadcast of a ground
+truth from rank 0 over xGMI -- the only collective on the path, issued through the C ABI
+(mvsim_comm_broadcast_volume: scatter + all-gather over all links).  Scaling is STRONG by default: the dataset has 8
+views whatever N is (N = 8: one view per GPU).  The broadcast is issued one dataset ahead into the second of two
+ground-truth buffers on its own HIP stream, so it overlaps the views of the current dataset (`--serial-broadcast` puts it
+in front of them instead).  `--scaling weak` keeps 8 views PER GPU instead (dataset of 8 N views).
 
 Rank 0 prints ONE JSON line (schema in the task contract) including
-  roofline     -- HBM roofline of the dominant stage, algorithmic bytes / HIP-event time
+  roofline     -- HBM roofline of the dominant stage: algorithmic bytes / HIP-event time, plus the PMC-measured traffic
+                  of the same stage (profiles/r02_traffic.json, valid only for the kernel sources it was measured on)
   cpu_baseline -- the CPU oracle (restatement of the reference's ImgLib2 path) on a bounded sample
+  end_to_end   -- N = 1: the same views with page-locked HOST buffers in and out (PCIe-inclusive; never `value`)
+  size_1024    -- N = 1: one 1024^3 view, same stage timings and roofline keys
 """
 from __future__ import annotations
 
@@ -34,12 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-
-# HBM bytes per view and stage measured with rocprofv3 PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes) for
-# the default workload; key = (volume edge, PSF edge, inc).  Source: profiles/r01_e_pmc_hbm_traffic.txt
-MEASURED_TRAFFIC = {
-    (512, 31, 1): {"rotate_attenuate": 1.06e9, "convolve": 6.41e9, "extract_poisson": 1.73e9},
-}
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def parse_args():
@@ -49,19 +48,28 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512, help="cubic volume edge (512 = BASELINE configs[1])")
     ap.add_argument("--psf", type=int, default=31, help="cubic PSF edge")
-    ap.add_argument("--views-per-gpu", type=int, default=8)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: --views-total views per dataset whatever N is (BASELINE configs[2]: 8 views, one per GPU "
+                         "at N = 8); weak: --views-per-gpu views on every GPU")
+    ap.add_argument("--views-total", type=int, default=8)
+    ap.add_argument("--views-per-gpu", type=int, default=8, help="weak scaling only")
     ap.add_argument("--inc", type=int, default=1, help="lightsheet spacing (1 = convolve+noise target)")
     ap.add_argument("--snr", type=float, default=25.0)
     ap.add_argument("--conv-method", type=int, default=1, help="1 FFT, 2 direct stencil")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer (PCIe-inclusive) record")
+    ap.add_argument("--no-size-1024", action="store_true", help="skip the 1024^3 sub-record")
     ap.add_argument("--cpu-slab", type=int, default=64, help="z extent of the CPU-baseline sample slab")
-    ap.add_argument("--stage-timing", action="store_true", default=True)
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts/HIP streams per GPU; with 2 the views alternate between them so that the VALU-bound "
-                         "Poisson kernel of one view overlaps the HBM-bound passes of the next (+4 %% throughput, but "
-                         "per-kernel durations then include time sharing; the default keeps the roofline clean)")
+                         "Poisson kernel of one view overlaps the HBM-bound passes of the next (per-kernel durations then "
+                         "include time sharing; the default keeps the roofline clean)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the N > 1 control flow with several ranks on one GPU)")
+    ap.add_argument("--collective", choices=("auto", "mvsim", "torch"), default="auto",
+                    help="who broadcasts the ground truth: the C ABI's RCCL collective (default with the nccl backend) or "
+                         "torch.distributed (gloo rehearsals: RCCL cannot place two ranks on one GPU)")
+    ap.add_argument("--broadcast", choices=("scatter_allgather", "ring"), default="scatter_allgather")
     ap.add_argument("--serial-broadcast", action="store_true",
                     help="N > 1: broadcast the ground truth at the start of each step instead of one step ahead")
     return ap.parse_args()
@@ -79,7 +87,7 @@ def cpu_baseline(gt: np.ndarray, psf_raw: np.ndarray, degrees: int, inc: int, sn
     sub = np.ascontiguousarray(gt[z0:z0 + slab])
     t = {}
     t0 = time.perf_counter(); rot = oracle.rotate_around_axis(sub, 0, degrees); t["rotate"] = time.perf_counter() - t0
-    t0 = time.perf_counter(); att = oracle.attenuate3d(rot, 0.01); t["attenuate"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); att = oracle.attenuate3d(rot, float(np.float32(0.01))); t["attenuate"] = time.perf_counter() - t0
     psf = psf_raw.copy()
     t0 = time.perf_counter(); con = oracle.convolve_fft(att, psf, workers=-1); t["convolve_fft"] = time.perf_counter() - t0
     t0 = time.perf_counter(); oracle.adjust_image(con, 1e-4, 1.0); t["adjust"] = time.perf_counter() - t0
@@ -100,6 +108,167 @@ def cpu_baseline(gt: np.ndarray, psf_raw: np.ndarray, degrees: int, inc: int, sn
                    f"reference-exact Poisson timed on {nsl} slices and scaled to {n_extract}"),
         "seconds": {k: round(v, 3) for k, v in t.items()},
     }
+
+
+def load_traffic(n: int, psf: int, inc: int, streams: int, conv_method: int, kernel_sha: str):
+    """PMC-measured HBM bytes per view and stage (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), written
+    by tools/pmc_traffic.py --json.  Valid only for the workload and the kernel sources it was collected on."""
+    if not os.path.exists(TRAFFIC_JSON):
+        return None, f"{os.path.relpath(TRAFFIC_JSON, ROOT)} not present"
+    rec = json.load(open(TRAFFIC_JSON))
+    w = rec.get("workload", {})
+    if (w.get("size"), w.get("psf"), w.get("inc")) != (n, psf, inc):
+        return None, f"profiled workload {w} differs from this run"
+    if streams != 1 or conv_method != 1:
+        return None, "profiled with one stream on the FFT path; this run differs"
+    if rec.get("kernel_sha") != kernel_sha:
+        return None, f"kernel sources changed since the counters were collected ({rec.get('kernel_sha')} != {kernel_sha})"
+    return rec, None
+
+
+def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: int, conv_method: int, traffic, traffic_note):
+    """Roofline object from per-stage HIP-event times (ms): algorithmic bytes of SURVEY.md 8d per reference stage."""
+    k3 = psf_edge ** 3
+    alg = {
+        "rotate_attenuate": 16 * nvox,               # rotate 8N + attenuate 8N (one fused kernel)
+        "convolve": 8 * nvox + 4 * k3,               # + PSF spectrum
+        "extract_poisson": 8 * nprime,
+    }
+    ms = {
+        "rotate_attenuate": stage["rotate_ms"] + stage["attenuate_ms"],
+        "convolve": stage["psf_ms"] + stage["convolve_ms"] + stage["adjust_ms"],
+        "extract_poisson": stage["extract_ms"],
+    }
+    per_view = (traffic or {}).get("per_view_bytes", {})
+    stages = {}
+    for k in alg:
+        gbps = alg[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0
+        stages[k] = {"algorithmic_bytes": alg[k], "ms": round(ms[k], 4), "GBps": gbps, "frac": gbps / HBM_PEAK_GBS}
+        if k in per_view and ms[k] > 0:
+            stages[k]["traffic"] = per_view[k]
+            stages[k]["hbm_measured"] = per_view[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    dom = max(ms, key=ms.get)
+    b_view = 24 * nvox + 8 * nprime
+    b_cn = 8 * nvox + 8 * nprime
+    cn_ms = ms["convolve"] + ms["extract_poisson"]
+    names = {
+        "convolve": "convolve stage: PSF (x,y) spectrum (k_fft_x_r2c, k_fft_lines<FWD,sparse>), k_fft_x_r2c, k_fft_lines<FWD>, "
+                    "k_zconv (direct z convolution), k_fft_lines<INV>, k_fft_x_c2r (+ adjust/Poisson epilogue when fused), "
+                    "k_reduce_partials",
+        "extract_poisson": "extract stage: k_extract4_noise + k_poisson_resolve",
+        "rotate_attenuate": "k_rotate_attenuate_axis0",
+    }
+    passes = None
+    geo = (C.c_int64 * 5)()
+    if conv_method == 1 and mvs._lib.load().mvsim_fft_geometry((C.c_int64 * 3)(n, n, n), (C.c_int64 * 3)(psf_edge, psf_edge, psf_edge), geo) == 0:
+        px, py_, planes, hxp, zdirect = (int(v) for v in geo)
+        cplx = 8 * hxp * py_ * planes
+        pb = {"A k_fft_x_r2c": (4 * nvox + cplx, stage["pass_a_ms"]),
+              "B k_fft_lines<FWD>": (2 * cplx, stage["pass_b_ms"]),
+              ("C k_zconv" if zdirect else "C k_fft_lines<CONV>"): (2 * cplx + (0 if zdirect else cplx), stage["pass_c_ms"]),
+              "D k_fft_lines<INV>": (2 * cplx, stage["pass_d_ms"]),
+              "E k_fft_x_c2r": (cplx + 4 * nvox, stage["pass_e_ms"])}
+        passes = {k: {"bytes": b, "ms": round(t, 4), "GBps": b / (t * 1e-3) / 1e9, "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                  for k, (b, t) in pb.items() if t > 0}
+    rec = {
+        "bound": "hbm", "kernel": names[dom],
+        "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stages[dom]["frac"],
+        # HBM bytes of the dominant stage per view from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE,
+        # separate passes of this same command (profiles/r02_traffic.json); null when that record does not describe
+        # this build / workload
+        "traffic": stages[dom].get("traffic"),
+        "hbm_measured": stages[dom].get("hbm_measured"),
+        "algorithmic_bytes": alg[dom], "launch_ms": ms[dom],
+        "stages": stages,
+        "whole_view": {"bytes": b_view, "ms": stage["total_ms"],
+                       "frac": b_view / (stage["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "convolve_noise": {"bytes": b_cn, "ms": cn_ms, "frac": b_cn / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+        "passes": passes,
+    }
+    if traffic is None:
+        rec["traffic_note"] = traffic_note
+    else:
+        rec["traffic_source"] = {"file": os.path.relpath(TRAFFIC_JSON, ROOT), "kernel_sha": traffic.get("kernel_sha"),
+                                 "views_profiled": traffic.get("views_profiled")}
+        tv = sum(per_view.values())
+        rec["whole_view"]["traffic"] = tv
+        rec["whole_view"]["hbm_measured"] = tv / (stage["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return rec
+
+
+def end_to_end_record(mvs, dev_index: int, gt_host: np.ndarray, psfs_raw: list, angles: list, inc: int, snr: float) -> dict:
+    """The JNI boundary's view of the same workload: page-locked HOST buffers in and out through
+    mvsim_simulate_view_async / mvsim_wait (upload(v+1) || compute(v) || download(v-1)).  Two flavours: the view loop of
+    `main` (the SAME ground truth for every angle, SMVD:567-585: uploaded once, one acquisition comes back per view) and
+    a fresh ground truth for every view (0.54 GB up + 0.54 GB down per 512^3 view)."""
+    n = gt_host.shape[0]
+    nzo = (n - 1) // inc + 1
+    out = {}
+    with mvs.Context(dev_index) as c:
+        gts = [c.pinned_empty(gt_host.shape) for _ in range(2)]
+        for g in gts:
+            g[...] = gt_host
+        acq = [c.pinned_empty((nzo, n, n)) for _ in range(3)]
+        params = [c.view_params(degrees=a, inc=inc, snr=snr, seed=464232194, stream=v, conv_method=1) for v, a in enumerate(angles)]
+
+        def run(fresh_gt: bool, reps: int):
+            tickets = []
+            gen = 0
+            t0 = time.perf_counter()
+            for r in range(reps):
+                for v in range(len(angles)):
+                    i = r * len(angles) + v
+                    if fresh_gt:
+                        gen += 1
+                    tickets.append(c.simulate_view_async(gts[i % 2] if fresh_gt else gts[0], psfs_raw[v % len(psfs_raw)].copy(), params[v],
+                                                         {"acq": acq[i % 3]}, gt_generation=gen))
+                    if i >= 2:
+                        c.wait(tickets[i - 2])                      # keeps at most two views outstanding: acq[i % 3] is free again
+            for t in tickets[-2:]:
+                c.wait(t)
+            return (time.perf_counter() - t0) / (reps * len(angles))
+        run(False, 1)                                               # warm-up: workspaces, page tables
+        for key, fresh in (("same_ground_truth", False), ("fresh_ground_truth_per_view", True)):
+            dt = run(fresh, 2)
+            out[key] = {"ms_per_view": dt * 1e3, "views_per_s": 1.0 / dt, "Mvoxel_per_s": n ** 3 / dt / 1e6,
+                        "host_bytes_per_view": (4 * n ** 3 if fresh else 0) + 4 * n * n * nzo}
+        assert float(acq[0].max()) > 0
+        del gts, acq
+    out["note"] = ("page-locked host buffers in and out (mvsim_host_alloc), mvsim_simulate_view_async + mvsim_wait: two staging "
+                   "sets, three HIP streams; PCIe-inclusive, reported beside `value`, never as `value`")
+    return out
+
+
+def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.ndarray, inc: int, snr: float) -> dict:
+    """north_star's second size: one 1024^3 view (31^3 PSF, inc as the main run), device-resident, stage times by HIP
+    events.  The ground truth is the 512^3 phantom up-sampled 2x on the device (spheres of twice the radius: the
+    character of the phantom at that size, SimulateMultiViewDataset.java:436-522 scales the radii with the canvas)."""
+    n = 1024
+    g = gt_dev_512.view(512, 512, 512)
+    g = g.repeat_interleave(2, dim=0).repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous().view(-1)
+    nzo = (n - 1) // inc + 1
+    acq = torch.empty(n * n * nzo, dtype=torch.float32, device=dev)
+    with mvs.Context(dev_index) as c:
+        p = c.view_params(degrees=60, inc=inc, snr=snr, seed=464232194, stream=0, conv_method=1)
+        c.simulate_view_dev(g.data_ptr(), (n, n, n), psf_raw.copy(), p, acq.data_ptr())
+        c.synchronize()
+        c.enable_timing(True)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            c.simulate_view_dev(g.data_ptr(), (n, n, n), psf_raw.copy(), p, acq.data_ptr())
+        c.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        stage = c.timings()
+        c.enable_timing(False)
+        rl = roofline_record(mvs, stage, n ** 3, n * n * nzo, n, psf_raw.shape[0], 1, None, "not profiled at this size")
+    mean_count = float(acq[: n * n].double().mean().item())
+    del acq, g
+    torch.cuda.empty_cache()
+    return {"workload": f"1024^3 float volume, 1 view, {psf_raw.shape[0]}^3 PSF, inc={inc}, SNR {snr:g}, device-resident",
+            "views": reps, "ms_per_view": wall * 1e3, "value": n ** 3 / wall / 1e6, "unit": "Mvoxel/s",
+            "first_plane_mean_count": mean_count, "roofline": rl}
 
 
 def main():
@@ -124,24 +293,26 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    collective = args.collective
+    if collective == "auto":
+        collective = "mvsim" if args.backend == "nccl" else "torch"
 
     mvs = importlib.import_module("multiview-simulation_amd")
     synth = importlib.import_module("multiview-simulation_amd.synthetic")
+    build = importlib.import_module("multiview-simulation_amd.build")
 
     n = args.size
     dims = (n, n, n)
     nvox = n ** 3
-    views_per_gpu = args.views_per_gpu
-    total_views = views_per_gpu * world
+    total_views = args.views_total if args.scaling == "strong" else args.views_per_gpu * world
     my_views = mvs.shard_views(total_views, world, rank)
-    angles = [15 + (360 * v) // total_views for v in range(total_views)]
+    angles = [15 + (360 * v) // total_views for v in range(total_views)]      # 8 views: 45-degree steps (configs[2])
     nzo = (n - 1) // args.inc + 1
 
     # synthetic inputs (rank 0 owns the ground truth; other ranks receive it by broadcast, once per step = dataset).
     # N > 1 keeps two ground-truth buffers so that the broadcast of the next dataset runs (RCCL, own stream) while
     # the views of the current one are being computed.
     gt_bufs = [torch.empty(nvox, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
-    gt_dev = gt_bufs[0]
     gt_host = None
     if rank == 0:
         gt_host = synth.sphere_phantom(n)
@@ -157,6 +328,7 @@ def main():
     ctxs = [mvs.Context(dev_index) for _ in range(max(1, args.streams))]
     ctx = ctxs[0]
     view_streams = []
+    bc_ctx = None
     if world > 1:
         # the view pipelines run on torch-owned HIP streams so that torch events can order them against the
         # broadcast stream without blocking the host
@@ -164,6 +336,14 @@ def main():
         for c, vs in zip(ctxs, view_streams):
             c.set_stream(vs.cuda_stream)
         bc_stream = torch.cuda.Stream(device=dev)
+        if collective == "mvsim":
+            # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed is only the messenger
+            box = [mvs.Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            bc_ctx = mvs.Context(dev_index)
+            bc_ctx.set_stream(bc_stream.cuda_stream)
+            bc_ctx.set_option("broadcast", args.broadcast)
+            bc_ctx.comm_init(world, rank, box[0])
     views_done = [[], []]      # per ground-truth buffer: events after the last views that read it
     bcast_done = [None, None]  # per ground-truth buffer: event after the broadcast that filled it
     step_no = [0]
@@ -172,8 +352,11 @@ def main():
         with torch.cuda.stream(bc_stream):
             for e in views_done[b]:
                 bc_stream.wait_event(e)             # readers of the previous contents have finished
-            work = dist.broadcast(gt_bufs[b], src=0, async_op=True)
-            work.wait()                             # nccl: bc_stream waits for the collective; gloo: host waits
+            if bc_ctx is not None:
+                bc_ctx.comm_broadcast_volume(gt_bufs[b].data_ptr(), nvox, 0)      # enqueued on bc_stream
+            else:
+                work = dist.broadcast(gt_bufs[b], src=0, async_op=True)
+                work.wait()                         # nccl: bc_stream waits for the collective; gloo: host waits
             e = torch.cuda.Event()
             e.record(bc_stream)
             bcast_done[b] = e
@@ -224,9 +407,8 @@ def main():
         sync()
     # per-stage HIP events are recorded inside the timed region, on the stream each view runs on (one event set
     # per view; read once after the final sync): the stage durations include whatever overlap the streams produce
-    if args.stage_timing:
-        for c in ctxs:
-            c.enable_timing(True)
+    for c in ctxs:
+        c.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -238,91 +420,60 @@ def main():
         elapsed = float(tt.item())
 
     stage = None
-    if rank == 0 and args.stage_timing:
+    if rank == 0 and my_views:
         acc = {}
         for c in ctxs:
             for k, v in c.timings().items():
                 acc[k] = acc.get(k, 0.0) + v / len(ctxs)
-            c.enable_timing(False)
         stage = acc
+    for c in ctxs:
+        c.enable_timing(False)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         views_s = total_views * args.steps / elapsed
         mvox_s = views_s * nvox / 1e6
         out = {
-            "metric": "simulated Mvoxel/s (views x input voxels / s), 512^3 volume x 8 views per GPU",
+            "metric": "simulated Mvoxel/s (views x input voxels / s), 512^3 volume x 8 views",
             "value": mvox_s, "unit": "Mvoxel/s", "views_per_s": views_s,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 (f64 attenuation/reductions/Poisson)", "data": "synthetic",
-            "config": {"workload": f"{n}^3 float volume x {views_per_gpu} views per GPU, {args.psf}^3 PSF, "
+            "config": {"workload": f"{n}^3 float volume x {total_views} views per dataset (one dataset per step), {args.psf}^3 PSF, "
                                    f"rotate+attenuate+FFT-convolve+adjust+extract(inc={args.inc})+Poisson(SNR {args.snr:g}), "
-                                   f"device-resident; BASELINE configs[1] per view, configs[2] sharding",
+                                   f"device-resident; BASELINE configs[1] per view, configs[2] sharding (view v on GPU v % N)",
                        "volume": [n, n, n], "psf": [args.psf] * 3, "views_total": total_views,
-                       "views_per_gpu": views_per_gpu, "inc": args.inc, "snr": args.snr,
+                       "views_this_gpu": len(my_views), "inc": args.inc, "snr": args.snr,
                        "conv_method": "fft (hand-written LDS FFT passes in x and y, direct Kz-tap convolution in z; rocFFT only for unsupported sizes)" if args.conv_method == 1 else "direct stencil",
                        "streams_per_gpu": len(ctxs),
-                       "collective": ("none" if world == 1 else "RCCL broadcast of the ground truth, one per step, "
-                                      + ("serial" if args.serial_broadcast else "issued one dataset ahead"))},
+                       "collective": ("none" if world == 1 else
+                                      (f"mvsim_comm_broadcast_volume ({args.broadcast}, RCCL over xGMI)" if bc_ctx is not None
+                                       else f"torch.distributed.broadcast ({args.backend})")
+                                      + ", one per step, " + ("serial" if args.serial_broadcast else "issued one dataset ahead"))},
         }
         if stage:
-            nprime = n * n * nzo
-            k3 = args.psf ** 3
-            # ALGORITHMIC bytes per reference stage: each stage reads its input once and
-            # writes its output once; adjustImage costs nothing extra on the fused path.
-            alg = {
-                "rotate_attenuate": 16 * nvox,               # rotate 8N + attenuate 8N (one fused kernel)
-                "convolve": 8 * nvox + 4 * k3,               # + PSF spectrum, 8 launches
-                "extract_poisson": 8 * nprime,               # 2 launches
-            }
-            ms = {
-                "rotate_attenuate": stage["rotate_ms"] + stage["attenuate_ms"],
-                "convolve": stage["psf_ms"] + stage["convolve_ms"] + stage["adjust_ms"],
-                "extract_poisson": stage["extract_ms"],
-            }
-            stages = {k: {"algorithmic_bytes": alg[k], "ms": round(ms[k], 4),
-                          "GBps": alg[k] / (ms[k] * 1e-3) / 1e9, "frac": alg[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                      for k in alg}
-            dom = max(ms, key=ms.get)
-            b_view = 24 * nvox + 8 * nprime
-            b_cn = 8 * nvox + 8 * nprime
-            cn_ms = ms["convolve"] + ms["extract_poisson"]
-            names = {
-                "convolve": "convolve stage = 8 launches: PSF (x,y) spectrum (k_fft_x_r2c, k_fft_lines<FWD,sparse>), "
-                            "k_fft_x_r2c, k_fft_lines<FWD>, k_zconv (direct z convolution), k_fft_lines<INV>, k_fft_x_c2r, "
-                            "k_reduce_partials",
-                "extract_poisson": "extract stage = k_extract4_noise + k_poisson_resolve",
-                "rotate_attenuate": "k_rotate_attenuate_axis0",
-            }
-            # the five passes of the convolution, each against ITS OWN compulsory traffic (read its input once, write its
-            # output once): HIP events nested inside the convolve stage, same timed region
-            passes = None
-            geo = (C.c_int64 * 5)()
-            if args.conv_method == 1 and mvs._lib.load().mvsim_fft_geometry((C.c_int64 * 3)(n, n, n), (C.c_int64 * 3)(args.psf, args.psf, args.psf), geo) == 0:
-                px, py_, planes, hxp, zdirect = (int(v) for v in geo)
-                cplx = 8 * hxp * py_ * planes
-                pb = {"A k_fft_x_r2c": (4 * nvox + cplx, stage["pass_a_ms"]),
-                      "B k_fft_lines<FWD>": (2 * cplx, stage["pass_b_ms"]),
-                      ("C k_zconv" if zdirect else "C k_fft_lines<CONV>"): (2 * cplx + (0 if zdirect else cplx), stage["pass_c_ms"]),
-                      "D k_fft_lines<INV>": (2 * cplx, stage["pass_d_ms"]),
-                      "E k_fft_x_c2r": (cplx + 4 * nvox, stage["pass_e_ms"])}
-                passes = {k: {"bytes": b, "ms": round(t, 4), "GBps": b / (t * 1e-3) / 1e9, "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                          for k, (b, t) in pb.items() if t > 0}
-            out["roofline"] = {
-                "bound": "hbm", "kernel": names[dom],
-                "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stages[dom]["frac"],
-                # HBM bytes per launch group from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate
-                # passes of this same command: profiles/r01_c_pmc_hbm_traffic.txt (not collected live)
-                "traffic": MEASURED_TRAFFIC.get((n, args.psf, args.inc), {}).get(dom),
-                "algorithmic_bytes": alg[dom], "launch_ms": ms[dom],
-                "stages": stages,
-                "whole_view": {"bytes": b_view, "ms": stage["total_ms"],
-                               "frac": b_view / (stage["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "convolve_noise": {"bytes": b_cn, "ms": cn_ms, "frac": b_cn / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "stage_ms": {k: round(v, 4) for k, v in stage.items()},
-                "passes": passes,
-            }
+            kernel_sha = build.source_sha()
+            traffic, note = load_traffic(n, args.psf, args.inc, len(ctxs), args.conv_method, kernel_sha)
+            out["roofline"] = roofline_record(mvs, stage, nvox, n * n * nzo, n, args.psf, args.conv_method, traffic, note)
+            out["kernel_sha"] = kernel_sha
+    for c in ctxs:
+        c.close()
+    if bc_ctx is not None:
+        bc_ctx.close()
+
+    if rank == 0:
+        if world == 1 and not args.no_end_to_end:
+            try:
+                out["end_to_end"] = end_to_end_record(mvs, dev_index, gt_host, [psf_raw], angles, args.inc, args.snr)
+            except Exception as e:  # reported extras never cost the GPU line
+                out["end_to_end"] = {"failed": repr(e)}
+        if world == 1 and not args.no_size_1024 and n == 512:
+            try:
+                acq.clear()
+                torch.cuda.empty_cache()
+                out["size_1024"] = size_1024_record(mvs, torch, dev, dev_index, gt_bufs[0], psf_raw, args.inc, args.snr)
+            except Exception as e:
+                out["size_1024"] = {"failed": repr(e)}
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(gt_host, psf_raw, angles[0], args.inc, args.snr, args.cpu_slab)
@@ -331,8 +482,6 @@ def main():
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
 
-    for c in ctxs:
-        c.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -124,6 +124,17 @@ int mvsim_compute_weight_image(mvsim_ctx* ctx, const int64_t dim[3], float* out)
  * random stream) runs on the host, the max-compositing of the small spheres on the GPU.  n_spheres may be NULL. */
 int mvsim_draw_spheres(mvsim_ctx* ctx, float* img, const int64_t dim[3], double min_value, double max_value,
                        int scale, int half_pixel_offset, uint64_t* rnd_state, int64_t* n_spheres);
+/* The GPU half of drawSpheres for hosts that walk the large sphere THEMSELVES with the caller's java.util.Random (any
+ * subclass, SimulateTileStitching.java:93,108 passes `new Random(seed)`): max-composite n small spheres -- ImgLib2
+ * HyperSphere geometry, nested truncated radii -- into img, in place.  A sphere that leaves the image is rejected
+ * (the reference throws there). */
+typedef struct mvsim_sphere {
+    int32_t cx, cy, cz;       /* centre                                   */
+    int32_t radius;           /* rnd.nextInt(10*scale) + 1 (SMVD:468)     */
+    float   value;            /* (float) intensity, Math.max-composited   */
+} mvsim_sphere;
+int mvsim_splat_spheres(mvsim_ctx* ctx, float* img, const int64_t dim[3], const mvsim_sphere* spheres, int64_t n);
+int mvsim_splat_spheres_dev(mvsim_ctx* ctx, float* img_dev, const int64_t dim[3], const mvsim_sphere* spheres_host, int64_t n);
 /* SMVD:394-424 downSample2x: out has dim[d]/2 - 1 samples per dimension. */
 int mvsim_downsample2x(mvsim_ctx* ctx, const float* in, const int64_t dim[3], float* out);
 
@@ -195,6 +206,31 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3],
                         float* psf_host, const int64_t kdim[3],
                         const mvsim_view_params* params, const mvsim_view_outputs* out,
                         double* correction);
+
+/* Pipelined host-buffer views for a caller that loops over views (SMVD:567-613, SimulateTileStitching.java:93-111):
+ * the call enqueues  upload(gt) -> view -> download(outputs)  on three HIP streams over two staging sets and returns a
+ * ticket at once, so that upload(v+1), compute(v) and download(v-1) overlap; with page-locked buffers (mvsim_host_alloc)
+ * a 512^3 view costs one PCIe transfer time instead of the sum of three phases.  gt_host, psf_host and every output
+ * buffer must stay valid and untouched until mvsim_wait(ticket) returns; at most two tickets may be outstanding (a
+ * third call waits for the oldest).  The ground truth is uploaded again only when its pointer or `gt_generation`
+ * differs from what the staging set already holds (pass a new generation after changing the buffer's contents; the
+ * view loop of `main` passes the same `rendered` image for every angle).  psf_host is normalised in place before the
+ * call returns.  Intermediates (rot/att/con) may be requested; they are single-buffered on the device, so views that ask
+ * for them do not overlap with their neighbours' downloads. */
+int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt_host, uint64_t gt_generation, const int64_t dim[3],
+                              float* psf_host, const int64_t kdim[3], const mvsim_view_params* params,
+                              const mvsim_view_outputs* out_host, int64_t* ticket);
+/* Blocks until the view behind `ticket` has landed in its host buffers; *correction (may be NULL) receives the
+ * adjustImage factor.  Tickets may be waited for in any order, each once. */
+int mvsim_wait(mvsim_ctx* ctx, int64_t ticket, double* correction);
+/* Host buffers given as z slabs: volumes beyond 2^31-1 voxels do not fit one Java array / direct buffer
+ * (SimulateMultiViewDataset.java:109 uses ArrayImg and cannot hold them at all), so the ground truth arrives as
+ * n_gt_slabs pointers of gt_slab_nz[i] planes each (sum = dim[2]) and the acquisition leaves as n_acq_slabs pointers of
+ * acq_slab_nz[j] planes each (sum = mvsim_extract_nz(dim[2], inc)).  Same arithmetic as mvsim_simulate_view. */
+int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, const int64_t* gt_slab_nz, int n_gt_slabs,
+                               const int64_t dim[3], float* psf_host, const int64_t kdim[3],
+                               const mvsim_view_params* params, float* const* acq_slabs, const int64_t* acq_slab_nz,
+                               int n_acq_slabs, double* correction);
 
 /* ---- per-stage device timings of the last simulate_view / stage call (milliseconds) ------ */
 typedef struct mvsim_timings {

@@ -3,6 +3,8 @@ package net.preibisch.simulation.gpu;
 import java.nio.ByteBuffer;
 import java.nio.ByteOrder;
 import java.nio.FloatBuffer;
+import java.util.ArrayDeque;
+import java.util.HashMap;
 
 import net.imglib2.Cursor;
 import net.imglib2.Interval;
@@ -14,39 +16,100 @@ import net.imglib2.img.basictypeaccess.array.FloatArray;
 import net.imglib2.type.numeric.real.FloatType;
 import net.imglib2.view.Views;
 
-/** Marshalling between ImgLib2 images and the flat x-fastest float32 layout of the C ABI. */
+/**
+ * Marshalling between ImgLib2 images and the flat x-fastest float32 layout of the C ABI.
+ *
+ * Staging memory comes as {@link Block}s: PAGE-LOCKED bytes (mvsim_host_alloc wrapped by NewDirectByteBuffer; copies
+ * between such a block and HBM run at PCIe speed) together with their float view.  A block is OWNED by whoever asked
+ * for it and must be closed (try-with-resources in every facade method): close() hands it back to a small per-thread
+ * pool keyed by size -- page-locking is slow, so blocks are reused -- and the pool is capped: beyond
+ * {@code -Dmvsim.pool.bytes} (default 4 GiB) per thread a closed block is freed at once (mvsim_host_free).  The JVM never
+ * frees NewDirectByteBuffer memory it did not allocate, so nothing here relies on the garbage collector; the pool itself
+ * is emptied when the thread's native context goes away ({@link GpuContextPool}).
+ */
 final class Buffers
 {
 	private Buffers() {}
 
-	/**
-	 * Staging buffers come from a small per-thread pool of PAGE-LOCKED blocks (mvsim_host_alloc wrapped by
-	 * NewDirectByteBuffer): copies between such a block and HBM run at PCIe speed (30 ms per 512^3 view against 50 ms
-	 * from pageable memory), and page-locking is slow, so blocks are kept and reused by size instead of being
-	 * allocated per call.  Falls back to an ordinary direct buffer when the native allocation fails.
-	 */
-	private static final ThreadLocal< java.util.HashMap< Long, java.util.ArrayDeque< ByteBuffer > > > POOL =
-			ThreadLocal.withInitial( java.util.HashMap::new );
-
-	static FloatBuffer direct( final long n )
+	static final class Block implements AutoCloseable
 	{
-		if ( n > Integer.MAX_VALUE / 4 )
-			throw new IllegalArgumentException( "image has more than 2^29 voxels: pass z-slabs (see INTEGRATION.md)" );
-		final long bytes = 4 * n;
-		final java.util.ArrayDeque< ByteBuffer > free = POOL.get().get( bytes );
-		ByteBuffer b = free != null ? free.poll() : null;
-		if ( b == null )
-			b = MvsimNative.allocPinned( GpuContextPool.get(), bytes );
-		if ( b == null )
-			b = ByteBuffer.allocateDirect( (int)bytes );
-		b.clear();
-		return b.order( ByteOrder.nativeOrder() ).asFloatBuffer();
+		final ByteBuffer bytes;
+		final FloatBuffer floats;
+		final boolean pinned;
+		private boolean open = true;
+
+		Block( final ByteBuffer bytes, final boolean pinned )
+		{
+			this.bytes = bytes;
+			this.pinned = pinned;
+			bytes.clear();
+			this.floats = bytes.order( ByteOrder.nativeOrder() ).asFloatBuffer();
+		}
+
+		@Override
+		public void close()
+		{
+			if ( open )
+			{
+				open = false;
+				recycle( this );
+			}
+		}
 	}
 
-	/** hand a staging block back to the pool once its contents have been copied into an Img */
-	static void recycle( final ByteBuffer block )
+	private static final class Pool
 	{
-		POOL.get().computeIfAbsent( ( long )block.capacity(), k -> new java.util.ArrayDeque<>() ).add( block );
+		final HashMap< Long, ArrayDeque< ByteBuffer > > free = new HashMap<>();
+		long pooledBytes = 0;
+	}
+
+	private static final ThreadLocal< Pool > POOL = ThreadLocal.withInitial( Pool::new );
+	private static final long POOL_CAP = Long.getLong( "mvsim.pool.bytes", 4L << 30 );
+
+	/** a staging block of n floats (page-locked when the native allocation succeeds) */
+	static Block direct( final long n )
+	{
+		if ( n > Integer.MAX_VALUE / 4 )
+			throw new IllegalArgumentException( "image has more than 2^29 voxels: pass z-slabs (simulateViewSlabs, INTEGRATION.md)" );
+		final long bytes = 4 * Math.max( n, 1 );
+		final Pool pool = POOL.get();
+		final ArrayDeque< ByteBuffer > q = pool.free.get( bytes );
+		ByteBuffer b = q != null ? q.poll() : null;
+		if ( b != null )
+		{
+			pool.pooledBytes -= bytes;
+			return new Block( b, true );
+		}
+		b = MvsimNative.allocPinned( GpuContextPool.get(), bytes );
+		if ( b != null )
+			return new Block( b, true );
+		return new Block( ByteBuffer.allocateDirect( ( int ) bytes ), false );    // ordinary direct memory: the GC owns it
+	}
+
+	private static void recycle( final Block block )
+	{
+		if ( !block.pinned )
+			return;
+		final Pool pool = POOL.get();
+		final long bytes = block.bytes.capacity();
+		if ( pool.pooledBytes + bytes > POOL_CAP )
+		{
+			MvsimNative.freePinned( block.bytes );
+			return;
+		}
+		pool.free.computeIfAbsent( bytes, k -> new ArrayDeque<>() ).add( block.bytes );
+		pool.pooledBytes += bytes;
+	}
+
+	/** free every pooled block of the calling thread (called when its native context is destroyed) */
+	static void drain()
+	{
+		final Pool pool = POOL.get();
+		for ( final ArrayDeque< ByteBuffer > q : pool.free.values() )
+			for ( final ByteBuffer b : q )
+				MvsimNative.freePinned( b );
+		pool.free.clear();
+		pool.pooledBytes = 0;
 	}
 
 	static long[] dims( final Interval i )
@@ -59,37 +122,47 @@ final class Buffers
 
 	static long size( final long[] d ) { return d[ 0 ] * d[ 1 ] * d[ 2 ]; }
 
-	/** Any RAI view (zero-min or not, SimulateTileStitching.java:152-156) -> direct buffer in flat iteration order. */
-	static FloatBuffer toBuffer( final RandomAccessibleInterval< FloatType > rai )
+	/** Any RAI view (zero-min or not, SimulateTileStitching.java:152-156) -> staging block in flat iteration order. */
+	static Block toBlock( final RandomAccessibleInterval< FloatType > rai )
 	{
-		final FloatBuffer b = direct( size( dims( rai ) ) );
-		if ( rai instanceof ArrayImg && ( (ArrayImg< ?, ? >)rai ).update( null ) instanceof FloatArray )
+		final Block blk = direct( size( dims( rai ) ) );
+		final FloatBuffer b = blk.floats;
+		try
 		{
-			b.put( ( (FloatArray)( (ArrayImg< ?, ? >)rai ).update( null ) ).getCurrentStorageArray() );
+			if ( rai instanceof ArrayImg && ( ( ArrayImg< ?, ? > ) rai ).update( null ) instanceof FloatArray )
+			{
+				b.put( ( ( FloatArray ) ( ( ArrayImg< ?, ? > ) rai ).update( null ) ).getCurrentStorageArray() );
+			}
+			else
+			{
+				final Cursor< FloatType > c = Views.flatIterable( rai ).cursor();
+				while ( c.hasNext() )
+					b.put( c.next().get() );
+			}
+			b.rewind();
+			return blk;
 		}
-		else
+		catch ( final RuntimeException e )
 		{
-			final Cursor< FloatType > c = Views.flatIterable( rai ).cursor();
-			while ( c.hasNext() )
-				b.put( c.next().get() );
+			blk.close();
+			throw e;
 		}
-		b.rewind();
-		return b;
 	}
 
-	static Img< FloatType > toImg( final FloatBuffer b, final long[] d )
+	/** a fresh ArrayImg holding the block's first size(d) floats (the block stays owned by the caller) */
+	static Img< FloatType > toImg( final Block blk, final long[] d )
 	{
-		final float[] a = new float[ (int)size( d ) ];
-		b.rewind();
-		b.get( a );
+		final float[] a = new float[ ( int ) size( d ) ];
+		blk.floats.rewind();
+		blk.floats.get( a );
 		return ArrayImgs.floats( a, d );
 	}
 
 	/** Copy results back into a caller-owned image (in-place operators: normImage, adjustImage, poissonProcess). */
-	static void copyBack( final FloatBuffer b, final Iterable< FloatType > img )
+	static void copyBack( final Block blk, final Iterable< FloatType > img )
 	{
-		b.rewind();
+		blk.floats.rewind();
 		for ( final FloatType t : img )
-			t.set( b.get() );
+			t.set( blk.floats.get() );
 	}
 }

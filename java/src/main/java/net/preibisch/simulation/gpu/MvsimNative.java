@@ -6,8 +6,8 @@ import java.nio.FloatBuffer;
  * JNI binding of libmvsim.so (C ABI in include/mvsim.h).  One native context per GPU; the context is
  * not thread-safe, so {@link GpuContextPool} hands one to each calling thread.
  *
- * SOURCE ONLY in this repository: the build image has no JDK (no javac, no jni.h).  Compile on a host
- * with a JDK: see INTEGRATION.md.
+ * SOURCE ONLY in this repository: the build image has no JDK (no javac, no jni.h); this layer has never been compiled
+ * or run.  Compile on a host with a JDK: see INTEGRATION.md.
  */
 final class MvsimNative
 {
@@ -19,7 +19,8 @@ final class MvsimNative
 	static native void destroy( long ctx );                           // mvsim_destroy
 	static native int deviceCount();                                  // mvsim_device_count
 
-	// all buffers are DIRECT FloatBuffers (x fastest); dim = {nx, ny, nz}
+	// all buffers are DIRECT FloatBuffers (x fastest); dim = {nx, ny, nz}.  The shim checks every buffer's capacity against
+	// the dimensions before it touches the C ABI and throws IllegalArgumentException when one is too small.
 	static native void rotateAroundAxis( long ctx, FloatBuffer in, long[] dim, int axis, int degrees, FloatBuffer out );
 	static native void attenuate3d( long ctx, FloatBuffer in, long[] dim, double delta, FloatBuffer out );
 	static native void normImage( long ctx, FloatBuffer img, long n );
@@ -38,14 +39,31 @@ final class MvsimNative
 	/** drawSpheres (:436-522), in place; rndState[0] is the 48-bit java.util.Random state, advanced on return; returns the sphere count. */
 	static native long drawSpheres( long ctx, FloatBuffer img, long[] dim, double minValue, double maxValue, int scale,
 			boolean halfPixelOffset, long[] rndState );
+	/** mvsim_splat_spheres: geometry = { cx, cy, cz, radius } per sphere, values = one float per sphere; in place. */
+	static native void splatSpheres( long ctx, FloatBuffer img, long[] dim, int[] geometry, float[] values );
 	/** downSample2x (:394-424): out has dim/2 - 1 samples per dimension. */
 	static native void downSample2x( long ctx, FloatBuffer in, long[] dim, FloatBuffer out );
 
 	/** Cross-view weight normalisation (:615-640), in place on every buffer. */
 	static native void normalizeWeights( long ctx, FloatBuffer[] weights, long n, float osem );
 
-	/** Fused loop body of SimulateMultiViewDataset.main (:570-585); rot/att/con may be null. */
+	/** Fused loop body of SimulateMultiViewDataset.main (:570-585); rot/att/con may be null (then they never leave HBM). */
 	static native double simulateView( long ctx, FloatBuffer gt, long[] dim, FloatBuffer psf, long[] kdim,
 			int axis, int degrees, double delta, float minValue, float targetAverage, int inc, float snr, long seed, int stream,
 			FloatBuffer rot, FloatBuffer att, FloatBuffer con, FloatBuffer acq );
+
+	/** mvsim_simulate_view_async: returns a ticket at once; gt, psf and acq must stay reachable and untouched until waitView. */
+	static native long simulateViewAsync( long ctx, FloatBuffer gt, long gtGeneration, long[] dim, FloatBuffer psf, long[] kdim,
+			int axis, int degrees, double delta, float minValue, float targetAverage, int inc, float snr, long seed, int stream, FloatBuffer acq );
+	/** mvsim_wait: blocks until the view has landed; returns the adjustImage factor. */
+	static native double waitView( long ctx, long ticket );
+	/** mvsim_wait without exceptions (cleanup paths). */
+	static native void waitViewQuiet( long ctx, long ticket );
+
+	// ---- one JVM process driving several GPUs: mvsim_group_* (GpuGroup) ----
+	static native long groupCreate( int ndev );
+	static native void groupDestroy( long group );
+	static native void groupBroadcastVolume( long group, FloatBuffer gt, long[] dim );
+	static native void groupSimulateViews( long group, FloatBuffer[] psfs, long[] kdim, int[] degrees, double delta, float minValue,
+			float targetAverage, int inc, float snr, long[] seeds, FloatBuffer[] acqs );
 }

@@ -1,6 +1,7 @@
 package net.preibisch.simulation.gpu;
 
-import java.nio.FloatBuffer;
+import java.util.ArrayList;
+import java.util.List;
 import java.util.Random;
 import java.util.concurrent.ExecutorService;
 
@@ -20,7 +21,10 @@ import net.imglib2.view.Views;
  *
  * Random numbers: the reference consumes one sequential java.util.Random stream inside the Poisson loop; here
  * ONE nextLong() is drawn from the caller's Random per call and keys a counter-based generator, so callers that
- * pass new Random(seed) stay reproducible (distributional, not stream, parity: DESIGN.md).
+ * pass new Random(seed) stay reproducible (distributional, not stream, parity: DESIGN.md).  drawSpheres, whose
+ * stream the reference shares with everything else, consumes the caller's generator exactly as the reference does.
+ *
+ * SOURCE ONLY in this repository (no JDK in the build image): never compiled or run here.
  */
 public class SimulateMultiViewDatasetGPU
 {
@@ -40,28 +44,33 @@ public class SimulateMultiViewDatasetGPU
 	public static Img< FloatType > rotateAroundAxis( final RandomAccessibleInterval< FloatType > in, final int axis, final int degrees )
 	{
 		final long[] d = Buffers.dims( in );
-		final FloatBuffer out = Buffers.direct( Buffers.size( d ) );
-		MvsimNative.rotateAroundAxis( GpuContextPool.get(), Buffers.toBuffer( Views.zeroMin( in ) ), d, axis, degrees, out );
-		return Buffers.toImg( out, d );
+		try ( Buffers.Block src = Buffers.toBlock( Views.zeroMin( in ) ); Buffers.Block out = Buffers.direct( Buffers.size( d ) ) )
+		{
+			MvsimNative.rotateAroundAxis( GpuContextPool.get(), src.floats, d, axis, degrees, out.floats );
+			return Buffers.toImg( out, d );
+		}
 	}
 
 	public static Img< FloatType > attenuate3d( final RandomAccessibleInterval< FloatType > in, final double delta )
 	{
 		final long[] d = Buffers.dims( in );
-		final FloatBuffer out = Buffers.direct( Buffers.size( d ) );
-		MvsimNative.attenuate3d( GpuContextPool.get(), Buffers.toBuffer( Views.zeroMin( in ) ), d, delta, out );
-		return Buffers.toImg( out, d );
+		try ( Buffers.Block src = Buffers.toBlock( Views.zeroMin( in ) ); Buffers.Block out = Buffers.direct( Buffers.size( d ) ) )
+		{
+			MvsimNative.attenuate3d( GpuContextPool.get(), src.floats, d, delta, out.floats );
+			return Buffers.toImg( out, d );
+		}
 	}
 
 	/** The ExecutorService is accepted for signature compatibility and ignored. psf is normalised in place. */
 	public static Img< FloatType > convolve( final Img< FloatType > img, final Img< FloatType > psf, final ExecutorService service )
 	{
 		final long[] d = Buffers.dims( img ), k = Buffers.dims( psf );
-		final FloatBuffer p = Buffers.toBuffer( psf );
-		final FloatBuffer out = Buffers.direct( Buffers.size( d ) );
-		MvsimNative.convolve( GpuContextPool.get(), Buffers.toBuffer( img ), d, p, k, 0, out );
-		Buffers.copyBack( p, psf );   // Tools.normImage( psf ) side effect of the reference (:255)
-		return Buffers.toImg( out, d );
+		try ( Buffers.Block p = Buffers.toBlock( psf ); Buffers.Block src = Buffers.toBlock( img ); Buffers.Block out = Buffers.direct( Buffers.size( d ) ) )
+		{
+			MvsimNative.convolve( GpuContextPool.get(), src.floats, d, p.floats, k, 0, out.floats );
+			Buffers.copyBack( p, psf );   // Tools.normImage( psf ) side effect of the reference (:255)
+			return Buffers.toImg( out, d );
+		}
 	}
 
 	public static Img< FloatType > extractSlices( final RandomAccessibleInterval< FloatType > in, final int inc, final float poissonSNR )
@@ -73,61 +82,118 @@ public class SimulateMultiViewDatasetGPU
 	{
 		final long[] d = Buffers.dims( in );
 		final long[] o = new long[] { d[ 0 ], d[ 1 ], ( d[ 2 ] - 1 ) / inc + 1 };
-		final FloatBuffer out = Buffers.direct( Buffers.size( o ) );
 		final long seed = poissonSNR >= 0.0 ? rnd.nextLong() : 0L;
-		MvsimNative.extractSlices( GpuContextPool.get(), Buffers.toBuffer( Views.zeroMin( in ) ), d, inc, poissonSNR, seed, 0, out );
-		return Buffers.toImg( out, o );
+		try ( Buffers.Block src = Buffers.toBlock( Views.zeroMin( in ) ); Buffers.Block out = Buffers.direct( Buffers.size( o ) ) )
+		{
+			MvsimNative.extractSlices( GpuContextPool.get(), src.floats, d, inc, poissonSNR, seed, 0, out.floats );
+			return Buffers.toImg( out, o );
+		}
 	}
 
 	public static Img< FloatType > poissonProcess( final RandomAccessibleInterval< FloatType > in, final float poissonSNR, final Random rnd )
 	{
 		final long[] d = Buffers.dims( in );
-		final FloatBuffer b = Buffers.toBuffer( Views.zeroMin( in ) );
-		MvsimNative.poissonProcess( GpuContextPool.get(), b, Buffers.size( d ), poissonSNR, rnd.nextLong(), 0, 0L );
-		final long[] shape = new long[ in.numDimensions() ];
-		in.dimensions( shape );
-		return Buffers.toImg( b, in.numDimensions() == 3 ? d : new long[] { d[ 0 ], d[ 1 ], 1 } );
+		try ( Buffers.Block b = Buffers.toBlock( Views.zeroMin( in ) ) )
+		{
+			MvsimNative.poissonProcess( GpuContextPool.get(), b.floats, Buffers.size( d ), poissonSNR, rnd.nextLong(), 0, 0L );
+			return Buffers.toImg( b, in.numDimensions() == 3 ? d : new long[] { d[ 0 ], d[ 1 ], 1 } );
+		}
 	}
 
 	public static Img< FloatType > makeIsotropic( final RandomAccessibleInterval< FloatType > in, final int inc )
 	{
 		final long[] d = Buffers.dims( in );
 		final long[] o = new long[] { d[ 0 ], d[ 1 ], ( d[ 2 ] - 1 ) * inc + 1 };
-		final FloatBuffer out = Buffers.direct( Buffers.size( o ) );
-		MvsimNative.makeIsotropic( GpuContextPool.get(), Buffers.toBuffer( Views.zeroMin( in ) ), d, inc, out );
-		return Buffers.toImg( out, o );
+		try ( Buffers.Block src = Buffers.toBlock( Views.zeroMin( in ) ); Buffers.Block out = Buffers.direct( Buffers.size( o ) ) )
+		{
+			MvsimNative.makeIsotropic( GpuContextPool.get(), src.floats, d, inc, out.floats );
+			return Buffers.toImg( out, o );
+		}
 	}
 
 	public static Img< FloatType > computeWeightImage( final RandomAccessibleInterval< FloatType > in, final double delta )
 	{
 		final long[] d = Buffers.dims( in );
-		final FloatBuffer out = Buffers.direct( Buffers.size( d ) );
-		MvsimNative.computeWeightImage( GpuContextPool.get(), d, out );
-		return Buffers.toImg( out, d );
+		try ( Buffers.Block out = Buffers.direct( Buffers.size( d ) ) )
+		{
+			MvsimNative.computeWeightImage( GpuContextPool.get(), d, out.floats );
+			return Buffers.toImg( out, d );
+		}
 	}
 
-	/** simulate (:366-392): sphere cloud at 2x resolution, then 2x down-sampling; rnd must be a {@link GpuRandom}. */
+	/** simulate (:366-392): sphere cloud at 2x resolution, then 2x down-sampling; any java.util.Random. */
 	public static Img< FloatType > simulate( final boolean halfPixelOffset, final Random rnd )
 	{
 		final int scale = 2;
 		final long n = ( 289 + 1 ) * scale;
-		Img< FloatType > img = new ArrayImgFactory< FloatType >().create( new long[] { n, n, n }, new FloatType() );
+		final Img< FloatType > img = new ArrayImgFactory< FloatType >().create( new long[] { n, n, n }, new FloatType() );
 		drawSpheres( img, 0, 1, scale, halfPixelOffset, rnd );
 		return downSample2x( img );
 	}
 
-	/** drawSpheres (:436-522), in place: the walk over the large sphere on the host, the small spheres on the GPU. */
+	/**
+	 * drawSpheres (:436-522), in place.  The walk over the large sphere consumes ONE sequential random stream (three draws
+	 * per voxel, five where a small sphere starts), so it runs on the host; the ~10^8 voxel updates of the small spheres
+	 * are max-composited on the GPU (Math.max makes the order irrelevant).
+	 *
+	 * ANY java.util.Random works -- SimulateTileStitching passes a plain `new Random( seed )` (:93,:108): the walk then
+	 * runs right here with the caller's generator, in the HyperSphereCursor's order (last dimension outermost, nested
+	 * truncated radii), and the (centre, radius, value) list goes to mvsim_splat_spheres.  A {@link GpuRandom} is a fast
+	 * path only: its 48-bit state crosses the boundary and the native library replays the same walk.
+	 */
 	public static void drawSpheres( final Img< FloatType > img, final double minValue, final double maxValue, final int scale,
 			final boolean halfPixelOffset, final Random rnd )
 	{
-		if ( !( rnd instanceof GpuRandom ) )
-			throw new IllegalArgumentException( "drawSpheres on the GPU continues the caller's random stream: pass a GpuRandom" );
-		final GpuRandom g = ( GpuRandom ) rnd;
-		final long[] state = new long[] { g.getState() };
-		final FloatBuffer b = Buffers.toBuffer( img );
-		MvsimNative.drawSpheres( GpuContextPool.get(), b, Buffers.dims( img ), minValue, maxValue, scale, halfPixelOffset, state );
-		g.setState( state[ 0 ] );
-		Buffers.copyBack( b, img );
+		final long[] d = Buffers.dims( img );
+		try ( Buffers.Block b = Buffers.toBlock( img ) )
+		{
+			if ( rnd instanceof GpuRandom )
+			{
+				final GpuRandom g = ( GpuRandom ) rnd;
+				final long[] state = new long[] { g.getState() };
+				MvsimNative.drawSpheres( GpuContextPool.get(), b.floats, d, minValue, maxValue, scale, halfPixelOffset, state );
+				g.setState( state[ 0 ] );
+			}
+			else
+			{
+				final long[] c = new long[] { d[ 0 ] / 2, d[ 1 ] / 2, d[ 2 ] / 2 };
+				final long R = Math.min( d[ 0 ], Math.min( d[ 1 ], d[ 2 ] ) ) / 2 - 47L * scale - 1;
+				if ( R < 0 )
+					throw new IllegalArgumentException( "drawSpheres: image too small for scale " + scale );
+				final int maxRadius = 10 * scale;
+				final long modulus = ( long ) Math.pow( 7 * scale, 3 );            // Util.pow( 7*scale, numDimensions ) (:462)
+				final int off = halfPixelOffset ? 1 : 0;
+				final List< int[] > geo = new ArrayList<>();
+				final List< Float > val = new ArrayList<>();
+				for ( long dz = -R; dz <= R; ++dz )
+				{
+					final long r1 = ( long ) Math.sqrt( R * R - dz * dz );
+					for ( long dy = -r1; dy <= r1; ++dy )
+					{
+						final long r0 = ( long ) Math.sqrt( r1 * r1 - dy * dy );
+						for ( long dx = -r0; dx <= r0; ++dx )
+						{
+							final int radius = rnd.nextInt( maxRadius ) + 1;               // :468
+							final double randomValue = rnd.nextDouble();                    // :475
+							if ( Math.round( randomValue * 10000 ) % modulus != 0 )         // :478
+								continue;
+							final double value = rnd.nextDouble() * ( maxValue - minValue ) + minValue;   // :480
+							geo.add( new int[] { ( int ) ( c[ 0 ] + dx + off ), ( int ) ( c[ 1 ] + dy + off ), ( int ) ( c[ 2 ] + dz ), radius } );
+							val.add( ( float ) value );
+						}
+					}
+				}
+				final int[] g4 = new int[ 4 * geo.size() ];
+				final float[] v = new float[ geo.size() ];
+				for ( int i = 0; i < v.length; ++i )
+				{
+					System.arraycopy( geo.get( i ), 0, g4, 4 * i, 4 );
+					v[ i ] = val.get( i );
+				}
+				MvsimNative.splatSpheres( GpuContextPool.get(), b.floats, d, g4, v );
+			}
+			Buffers.copyBack( b, img );
+		}
 	}
 
 	/** downSample2x (:394-424) */
@@ -135,39 +201,129 @@ public class SimulateMultiViewDatasetGPU
 	{
 		final long[] d = Buffers.dims( in );
 		final long[] o = new long[] { d[ 0 ] / 2 - 1, d[ 1 ] / 2 - 1, d[ 2 ] / 2 - 1 };
-		final FloatBuffer out = Buffers.direct( Buffers.size( o ) );
-		MvsimNative.downSample2x( GpuContextPool.get(), Buffers.toBuffer( Views.zeroMin( in ) ), d, out );
-		return Buffers.toImg( out, o );
+		try ( Buffers.Block src = Buffers.toBlock( Views.zeroMin( in ) ); Buffers.Block out = Buffers.direct( Buffers.size( o ) ) )
+		{
+			MvsimNative.downSample2x( GpuContextPool.get(), src.floats, d, out.floats );
+			return Buffers.toImg( out, o );
+		}
 	}
 
 	/**
 	 * The block of main() after the view loop (:615-640): per voxel, sum the weights of all views; zero sum gives
 	 * zero weights, otherwise w = min( 1, osem * w / sum ).  In place on the given images.
 	 */
-	public static void normalizeWeights( final java.util.List< Img< FloatType > > weights, final float osem )
+	public static void normalizeWeights( final List< Img< FloatType > > weights, final float osem )
 	{
-		final FloatBuffer[] b = new FloatBuffer[ weights.size() ];
-		for ( int i = 0; i < b.length; ++i )
-			b[ i ] = Buffers.toBuffer( weights.get( i ) );
-		MvsimNative.normalizeWeights( GpuContextPool.get(), b, b[ 0 ].capacity(), osem );
-		for ( int i = 0; i < b.length; ++i )
-			Buffers.copyBack( b[ i ], weights.get( i ) );
+		final Buffers.Block[] b = new Buffers.Block[ weights.size() ];
+		try
+		{
+			final java.nio.FloatBuffer[] f = new java.nio.FloatBuffer[ b.length ];
+			for ( int i = 0; i < b.length; ++i )
+			{
+				b[ i ] = Buffers.toBlock( weights.get( i ) );
+				f[ i ] = b[ i ].floats;
+			}
+			MvsimNative.normalizeWeights( GpuContextPool.get(), f, Buffers.size( Buffers.dims( weights.get( 0 ) ) ), osem );
+			for ( int i = 0; i < b.length; ++i )
+				Buffers.copyBack( b[ i ], weights.get( i ) );
+		}
+		finally
+		{
+			for ( final Buffers.Block x : b )
+				if ( x != null ) x.close();
+		}
 	}
 
-	/** One view of the main loop (:570-585) with intermediates kept in HBM; returns { rot, att, con, acq }. */
+	/** Which stages of a view come back to the host (the acquisition always does). */
+	public static final int ROT = 1, ATT = 2, CON = 4;
+
+	/**
+	 * One view of the main loop (:570-585) as ONE native call, intermediates resident in HBM.  `want` is a bit set of
+	 * {@link #ROT}, {@link #ATT}, {@link #CON}: only those volumes are materialised and copied back (each costs a 0.5 GB
+	 * PCIe transfer at 512^3, against 2.4 ms for the whole view on the GPU).  Returns { rot, att, con, acq } with null
+	 * for stages that were not asked for.
+	 */
 	public static Img< FloatType >[] simulateView( final RandomAccessibleInterval< FloatType > groundTruth, final Img< FloatType > psf,
-			final int degrees, final double attenuation, final int lightsheetSpacing, final float poissonSNR, final Random rnd, final int view )
+			final int degrees, final double attenuation, final int lightsheetSpacing, final float poissonSNR, final Random rnd, final int view,
+			final int want )
 	{
 		final long[] d = Buffers.dims( groundTruth ), k = Buffers.dims( psf );
 		final long[] o = new long[] { d[ 0 ], d[ 1 ], ( d[ 2 ] - 1 ) / lightsheetSpacing + 1 };
-		final FloatBuffer p = Buffers.toBuffer( psf );
-		final FloatBuffer rot = Buffers.direct( Buffers.size( d ) ), att = Buffers.direct( Buffers.size( d ) ),
-				con = Buffers.direct( Buffers.size( d ) ), acq = Buffers.direct( Buffers.size( o ) );
-		MvsimNative.simulateView( GpuContextPool.get(), Buffers.toBuffer( Views.zeroMin( groundTruth ) ), d, p, k, 0, degrees, attenuation,
-				minValue, avgIntensity, lightsheetSpacing, poissonSNR, rnd.nextLong(), view, rot, att, con, acq );
-		Buffers.copyBack( p, psf );
-		@SuppressWarnings( "unchecked" )
-		final Img< FloatType >[] res = new Img[] { Buffers.toImg( rot, d ), Buffers.toImg( att, d ), Buffers.toImg( con, d ), Buffers.toImg( acq, o ) };
-		return res;
+		final long n = Buffers.size( d );
+		try ( Buffers.Block p = Buffers.toBlock( psf ); Buffers.Block gt = Buffers.toBlock( Views.zeroMin( groundTruth ) );
+				Buffers.Block rot = ( want & ROT ) != 0 ? Buffers.direct( n ) : null; Buffers.Block att = ( want & ATT ) != 0 ? Buffers.direct( n ) : null;
+				Buffers.Block con = ( want & CON ) != 0 ? Buffers.direct( n ) : null; Buffers.Block acq = Buffers.direct( Buffers.size( o ) ) )
+		{
+			MvsimNative.simulateView( GpuContextPool.get(), gt.floats, d, p.floats, k, 0, degrees, attenuation, minValue, avgIntensity,
+					lightsheetSpacing, poissonSNR, rnd.nextLong(), view, rot != null ? rot.floats : null, att != null ? att.floats : null,
+					con != null ? con.floats : null, acq.floats );
+			Buffers.copyBack( p, psf );
+			@SuppressWarnings( "unchecked" )
+			final Img< FloatType >[] res = new Img[] { rot != null ? Buffers.toImg( rot, d ) : null, att != null ? Buffers.toImg( att, d ) : null,
+					con != null ? Buffers.toImg( con, d ) : null, Buffers.toImg( acq, o ) };
+			return res;
+		}
+	}
+
+	/** as above with every intermediate (what main() saves, :598-604) */
+	public static Img< FloatType >[] simulateView( final RandomAccessibleInterval< FloatType > groundTruth, final Img< FloatType > psf,
+			final int degrees, final double attenuation, final int lightsheetSpacing, final float poissonSNR, final Random rnd, final int view )
+	{
+		return simulateView( groundTruth, psf, degrees, attenuation, lightsheetSpacing, poissonSNR, rnd, view, ROT | ATT | CON );
+	}
+
+	/**
+	 * The view loop of main() (:567-585) pipelined over PCIe: every view is submitted with mvsim_simulate_view_async, which
+	 * returns at once, and the previous view is collected while the next one uploads and computes (two page-locked staging
+	 * sets inside the library, three HIP streams).  The ground truth crosses PCIe ONCE (same buffer for every angle); per
+	 * view only the acquisition comes back.  psfs.get( v ) is normalised in place like convolve does.
+	 */
+	public static List< Img< FloatType > > simulateViews( final RandomAccessibleInterval< FloatType > groundTruth, final List< Img< FloatType > > psfs,
+			final int[] degrees, final double attenuation, final int lightsheetSpacing, final float poissonSNR, final Random rnd )
+	{
+		final long[] d = Buffers.dims( groundTruth );
+		final long[] o = new long[] { d[ 0 ], d[ 1 ], ( d[ 2 ] - 1 ) / lightsheetSpacing + 1 };
+		final long ctx = GpuContextPool.get();
+		final List< Img< FloatType > > result = new ArrayList<>();
+		final Buffers.Block[] acq = new Buffers.Block[ 2 ], psf = new Buffers.Block[ 2 ];
+		final long[] ticket = new long[ 2 ];
+		try ( Buffers.Block gt = Buffers.toBlock( Views.zeroMin( groundTruth ) ) )
+		{
+			for ( int v = 0; v < degrees.length; ++v )
+			{
+				final int s = v & 1;
+				if ( acq[ s ] != null )                                   // view v - 2 used this staging pair: collect it first
+				{
+					MvsimNative.waitView( ctx, ticket[ s ] );
+					result.add( Buffers.toImg( acq[ s ], o ) );
+					Buffers.copyBack( psf[ s ], psfs.get( v - 2 ) );
+					acq[ s ].close(); psf[ s ].close();
+					acq[ s ] = null; psf[ s ] = null;
+				}
+				psf[ s ] = Buffers.toBlock( psfs.get( v ) );
+				acq[ s ] = Buffers.direct( Buffers.size( o ) );
+				ticket[ s ] = MvsimNative.simulateViewAsync( ctx, gt.floats, 0L, d, psf[ s ].floats, Buffers.dims( psfs.get( v ) ), 0, degrees[ v ],
+						attenuation, minValue, avgIntensity, lightsheetSpacing, poissonSNR, rnd.nextLong(), v, acq[ s ].floats );
+			}
+			// the last two views, in order
+			for ( int v = Math.max( 0, degrees.length - 2 ); v < degrees.length; ++v )
+			{
+				final int s = v & 1;
+				MvsimNative.waitView( ctx, ticket[ s ] );
+				result.add( Buffers.toImg( acq[ s ], o ) );
+				Buffers.copyBack( psf[ s ], psfs.get( v ) );
+				acq[ s ].close(); psf[ s ].close();
+				acq[ s ] = null; psf[ s ] = null;
+			}
+			return result;
+		}
+		finally
+		{
+			for ( int s = 0; s < 2; ++s )
+			{
+				if ( acq[ s ] != null ) { MvsimNative.waitViewQuiet( ctx, ticket[ s ] ); acq[ s ].close(); }
+				if ( psf[ s ] != null ) psf[ s ].close();
+			}
+		}
 	}
 }

@@ -1,6 +1,5 @@
 package net.preibisch.simulation.gpu;
 
-import java.nio.FloatBuffer;
 import java.util.Random;
 
 import net.imglib2.IterableInterval;
@@ -13,29 +12,35 @@ public class ToolsGPU
 {
 	public static void poissonProcess( final RandomAccessibleInterval< FloatType > img, final double SNR, final Random rnd )
 	{
-		final FloatBuffer b = Buffers.toBuffer( Views.zeroMin( img ) );
-		MvsimNative.poissonProcess( GpuContextPool.get(), b, b.capacity(), SNR, rnd.nextLong(), 0, 0L );
-		Buffers.copyBack( b, Views.flatIterable( img ) );
+		try ( Buffers.Block b = Buffers.toBlock( Views.zeroMin( img ) ) )
+		{
+			MvsimNative.poissonProcess( GpuContextPool.get(), b.floats, Buffers.size( Buffers.dims( img ) ), SNR, rnd.nextLong(), 0, 0L );
+			Buffers.copyBack( b, Views.flatIterable( img ) );
+		}
 	}
 
 	public static void normImage( final Iterable< FloatType > img )
 	{
-		int n = 0;
+		long n = 0;
 		for ( @SuppressWarnings( "unused" ) final FloatType t : img ) ++n;
-		final FloatBuffer b = Buffers.direct( n );
-		for ( final FloatType t : img ) b.put( t.get() );
-		b.rewind();
-		MvsimNative.normImage( GpuContextPool.get(), b, n );
-		Buffers.copyBack( b, img );
+		try ( Buffers.Block b = Buffers.direct( n ) )
+		{
+			for ( final FloatType t : img ) b.floats.put( t.get() );
+			b.floats.rewind();
+			MvsimNative.normImage( GpuContextPool.get(), b.floats, n );
+			Buffers.copyBack( b, img );
+		}
 	}
 
 	public static double adjustImage( final IterableInterval< FloatType > image, final float minValue, final float targetAverage )
 	{
-		final FloatBuffer b = Buffers.direct( image.size() );
-		for ( final FloatType t : image ) b.put( t.get() );
-		b.rewind();
-		final double corr = MvsimNative.adjustImage( GpuContextPool.get(), b, image.size(), minValue, targetAverage );
-		Buffers.copyBack( b, image );
-		return corr;
+		try ( Buffers.Block b = Buffers.direct( image.size() ) )
+		{
+			for ( final FloatType t : image ) b.floats.put( t.get() );
+			b.floats.rewind();
+			final double corr = MvsimNative.adjustImage( GpuContextPool.get(), b.floats, image.size(), minValue, targetAverage );
+			Buffers.copyBack( b, image );
+			return corr;
+		}
 	}
 }

@@ -23,7 +23,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import MvsimError, MvsimNoDeviceError, Timings, ViewOutputs, ViewParams  # noqa: F401
+from ._lib import MvsimError, MvsimNoDeviceError, Sphere, Timings, ViewOutputs, ViewParams  # noqa: F401
 
 __all__ = ["Context", "Group", "JavaRandom", "SimulateMultiViewDataset", "Tools", "default_context", "MvsimError",
            "MvsimNoDeviceError", "ViewParams", "shard_views", "version"]
@@ -262,6 +262,12 @@ class Context:
         rnd._s = int(st.value)
         return int(n.value)
 
+    def splat_spheres(self, img: np.ndarray, spheres) -> None:
+        """The GPU half of drawSpheres: max-composite (cx, cy, cz, radius, value) items into ``img`` in place."""
+        _check_inplace(img)
+        arr = (Sphere * len(spheres))(*[Sphere(int(cx), int(cy), int(cz), int(r), float(v)) for cx, cy, cz, r, v in spheres])
+        _lib.check(self._L.mvsim_splat_spheres(self._h, _ptr(img), _dim(img), arr, len(spheres)))
+
     def downsample2x(self, img) -> np.ndarray:
         v = _as_volume(img)
         nz, ny, nx = v.shape
@@ -365,6 +371,53 @@ class Context:
                                                C.byref(o), C.byref(corr)))
         res["corr"] = corr.value
         return res
+
+    def simulate_view_async(self, gt: np.ndarray, psf: np.ndarray, params: ViewParams, out: dict, gt_generation: int = 0) -> int:
+        """Pipelined host-buffer view (mvsim_simulate_view_async): returns a ticket at once; ``out`` maps stage names
+        ('acq' required; 'rot', 'att', 'con' optional) to preallocated contiguous float32 arrays -- page-locked ones
+        (pinned_empty) make the transfers overlap the kernels.  ``gt``, ``psf`` and the outputs must stay alive and
+        untouched until ``wait(ticket)``."""
+        if not (isinstance(gt, np.ndarray) and gt.dtype == np.float32 and gt.flags.c_contiguous and gt.ndim == 3):
+            raise ValueError("ground truth: contiguous float32 (Nz,Ny,Nx) array required (no hidden copy on the async path)")
+        _check_inplace(psf, "psf")
+        nz, ny, nx = gt.shape
+        o = ViewOutputs()
+        shapes = {"rot": gt.shape, "att": gt.shape, "con": gt.shape, "acq": (self._L.mvsim_extract_nz(nz, params.inc), ny, nx)}
+        if "acq" not in out:
+            raise ValueError("out['acq'] is required")
+        for name, a in out.items():
+            if name not in shapes:
+                raise ValueError(f"unknown output {name!r}")
+            if a.shape != tuple(shapes[name]) or a.dtype != np.float32 or not a.flags.c_contiguous:
+                raise ValueError(f"out[{name!r}] must be a contiguous float32 array of shape {tuple(shapes[name])}")
+            setattr(o, name, a.ctypes.data)
+        t = C.c_int64()
+        _lib.check(self._L.mvsim_simulate_view_async(self._h, _ptr(gt), gt_generation, _dim(gt), _ptr(psf), _dim(psf),
+                                                     C.byref(params), C.byref(o), C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket: int) -> float:
+        """Blocks until the view behind ``ticket`` has landed in its host buffers; returns the adjustImage factor."""
+        corr = C.c_double()
+        _lib.check(self._L.mvsim_wait(self._h, ticket, C.byref(corr)))
+        return corr.value
+
+    def simulate_view_zslabs(self, gt_slabs: list, psf: np.ndarray, params: ViewParams, acq_slab_nz: list) -> tuple:
+        """Host buffers as z slabs (volumes beyond 2^31-1 voxels do not fit one Java array): ``gt_slabs`` is a list of
+        contiguous float32 (nz_i, Ny, Nx) arrays, ``acq_slab_nz`` the plane counts of the acquisition slabs to return."""
+        _check_inplace(psf, "psf")
+        gs = [np.ascontiguousarray(g, dtype=np.float32) for g in gt_slabs]
+        ny, nx = gs[0].shape[1:]
+        nz = sum(g.shape[0] for g in gs)
+        acq = [np.empty((int(k), ny, nx), dtype=np.float32) for k in acq_slab_nz]
+        ga = (C.c_void_p * len(gs))(*[g.ctypes.data for g in gs])
+        gn = (C.c_int64 * len(gs))(*[g.shape[0] for g in gs])
+        aa = (C.c_void_p * len(acq))(*[a.ctypes.data for a in acq])
+        an = (C.c_int64 * len(acq))(*[a.shape[0] for a in acq])
+        corr = C.c_double()
+        _lib.check(self._L.mvsim_simulate_view_zslabs(self._h, ga, gn, len(gs), (C.c_int64 * 3)(nx, ny, nz), _ptr(psf), _dim(psf),
+                                                      C.byref(params), aa, an, len(acq), C.byref(corr)))
+        return acq, corr.value
 
     def simulate_view_dev(self, gt_dptr: int, dim_xyz, psf: np.ndarray, params: ViewParams, acq_dptr: int,
                           rot_dptr: int = 0, att_dptr: int = 0, con_dptr: int = 0, want_corr: bool = False):
@@ -536,6 +589,39 @@ def shard_views(n_views: int, nranks: int, rank: int) -> list[int]:
     return [buf[i] for i in range(cnt)]
 
 
+def _isqrt(v: int) -> int:
+    import math
+    return math.isqrt(v)
+
+
+def walk_large_sphere(shape_zyx, minValue: float, maxValue: float, scale: int, halfPixelOffset: bool, rnd) -> list:
+    """The host half of drawSpheres (SimulateMultiViewDataset.java:436-522) with the CALLER's generator: visit the voxels
+    of the large sphere in ImgLib2 HyperSphereCursor order (z outermost, nested truncated radii, x fastest), draw
+    ``radius = rnd.nextInt(10*scale) + 1`` and a double per voxel, and where the rounding test on that double selects
+    the voxel, a second double for the intensity.  Returns the (cx, cy, cz, radius, value) list for the GPU splat."""
+    nz, ny, nx = (int(v) for v in shape_zyx)
+    c = (nx // 2, ny // 2, nz // 2)
+    R = min(nx, ny, nz) // 2 - 47 * scale - 1
+    if R < 0:
+        raise ValueError("drawSpheres: image too small for this scale")
+    max_radius = 10 * scale
+    modulus = (7 * scale) ** 3
+    off = 1 if halfPixelOffset else 0
+    out = []
+    for dz in range(-R, R + 1):
+        r1 = _isqrt(R * R - dz * dz)
+        for dy in range(-r1, r1 + 1):
+            r0 = _isqrt(r1 * r1 - dy * dy)
+            for dx in range(-r0, r0 + 1):
+                radius = rnd.nextInt(max_radius) + 1
+                rv = rnd.nextDouble()
+                if int(np.floor(rv * 10000 + 0.5)) % modulus != 0:
+                    continue
+                value = rnd.nextDouble() * (maxValue - minValue) + minValue
+                out.append((c[0] + dx + off, c[1] + dy + off, c[2] + dz, radius, np.float32(value)))
+    return out
+
+
 _default_ctx: Context | None = None
 
 
@@ -639,9 +725,15 @@ class SimulateMultiViewDataset:
     @staticmethod
     def drawSpheres(img: np.ndarray, minValue: float, maxValue: float, scale: int, halfPixelOffset: bool,
                     rnd=None) -> None:
-        """:436-522, in place."""
-        default_context().draw_spheres(img, minValue, maxValue, scale, halfPixelOffset,
-                                       rnd if rnd is not None else SimulateMultiViewDataset.rnd)
+        """:436-522, in place.  ``rnd`` may be this package's JavaRandom (its 48-bit state goes to the library, which
+        replays the walk natively) or ANY object with java.util.Random's ``nextInt(bound)`` / ``nextDouble()`` -- the
+        second caller passes a plain ``new Random(seed)`` (SimulateTileStitching.java:93,108): then the walk over the
+        large sphere runs here on the host with the caller's generator and only the compositing goes to the GPU."""
+        rnd = rnd if rnd is not None else SimulateMultiViewDataset.rnd
+        if isinstance(rnd, JavaRandom):
+            default_context().draw_spheres(img, minValue, maxValue, scale, halfPixelOffset, rnd)
+        else:
+            default_context().splat_spheres(img, walk_large_sphere(img.shape, minValue, maxValue, scale, halfPixelOffset, rnd))
 
     @staticmethod
     def downSample2x(img) -> np.ndarray:

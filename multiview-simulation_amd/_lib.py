@@ -36,6 +36,10 @@ class ViewOutputs(C.Structure):
     _fields_ = [("rot", C.c_void_p), ("att", C.c_void_p), ("con", C.c_void_p), ("acq", C.c_void_p)]
 
 
+class Sphere(C.Structure):
+    _fields_ = [("cx", C.c_int32), ("cy", C.c_int32), ("cz", C.c_int32), ("radius", C.c_int32), ("value", C.c_float)]
+
+
 class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in
                 ("rotate_ms", "attenuate_ms", "psf_ms", "convolve_ms", "adjust_ms", "extract_ms", "total_ms",
@@ -100,6 +104,13 @@ SIGNATURES = {
                                           C.POINTER(ViewOutputs), C.POINTER(C.c_double)]),
     "mvsim_simulate_view": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams),
                                       C.POINTER(ViewOutputs), C.POINTER(C.c_double)]),
+    "mvsim_splat_spheres": (C.c_int, [_vp, _vp, _i64p, _vp, C.c_int64]),
+    "mvsim_splat_spheres_dev": (C.c_int, [_vp, _vp, _i64p, _vp, C.c_int64]),
+    "mvsim_simulate_view_async": (C.c_int, [_vp, _vp, C.c_uint64, _i64p, _vp, _i64p, C.POINTER(ViewParams),
+                                            C.POINTER(ViewOutputs), C.POINTER(C.c_int64)]),
+    "mvsim_wait": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_double)]),
+    "mvsim_simulate_view_zslabs": (C.c_int, [_vp, C.POINTER(_vp), _i64p, C.c_int, _i64p, _vp, _i64p, C.POINTER(ViewParams),
+                                             C.POINTER(_vp), _i64p, C.c_int, C.POINTER(C.c_double)]),
     "mvsim_fft_geometry": (C.c_int, [_i64p, _i64p, _i64p]),
     "mvsim_enable_timing": (C.c_int, [_vp, C.c_int]),
     "mvsim_get_timings": (C.c_int, [_vp, C.POINTER(Timings)]),

@@ -25,6 +25,19 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def source_sha() -> str:
+    """First 16 hex digits of the SHA-256 over the kernel / host sources of libmvsim.so (and the header): the identity
+    the PMC traffic record of profiles/ is keyed by, so that bench.py never prints counters collected on other kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(sources() + [os.path.normpath(os.path.join(CSRC, x)) for x in HEADERS])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def is_current() -> bool:
     if not os.path.exists(LIB):
         return False

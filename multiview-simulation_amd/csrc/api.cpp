@@ -262,6 +262,8 @@ static int scal_ptr(mvsim_ctx* ctx, double** partial, double** scal)
 
 using namespace mvsim;
 
+static void async_release(mvsim_ctx* ctx);
+
 extern "C" {
 
 const char* mvsim_version(void) { return "mvsim 0.1.0 (gfx950)"; }
@@ -312,6 +314,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     mvsim_comm_destroy(ctx);
+    async_release(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
     ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release();
@@ -353,6 +356,7 @@ int mvsim_release_caches(mvsim_ctx* ctx)
 {
     MVSIM_TRY(set_device(ctx));
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    async_release(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
     ctx->pqueue.release(); ctx->psf_dev.release(); ctx->sphere_list.release();
@@ -955,6 +959,175 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], f
     if (rc == MVSIM_OK && o->con) rc = down(ctx, o->con, dev.con, vbytes);
     if (rc == MVSIM_OK) rc = down(ctx, o->acq, dev.acq, obytes);
     (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+int mvsim_splat_spheres_dev(mvsim_ctx* ctx, float* img, const int64_t dim[3], const mvsim_sphere* spheres, int64_t n)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(img && (spheres || n == 0) && n >= 0, "null pointer or negative count");
+    return splat_spheres_dev(ctx, img, dim, spheres, n);
+}
+
+int mvsim_splat_spheres(mvsim_ctx* ctx, float* img, const int64_t dim[3], const mvsim_sphere* spheres, int64_t n)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(img && (spheres || n == 0) && n >= 0, "null pointer or negative count");
+    const size_t bytes = (size_t)nvox(dim) * sizeof(float);
+    MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
+    MVSIM_TRY(splat_spheres_dev(ctx, ctx->vol_a.as<float>(), dim, spheres, n));
+    return down(ctx, img, ctx->vol_a.p, bytes);
+}
+
+// ---- pipelined host-buffer views ----------------------------------------------------------------------
+static int async_setup(mvsim_ctx* ctx)
+{
+    if (ctx->async_ready) return MVSIM_OK;
+    MVSIM_HIP(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
+    MVSIM_HIP(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+    for (int s = 0; s < mvsim_ctx::ASYNC_SLOTS; ++s) {
+        MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_h2d[s], hipEventDisableTiming));
+        MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_compute[s], hipEventDisableTiming));
+        MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_d2h[s], hipEventDisableTiming));
+    }
+    MVSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->async_corr), mvsim_ctx::ASYNC_SLOTS * sizeof(double), hipHostMallocDefault));
+    ctx->async_ready = true;
+    return MVSIM_OK;
+}
+
+static void async_release(mvsim_ctx* ctx)
+{
+    if (!ctx->async_ready) return;
+    (void)hipStreamSynchronize(ctx->h2d_stream);
+    (void)hipStreamSynchronize(ctx->d2h_stream);
+    for (int s = 0; s < mvsim_ctx::ASYNC_SLOTS; ++s) {
+        (void)hipEventDestroy(ctx->ev_h2d[s]); (void)hipEventDestroy(ctx->ev_compute[s]); (void)hipEventDestroy(ctx->ev_d2h[s]);
+        ctx->async_gt[s].release(); ctx->async_acq[s].release();
+        ctx->async_inflight[s] = false; ctx->async_gt_src[s] = nullptr;
+    }
+    (void)hipStreamDestroy(ctx->h2d_stream);
+    (void)hipStreamDestroy(ctx->d2h_stream);
+    (void)hipHostFree(ctx->async_corr);
+    ctx->async_corr = nullptr;
+    ctx->async_ready = false;
+}
+
+int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt, uint64_t gt_generation, const int64_t dim[3], float* psf_host,
+                              const int64_t kdim[3], const mvsim_view_params* p, const mvsim_view_outputs* o, int64_t* ticket)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(gt && p && o && o->acq && ticket, "null pointer (outputs.acq and ticket are required)");
+    MVSIM_CHECK_ARG(p->inc >= 1, "inc must be >= 1");
+    MVSIM_TRY(async_setup(ctx));
+    const int64_t n = nvox(dim);
+    const size_t vbytes = (size_t)n * sizeof(float);
+    const size_t obytes = (size_t)(dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc)) * sizeof(float);
+    const long long k = ctx->async_next;
+    const int s = (int)(k % mvsim_ctx::ASYNC_SLOTS);
+    // the staging set is free once its previous view has landed on the host
+    if (ctx->async_inflight[s]) {
+        MVSIM_HIP(hipEventSynchronize(ctx->ev_d2h[s]));
+        ctx->async_inflight[s] = false;
+        ctx->async_corr_done[ctx->async_ticket[s] % mvsim_ctx::ASYNC_HISTORY] = ctx->async_corr[s];
+    }
+    const bool wants_twins = o->rot || o->att || o->con;
+    mvsim_view_outputs dev = {nullptr, nullptr, nullptr, nullptr};
+    MVSIM_TRY(ctx->async_gt[s].reserve(vbytes));
+    MVSIM_TRY(ctx->async_acq[s].reserve(obytes));
+    if (o->rot) { MVSIM_TRY(ctx->host_rot.reserve(vbytes)); dev.rot = ctx->host_rot.as<float>(); }
+    if (o->att) { MVSIM_TRY(ctx->host_att.reserve(vbytes)); dev.att = ctx->host_att.as<float>(); }
+    if (o->con) { MVSIM_TRY(ctx->host_con.reserve(vbytes)); dev.con = ctx->host_con.as<float>(); }
+    dev.acq = ctx->async_acq[s].as<float>();
+    // upload: only when this staging set does not hold this ground truth already; the copy must not overtake the
+    // view that last read the set (ev_compute)
+    if (ctx->async_gt_src[s] != gt || ctx->async_gt_gen[s] != gt_generation) {
+        if (k >= mvsim_ctx::ASYNC_SLOTS) MVSIM_HIP(hipStreamWaitEvent(ctx->h2d_stream, ctx->ev_compute[s], 0));
+        MVSIM_HIP(hipMemcpyAsync(ctx->async_gt[s].p, gt, vbytes, hipMemcpyHostToDevice, ctx->h2d_stream));
+        MVSIM_HIP(hipEventRecord(ctx->ev_h2d[s], ctx->h2d_stream));
+        MVSIM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_h2d[s], 0));
+        ctx->async_gt_src[s] = gt;
+        ctx->async_gt_gen[s] = gt_generation;
+    }
+    // compute: the acquisition buffer of the set is free (waited for above); the single-buffered intermediates are free
+    // once the neighbour's downloads are through
+    if (wants_twins || ctx->async_twins_busy) {
+        for (int q = 0; q < mvsim_ctx::ASYNC_SLOTS; ++q)
+            if (ctx->async_inflight[q]) MVSIM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_d2h[q], 0));
+    }
+    int rc = mvsim_simulate_view_dev(ctx, ctx->async_gt[s].as<float>(), dim, psf_host, kdim, p, &dev, nullptr);
+    if (rc != MVSIM_OK) { ctx->async_gt_src[s] = nullptr; return rc; }
+    {
+        double *partial, *scal;
+        MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
+        MVSIM_HIP(hipMemcpyAsync(&ctx->async_corr[s], scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MVSIM_HIP(hipEventRecord(ctx->ev_compute[s], ctx->stream));
+    // download
+    MVSIM_HIP(hipStreamWaitEvent(ctx->d2h_stream, ctx->ev_compute[s], 0));
+    if (o->rot) MVSIM_HIP(hipMemcpyAsync(o->rot, dev.rot, vbytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    if (o->att) MVSIM_HIP(hipMemcpyAsync(o->att, dev.att, vbytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    if (o->con) MVSIM_HIP(hipMemcpyAsync(o->con, dev.con, vbytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    MVSIM_HIP(hipMemcpyAsync(o->acq, dev.acq, obytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    MVSIM_HIP(hipEventRecord(ctx->ev_d2h[s], ctx->d2h_stream));
+    ctx->async_inflight[s] = true;
+    ctx->async_ticket[s] = k;
+    ctx->async_twins_busy = wants_twins;
+    ctx->async_next = k + 1;
+    *ticket = (int64_t)k;
+    return MVSIM_OK;
+}
+
+int mvsim_wait(mvsim_ctx* ctx, int64_t ticket, double* correction)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_CHECK_ARG(ctx->async_ready && ticket >= 0 && ticket < ctx->async_next, "no such ticket");
+    MVSIM_CHECK_ARG(ticket + mvsim_ctx::ASYNC_HISTORY > ctx->async_next, "ticket too old");
+    const int s = (int)(ticket % mvsim_ctx::ASYNC_SLOTS);
+    if (ctx->async_ticket[s] == ticket && ctx->async_inflight[s]) {
+        MVSIM_HIP(hipEventSynchronize(ctx->ev_d2h[s]));
+        ctx->async_inflight[s] = false;
+        ctx->async_corr_done[ticket % mvsim_ctx::ASYNC_HISTORY] = ctx->async_corr[s];
+    }
+    // otherwise the view has landed already: a later call on the same staging set, or an earlier wait, saw to that
+    if (correction) *correction = ctx->async_corr_done[ticket % mvsim_ctx::ASYNC_HISTORY];
+    return MVSIM_OK;
+}
+
+int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, const int64_t* gt_slab_nz, int n_gt_slabs,
+                               const int64_t dim[3], float* psf_host, const int64_t kdim[3], const mvsim_view_params* p,
+                               float* const* acq_slabs, const int64_t* acq_slab_nz, int n_acq_slabs, double* correction)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(gt_slabs && gt_slab_nz && acq_slabs && acq_slab_nz && p, "null pointer");
+    MVSIM_CHECK_ARG(n_gt_slabs >= 1 && n_acq_slabs >= 1 && p->inc >= 1, "slab counts and inc must be >= 1");
+    const int64_t plane = dim[0] * dim[1];
+    const int64_t nzo = mvsim_extract_nz(dim[2], p->inc);
+    int64_t zs = 0, za = 0;
+    for (int i = 0; i < n_gt_slabs; ++i) { MVSIM_CHECK_ARG(gt_slabs[i] && gt_slab_nz[i] >= 1, "empty ground-truth slab"); zs += gt_slab_nz[i]; }
+    for (int j = 0; j < n_acq_slabs; ++j) { MVSIM_CHECK_ARG(acq_slabs[j] && acq_slab_nz[j] >= 1, "empty acquisition slab"); za += acq_slab_nz[j]; }
+    MVSIM_CHECK_ARG(zs == dim[2], "ground-truth slabs must add up to dim[2] planes");
+    MVSIM_CHECK_ARG(za == nzo, "acquisition slabs must add up to mvsim_extract_nz(dim[2], inc) planes");
+    MVSIM_TRY(ctx->host_gt.reserve((size_t)(plane * dim[2]) * sizeof(float)));
+    MVSIM_TRY(ctx->out_buf.reserve((size_t)(plane * nzo) * sizeof(float)));
+    int64_t z = 0;
+    for (int i = 0; i < n_gt_slabs; ++i) {
+        MVSIM_HIP(hipMemcpyAsync(ctx->host_gt.as<float>() + plane * z, gt_slabs[i], (size_t)(plane * gt_slab_nz[i]) * sizeof(float),
+                                 hipMemcpyHostToDevice, ctx->stream));
+        z += gt_slab_nz[i];
+    }
+    mvsim_view_outputs dev = {nullptr, nullptr, nullptr, ctx->out_buf.as<float>()};
+    int rc = mvsim_simulate_view_dev(ctx, ctx->host_gt.as<float>(), dim, psf_host, kdim, p, &dev, correction);
+    z = 0;
+    for (int j = 0; j < n_acq_slabs && rc == MVSIM_OK; ++j) {
+        if (hipMemcpyAsync(acq_slabs[j], dev.acq + plane * z, (size_t)(plane * acq_slab_nz[j]) * sizeof(float), hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess) { set_error("download of acquisition slab %d failed", j); rc = MVSIM_EHIP; }
+        z += acq_slab_nz[j];
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MVSIM_OK) { set_error("stream synchronise failed"); rc = MVSIM_EHIP; }
     return rc;
 }
 

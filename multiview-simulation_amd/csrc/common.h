@@ -145,6 +145,21 @@ struct mvsim_ctx {
     bool       ev_created = false;
     mvsim_timings last = {};
 
+    // pipelined host-buffer views (mvsim_simulate_view_async): upload(v+1) || compute(v) || download(v-1)
+    static constexpr int ASYNC_SLOTS = 2, ASYNC_HISTORY = 8;
+    double     async_corr_done[ASYNC_HISTORY] = {};   // adjustImage factors of the views that have landed
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    mvsim::DevBuf async_gt[ASYNC_SLOTS], async_acq[ASYNC_SLOTS];
+    hipEvent_t ev_h2d[ASYNC_SLOTS] = {}, ev_compute[ASYNC_SLOTS] = {}, ev_d2h[ASYNC_SLOTS] = {};
+    bool       async_inflight[ASYNC_SLOTS] = {};
+    long long  async_ticket[ASYNC_SLOTS] = {};
+    double*    async_corr = nullptr;          // pinned: one double per slot
+    const void* async_gt_src[ASYNC_SLOTS] = {};   // host ground truth a slot holds (identity + generation: re-upload skipped)
+    unsigned long long async_gt_gen[ASYNC_SLOTS] = {};
+    long long  async_next = 0;
+    bool       async_ready = false;
+    bool       async_twins_busy = false;      // the single-buffered rot/att/con twins are being downloaded
+
     // RCCL
     void* comm = nullptr;
     int   nranks = 1, rank = 0;
@@ -177,6 +192,7 @@ int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int6
 int launch_downsample2x(hipStream_t s, const float* in, const int64_t dim[3], float* out);
 int draw_spheres_dev(mvsim_ctx* ctx, float* img, const int64_t dim[3], double min_value, double max_value, int scale,
                      int half_pixel_offset, uint64_t* rnd_state, int64_t* n_spheres);
+int splat_spheres_dev(mvsim_ctx* ctx, float* img, const int64_t dim[3], const mvsim_sphere* spheres, int64_t n);
 int launch_weight_image(hipStream_t s, float* out, const int64_t dim[3]);
 int launch_weights(hipStream_t s, float* const* views, int nv, int64_t n, const float* sum_in, float* sum_out,
                    float osem, bool sum_only);

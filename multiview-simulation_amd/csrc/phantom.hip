@@ -59,10 +59,12 @@ inline int64_t isqrt_host(int64_t v)
 
 }  // namespace
 
+// device-side item = the C ABI's mvsim_sphere (centre, radius, value)
 struct SphereItem {
     int cx, cy, cz, r;
     float v;
 };
+static_assert(sizeof(SphereItem) == sizeof(mvsim_sphere), "SphereItem must mirror mvsim_sphere");
 
 __device__ __forceinline__ int isqrt_dev(int v)
 {
@@ -183,17 +185,35 @@ int draw_spheres_dev(mvsim_ctx* ctx, float* img, const int64_t dim[3], double mi
     }
     *rnd_state = rnd.s;
     if (n_spheres) *n_spheres = (int64_t)items.size();
-    if (items.empty()) return MVSIM_OK;
-    MVSIM_TRY(ctx->sphere_list.reserve(items.size() * sizeof(SphereItem)));
-    // the list lives in pageable host memory: a synchronous copy (the host walk above dominates anyway)
+    return splat_spheres_dev(ctx, img, dim, reinterpret_cast<const mvsim_sphere*>(items.data()), (int64_t)items.size());
+}
+
+// Max-compositing of a list of small spheres (the GPU half of drawSpheres; also the entry point for hosts that walk
+// the large sphere themselves with their own java.util.Random, mvsim_splat_spheres).
+int splat_spheres_dev(mvsim_ctx* ctx, float* img, const int64_t dim[3], const mvsim_sphere* spheres, int64_t n)
+{
+    if (n <= 0) return MVSIM_OK;
+    int max_radius = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const mvsim_sphere& q = spheres[i];
+        if (q.radius < 0 || q.radius > 4096) { set_error("invalid argument: sphere %lld has radius %d", (long long)i, q.radius); return MVSIM_EINVAL; }
+        if (q.cx - q.radius < 0 || q.cy - q.radius < 0 || q.cz - q.radius < 0 || (int64_t)q.cx + q.radius >= dim[0] ||
+            (int64_t)q.cy + q.radius >= dim[1] || (int64_t)q.cz + q.radius >= dim[2]) {
+            set_error("drawSpheres: a small sphere leaves the image (the reference throws here)");
+            return MVSIM_EINVAL;
+        }
+        if (q.radius > max_radius) max_radius = q.radius;
+    }
+    MVSIM_TRY(ctx->sphere_list.reserve((size_t)n * sizeof(SphereItem)));
+    // the list lives in pageable host memory: a synchronous copy (the host walk dominates anyway)
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
-    MVSIM_HIP(hipMemcpy(ctx->sphere_list.p, items.data(), items.size() * sizeof(SphereItem), hipMemcpyHostToDevice));
+    MVSIM_HIP(hipMemcpy(ctx->sphere_list.p, spheres, (size_t)n * sizeof(SphereItem), hipMemcpyHostToDevice));
     // Math.max( value, existing ) stores (float)value when value > existing: with monotonic rounding that is the
     // float max of (float)value and existing
-    const size_t chunk = 32768;        // grid.x limit is far away; chunking only bounds a single launch
-    for (size_t i0 = 0; i0 < items.size(); i0 += chunk) {
-        const size_t n = items.size() - i0 < chunk ? items.size() - i0 : chunk;
-        hipLaunchKernelGGL(k_splat_spheres, dim3((unsigned)n, (unsigned)(2 * max_radius + 1)), dim3(256), 0, ctx->stream,
+    const int64_t chunk = 32768;        // grid.x limit is far away; chunking only bounds a single launch
+    for (int64_t i0 = 0; i0 < n; i0 += chunk) {
+        const int64_t m = n - i0 < chunk ? n - i0 : chunk;
+        hipLaunchKernelGGL(k_splat_spheres, dim3((unsigned)m, (unsigned)(2 * max_radius + 1)), dim3(256), 0, ctx->stream,
                            img, (int)dim[0], (int)dim[1], (int)dim[2], ctx->sphere_list.as<SphereItem>() + i0);
     }
     MVSIM_HIP(hipGetLastError());

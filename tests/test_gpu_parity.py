@@ -365,7 +365,7 @@ def test_full_width_512x512x64_view_matches_oracle(ctx, orc, synth):
     got, _ = _view_against_oracle(ctx, orc, full, psf, degrees=15, inc=1, stream=2)
     assert got["acq"].size >= 1.6e7
     lam = got["con"].astype(np.float64) * 124.99999999999997
-    assert (lam >= 10.0).mean() > 0.02 and lam.max() > 2000.0
+    assert (lam >= 10.0).mean() > 0.1 and lam.max() > 500.0
 
 
 def test_context_options_select_identical_variants(ctx, orc, synth, options):
@@ -942,3 +942,81 @@ def test_rccl_two_processes_two_gpus(mvs, tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+# ------------------------------------------------------------------------------------------------ boundary: round 2 additions
+class _PlainRandom:
+    """A java.util.Random look-alike that is NOT this package's JavaRandom (what SimulateTileStitching.java:93,108 hands
+    to `simulate`): only nextInt(bound) / nextDouble() are offered."""
+
+    def __init__(self, mvs, seed):
+        self._j = mvs.JavaRandom(seed)
+
+    def nextInt(self, bound):
+        return self._j.nextInt(bound)
+
+    def nextDouble(self):
+        return self._j.nextDouble()
+
+
+def test_draw_spheres_accepts_any_random(mvs, orc):
+    """drawSpheres with a caller-supplied generator that is not the package's own: the walk over the large sphere runs
+    on the host with THAT generator, the compositing on the GPU (mvsim_splat_spheres) -- same image and same generator
+    state as the oracle's drawSpheres."""
+    S = mvs.SimulateMultiViewDataset
+    img = np.zeros((140, 132, 150), np.float32)
+    r = _PlainRandom(mvs, 77)
+    S.drawSpheres(img, 0.0, 1.0, 1, True, r)
+    ref = np.zeros_like(img)
+    ro = orc.JRandom(77)
+    n = orc.draw_spheres(ref, 0.0, 1.0, 1, True, ro)
+    assert n > 0 and np.array_equal(img, ref)
+    assert r._j._s == int(ro.st.s)
+    with pytest.raises(ValueError):                                     # a sphere that leaves the image: the reference throws
+        mvs.default_context().splat_spheres(img, [(2, 50, 50, 5, 1.0)])
+
+
+def test_async_pipelined_views_equal_synchronous_views(ctx, synth):
+    """mvsim_simulate_view_async / mvsim_wait: six views of one ground truth through the two staging sets (page-locked
+    buffers, uploads skipped while the ground truth is unchanged, re-upload on a new generation, intermediates on
+    request) give exactly the voxels of the synchronous entry point."""
+    gt = synth.sphere_phantom(48)
+    g = ctx.pinned_empty(gt.shape)
+    g[...] = gt
+    psfs = [synth.gaussian_psf(7, sigma=(1.1, 1.2, 1.6 + 0.1 * v)) for v in range(6)]
+    params = [ctx.view_params(degrees=15 + 60 * v, inc=2, snr=25.0, seed=SEED, stream=v) for v in range(6)]
+    want = [ctx.simulate_view(gt, psfs[v].copy(), params[v], want=("con", "acq")) for v in range(6)]
+    outs = [{"acq": ctx.pinned_empty(want[0]["acq"].shape)} for _ in range(6)]
+    outs[3]["con"] = ctx.pinned_empty(gt.shape)
+    raws = [q.copy() for q in psfs]
+    tickets = []
+    for v in range(6):
+        tickets.append(ctx.simulate_view_async(g, raws[v], params[v], outs[v]))
+        if v >= 1:
+            corr = ctx.wait(tickets[v - 1])                             # the caller's loop: submit v, collect v - 1
+            assert abs(corr - want[v - 1]["corr"]) <= 1e-12 * corr
+            assert np.array_equal(outs[v - 1]["acq"], want[v - 1]["acq"])
+    ctx.wait(tickets[5])
+    assert np.array_equal(outs[5]["acq"], want[5]["acq"]) and np.array_equal(outs[3]["con"], want[3]["con"])
+    assert ctx.wait(tickets[4]) == pytest.approx(want[4]["corr"], rel=1e-12)     # waiting again is harmless
+    # new contents behind the same pointer: a new generation forces the upload
+    g[...] = gt[::-1]
+    o2 = {"acq": ctx.pinned_empty(want[0]["acq"].shape)}
+    ctx.wait(ctx.simulate_view_async(g, psfs[0].copy(), params[0], o2, gt_generation=1))
+    assert np.array_equal(o2["acq"], ctx.simulate_view(gt[::-1], psfs[0].copy(), params[0])["acq"])
+    with pytest.raises(ValueError):
+        ctx.wait(10_000)
+
+
+def test_view_from_z_slab_host_buffers(ctx, synth):
+    """mvsim_simulate_view_zslabs: ground truth and acquisition as lists of z slabs (the host convention for volumes
+    beyond 2^31-1 voxels) -- same voxels as the single-buffer entry point."""
+    gt = synth.sphere_phantom(40)
+    psf = synth.gaussian_psf(7, sigma=(1.1, 1.2, 1.8))
+    p = ctx.view_params(degrees=40, inc=3, snr=25.0, seed=SEED, stream=1)
+    ref = ctx.simulate_view(gt, psf.copy(), p)
+    acq, corr = ctx.simulate_view_zslabs([gt[:7], gt[7:30], gt[30:]], psf.copy(), p, [5, 1, 8])
+    assert abs(corr - ref["corr"]) <= 1e-12 * corr
+    assert np.array_equal(np.concatenate(acq, axis=0), ref["acq"])
+    with pytest.raises(ValueError):
+        ctx.simulate_view_zslabs([gt[:7], gt[7:30]], psf.copy(), p, [14])          # slabs do not add up to the volume

@@ -281,3 +281,20 @@ def test_c_abi_host_only_leg_under_sanitizers(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0")   # the ROCm runtime keeps process-lifetime blocks
     r = subprocess.run([exe], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "host-only sanitizer run ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_jni_shim_covers_every_native_method():
+    """Source-only Java layer (no JDK in the image): at least keep MvsimNative.java and java/jni/mvsim_jni.cpp in step --
+    every `static native` method has exactly one JNI_FN definition, and the shim only calls C-ABI symbols the header
+    declares."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    java = open(os.path.join(root, "java/src/main/java/net/preibisch/simulation/gpu/MvsimNative.java")).read()
+    cpp = open(os.path.join(root, "java/jni/mvsim_jni.cpp")).read()
+    header = open(os.path.join(root, "include/mvsim.h")).read()
+    natives = re.findall(r"static\s+native\s+[\w.\[\]<>]+\s+(\w+)\s*\(", java)
+    defined = re.findall(r"JNI_FN\((\w+)\)", cpp)
+    assert natives and sorted(natives) == sorted(defined), (set(natives) ^ set(defined))
+    declared = set(re.findall(r"\b(mvsim_\w+)\s*\(", header))
+    for sym in set(re.findall(r"\b(mvsim_[a-z0-9_]+)\s*\(", cpp)):
+        assert sym in declared, sym

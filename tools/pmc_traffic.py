@@ -1,7 +1,11 @@
 """Aggregate two rocprofv3 counter passes (--pmc FETCH_SIZE and --pmc WRITE_SIZE, run separately and without
 any trace domain) into the per-kernel HBM traffic table committed under profiles/.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <views_profiled> > profiles/rNN_pmc_hbm_traffic.txt
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <views_profiled> [--json profiles/rNN_traffic.json
+                                 --size 512 --psf 31 --inc 1] > profiles/rNN_pmc_hbm_traffic.txt
+
+With --json the per-view, per-stage byte totals are also written as the record bench.py reads (`roofline.traffic`,
+`roofline.hbm_measured`), keyed by the workload and by the SHA of the kernel sources they were measured on.
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are
 in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream, so the read column is multiplied by 2;
@@ -32,8 +36,24 @@ def load(d, counter):
     return acc
 
 
+def stage_of(kernel: str) -> str:
+    k = kernel
+    if "k_rotate" in k or "k_attenuate" in k:
+        return "rotate_attenuate"
+    if "k_extract" in k or "k_poisson" in k:
+        return "extract_poisson"
+    if "fft::" in k or "k_reduce_partials" in k or "k_adjust" in k or "k_sum" in k or "k_stencil" in k or "k_pad" in k or "k_cmul" in k or "k_crop" in k or "k_psf" in k:
+        return "convolve"
+    return "other"
+
+
 def main():
-    fd, wd, views = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    argv = sys.argv[1:]
+    opts = {}
+    while len(argv) > 3:
+        opts[argv[3].lstrip("-")] = argv[4]
+        del argv[3:5]
+    fd, wd, views = argv[0], argv[1], int(argv[2])
     rd, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; no trace domains), "
           "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline")
@@ -42,13 +62,28 @@ def main():
     print("# (MI355X_MICROARCH.md, HBM section) -> x2 correction applied to the read column.  Values are means per launch.")
     print(f"{'kernel':100s} {'launches':>8s} {'read_GB':>9s} {'write_GB':>9s}")
     total = 0.0
+    stages, per_kernel = {}, {}
     for k, (n, v) in rd.items():
         r = 2.0 * v * 1024 / n / 1e9
         wn, wv = wr.get(k, [1, 0.0])
         w = wv * 1024 / max(wn, 1) / 1e9
         total += (r + w) * n
+        stages[stage_of(k)] = stages.get(stage_of(k), 0.0) + (r + w) * n * 1e9 / views
+        per_kernel[k[:120]] = {"launches": n, "read_bytes": r * 1e9, "write_bytes": w * 1e9}
         print(f"{k[:100]:100s} {n:8d} {r:9.3f} {w:9.3f}")
     print(f"# total HBM traffic per view (all launches, {views} views profiled): {total / views:.2f} GB")
+    if "json" in opts:
+        import importlib, json, os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        sha = importlib.import_module("multiview-simulation_amd.build").source_sha()
+        rec = {"kernel_sha": sha, "workload": {"size": int(opts.get("size", 512)), "psf": int(opts.get("psf", 31)), "inc": int(opts.get("inc", 1))},
+               "views_profiled": views, "per_view_bytes": {k: v for k, v in stages.items() if k != "other"},
+               "per_kernel": per_kernel,
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (no trace domains) of "
+                         "`python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-size-1024`; counter unit "
+                         "KiB; FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md)"}
+        json.dump(rec, open(opts["json"], "w"), indent=1)
+        print(f"# wrote {opts['json']} (kernel_sha {sha})")
 
 
 if __name__ == "__main__":
