@@ -36,7 +36,11 @@ int parse_option(Options& o, const char* name, const char* value)
         if (v == "custom" || v == "auto") o.rocfft = false; else if (v == "rocfft") o.rocfft = true; else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
-    if (n == "fused_rotate") return flag(&o.fused_rotate);
+    if (n == "fused_rotate") {
+        if (v == "1" || v == "on" || v == "lds") o.fused_rotate = 1; else if (v == "0" || v == "off") o.fused_rotate = 0;
+        else if (v == "2" || v == "lane") o.fused_rotate = 2; else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
     if (n == "poisson_queue") return flag(&o.poisson_queue);
     if (n == "early_sum") return flag(&o.early_sum);
     if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
@@ -64,11 +68,24 @@ const Options& env_options()
         if (const char* e = getenv("MVSIM_FFT_ZPASS")) (void)parse_option(o, "fft_zpass", e);
         if (const char* e = getenv("MVSIM_FFT_BACKEND")) (void)parse_option(o, "fft_backend", e);
         if (const char* e = getenv("MVSIM_FFT_PAD")) (void)parse_option(o, "fft_pad", e);
-        if (getenv("MVSIM_NO_FUSED_ROTATE")) o.fused_rotate = false;
+        if (getenv("MVSIM_NO_FUSED_ROTATE")) o.fused_rotate = 0;
         if (getenv("MVSIM_POISSON_NOQUEUE")) o.poisson_queue = false;
         if (getenv("MVSIM_NO_EARLY_SUM")) o.early_sum = false;
         if (const char* e = getenv("MVSIM_GRAPH")) (void)parse_option(o, "graph", e);
         if (const char* e = getenv("MVSIM_BROADCAST")) (void)parse_option(o, "broadcast", e);
+        // MVSIM_OPTIONS="name=value;name=value": any option by its mvsim_set_option name (experiments, A/B runs)
+        if (const char* e = getenv("MVSIM_OPTIONS")) {
+            std::string all(e);
+            size_t pos = 0;
+            while (pos < all.size()) {
+                size_t end = all.find(';', pos);
+                if (end == std::string::npos) end = all.size();
+                const std::string kv = all.substr(pos, end - pos);
+                const size_t eq = kv.find('=');
+                if (eq != std::string::npos) (void)parse_option(o, kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str());
+                pos = end + 1;
+            }
+        }
     });
     return o;
 }

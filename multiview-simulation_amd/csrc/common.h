@@ -91,7 +91,8 @@ struct PinnedRing {
 struct Options {
     int     zpass = 0;                 // z pass of the hand-written convolution: 0 auto (direct for Kz <= 64), 1 direct, 2 FFT
     bool    rocfft = false;            // library fallback instead of the hand-written passes
-    bool    fused_rotate = true;       // rotate+attenuate as one kernel when the rotation is about x
+    int     fused_rotate = 1;          // rotate+attenuate as one kernel when the rotation is about x: 0 off, 1 row geometry
+                                       // shared through LDS (production), 2 recomputed per lane (kept for A/B runs)
     bool    poisson_queue = true;      // two-launch Poisson (streaming kernel + work-queue resolver)
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
     int     graph = 0;                 // replay simulate_view_dev from a captured hipGraph (small, launch-bound volumes)
@@ -171,9 +172,9 @@ namespace mvsim {
 int launch_rotate(hipStream_t s, const float* in, float* out, const int64_t dim[3], const Affine& inv);
 int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta);
 int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
-                            const Affine& inv, double delta, bool allow_fused, bool* fused);
+                            const Affine& inv, double delta, int fused_mode, bool* fused);
 int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
-                                   const Affine& inv, double delta, int z_begin, int z_count, bool allow_fused, bool* fused);
+                                   const Affine& inv, double delta, int z_begin, int z_count, int fused_mode, bool* fused);
 // sum -> scal[0]; partial workspace must hold >= SUM_BLOCKS doubles
 constexpr int SUM_BLOCKS = 2048;
 int launch_sum(hipStream_t s, const float* in, int64_t n, double* partial, double* scal);

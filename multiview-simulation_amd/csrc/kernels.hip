@@ -269,22 +269,222 @@ __global__ __launch_bounds__(64) void k_rotate_attenuate_axis0(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same arithmetic, different decomposition (the production form): the geometry of an output row (y, z) -- the two
+// source rows, the four fp64 weights -- is the same for every x, and the scalar unit has no fp64, so the kernel
+// above spends half of its vector instructions recomputing wave-uniform values in every lane.  Here a block covers
+// the WHOLE x extent of one plane (up to 16 waves), the threads first compute the geometry of the rows of a chunk
+// once, one row per thread, into an LDS table, and every lane then fetches a row's entry with same-address (broadcast)
+// LDS reads while it walks y.  The element offset of the first source row and the row class come back to the scalar
+// unit through v_readfirstlane, so the four row loads and the stores use scalar base addresses and the lane's
+// constant x offset.  Row classes: 0 = no tap inside the volume (output is +0, attenuation state unchanged -- what the
+// generic arithmetic produces for four zero taps), 1 = all four source rows inside, 2 = some inside (per-tap mask).
+// Rounding points unchanged => bit-identical to k_rotate_axis0_v4 + k_attenuate and to the kernel above.
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) RowGeo {
+    double    w00, w10, w11, w01;
+    long long off00;            // byte offset of source row (sy, sz), x = 0; only meaningful for the taps that are inside
+    int       kind;             // 0 none, 1 all four taps inside, 2 partial: bits 8..11 = inside(00, 10, 11, 01)
+    int       pad;
+};
+constexpr int GEO_CHUNK = 512;  // rows per LDS table (24 KB)
+
+template <int U, bool WRITE_ROT>
+__global__ __launch_bounds__(1024) void k_rotate_attenuate_axis0_lds(const float* __restrict__ in, float* __restrict__ rot_out,
+                                                                     float* __restrict__ att_out, int nx, int ny, int nz,
+                                                                     int steps, Affine a, double delta, int z_off)
+{
+    __shared__ RowGeo geo[GEO_CHUNK];
+    __shared__ int bclass[GEO_CHUNK / U];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int z = blockIdx.y + z_off;
+    const bool active = x < nx;                       // no early exit: every thread takes part in the barriers
+    const long long row = (long long)nx;
+    const long long plane = row * ny;
+    const long long out_plane = plane * blockIdx.y;   // output buffers start at plane z_off of the view
+    const double l2 = (double)z;
+    // byte-addressed views for the straight-line path: scalar 64-bit bases plus one 32-bit per-lane offset
+    const char* __restrict__ in_b = reinterpret_cast<const char*>(in);
+    const long long row_b = row * 4, plane_b = plane * 4;
+    const unsigned xoff = (unsigned)(active ? x : nx - 1) * 4u;
+    double n = 1.0;
+    for (int c0 = 0; c0 < steps; c0 += GEO_CHUNK) {
+        const int cnt = min(GEO_CHUNK, steps - c0);
+        if (c0 > 0) __syncthreads();                  // the previous chunk's readers are done
+        for (int r = threadIdx.x; r < cnt; r += blockDim.x) {
+            const int yy = ny - 1 - (c0 + r);
+            const double l1 = (double)yy;
+            // l0 * m4 with m4 == 0 contributes +0 exactly; keep the reference's evaluation order
+            const double py = 0.0 * a.m[4] + l1 * a.m[5] + l2 * a.m[6] + a.m[7];
+            const double pz = 0.0 * a.m[8] + l1 * a.m[9] + l2 * a.m[10] + a.m[11];
+            const double fy = floor(py), fz = floor(pz);
+            RowGeo g;
+            g.w00 = g.w10 = g.w11 = g.w01 = 0.0;
+            g.off00 = 0;
+            g.kind = 0;
+            g.pad = 0;
+            if (fy >= -1.0 && fz >= -1.0 && fy < (double)ny && fz < (double)nz) {
+                const int sy = (int)fy, sz = (int)fz;
+                const double w1 = py - fy, w2 = pz - fz;
+                const double w1n = 1.0 - w1, w2n = 1.0 - w2;
+                g.w00 = 1.0 * w1n * w2n; g.w10 = 1.0 * w1 * w2n; g.w11 = 1.0 * w1 * w2; g.w01 = 1.0 * w1n * w2;
+                const bool ya = sy >= 0, yb = sy + 1 < ny, za = sz >= 0, zb = sz + 1 < nz;
+                g.off00 = row * (sy + (long long)ny * sz) * 4;          // BYTE offset
+                const int m = ((ya && za) ? 1 : 0) | ((yb && za) ? 2 : 0) | ((yb && zb) ? 4 : 0) | ((ya && zb) ? 8 : 0);
+                g.kind = m == 15 ? 1 : (m == 0 ? 0 : (2 | (m << 8)));
+            }
+            geo[r] = g;
+        }
+        __syncthreads();
+        // class of every batch of U rows: 1 = all rows have their four taps inside (straight-line code), 0 = all rows are
+        // outside (zeros), 2 = mixed or incomplete batch (generic code)
+        for (int bq = threadIdx.x; bq < (cnt + U - 1) / U; bq += blockDim.x) {
+            bool all1 = true, all0 = true;
+            for (int u = 0; u < U; ++u) {
+                const int r = bq * U + u;
+                if (r < cnt) {
+                    const int k = geo[r].kind;
+                    all1 = all1 && k == 1;
+                    all0 = all0 && k == 0;
+                } else {
+                    all1 = false;
+                    all0 = false;
+                }
+            }
+            bclass[bq] = all1 ? 1 : (all0 ? 0 : 2);
+        }
+        __syncthreads();
+        for (int r0 = 0; r0 < cnt; r0 += U) {
+            const int cls = __builtin_amdgcn_readfirstlane(bclass[r0 / U]);
+            const int y0 = ny - 1 - (c0 + r0);                        // rows y0, y0 - 1, ..., y0 - U + 1
+            if (cls == 1) {
+                // straight-line: U offsets from the table, U x 4 row loads (scalar base + the lane's constant byte offset;
+                // lanes beyond nx read the last column, only their stores are masked), then the U dependent steps
+                long long offs[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) offs[u] = geo[r0 + u].off00;
+                float v00[U], v10[U], v11[U], v01[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)offs[u]);
+                    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)offs[u] >> 32));
+                    const char* __restrict__ p00 = in_b + (long long)(((unsigned long long)hi << 32) | lo);   // scalar base
+                    v00[u] = *reinterpret_cast<const float*>(p00 + xoff);
+                    v10[u] = *reinterpret_cast<const float*>(p00 + row_b + xoff);
+                    v11[u] = *reinterpret_cast<const float*>(p00 + row_b + plane_b + xoff);
+                    v01[u] = *reinterpret_cast<const float*>(p00 + plane_b + xoff);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const RowGeo* g = &geo[r0 + u];
+                    float r = (float)((double)v00[u] * g->w00);
+                    r += (float)((double)v10[u] * g->w10);
+                    r += (float)((double)v11[u] * g->w11);
+                    r += (float)((double)v01[u] * g->w01);
+                    const double d = (double)r;
+                    n = fmax(n - d * delta * n, 0.0);
+                    if (active) {
+                        const long long ob = (out_plane + (long long)(y0 - u) * row) * 4;                    // scalar
+                        if (WRITE_ROT) *reinterpret_cast<float*>(reinterpret_cast<char*>(rot_out) + ob + xoff) = r;
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(att_out) + ob + xoff) = (float)(d * n);
+                    }
+                }
+            } else if (cls == 0) {
+                // four zero taps per row: r = +0, n = max(n - 0 * delta * n, 0) = n, out = (float)(0 * n) = +0
+                if (active) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const long long o = out_plane + (long long)(y0 - u) * row;
+                        if (WRITE_ROT) rot_out[o + x] = 0.f;
+                        att_out[o + x] = 0.f;
+                    }
+                }
+            } else {
+                for (int u = 0; u < U && r0 + u < cnt; ++u) {
+                    const RowGeo* g = &geo[r0 + u];
+                    const int kind = __builtin_amdgcn_readfirstlane(g->kind);
+                    const long long o = out_plane + (long long)(y0 - u) * row;
+                    float r = 0.f;
+                    if (kind != 0) {
+                        const float* __restrict__ p00 = reinterpret_cast<const float*>(in_b + g->off00);
+                        const bool t00 = kind == 1 || (kind & (1 << 8)), t10 = kind == 1 || (kind & (2 << 8));
+                        const bool t11 = kind == 1 || (kind & (4 << 8)), t01 = kind == 1 || (kind & (8 << 8));
+                        const float a00 = (active && t00) ? p00[x] : 0.f;
+                        const float a10 = (active && t10) ? p00[row + x] : 0.f;
+                        const float a11 = (active && t11) ? p00[row + plane + x] : 0.f;
+                        const float a01 = (active && t01) ? p00[plane + x] : 0.f;
+                        r = (float)((double)a00 * g->w00);
+                        r += (float)((double)a10 * g->w10);
+                        r += (float)((double)a11 * g->w11);
+                        r += (float)((double)a01 * g->w01);
+                        const double d = (double)r;
+                        n = fmax(n - d * delta * n, 0.0);
+                        if (active) att_out[o + x] = (float)(d * n);
+                    } else if (active) {
+                        att_out[o + x] = 0.f;
+                    }
+                    if (WRITE_ROT && active) rot_out[o + x] = r;
+                }
+            }
+        }
+    }
+    // rows the reference never visits (Ny > Nx): attenuated image stays zero; rot still needs its values
+    for (int yy = ny - 1 - steps; yy >= 0; --yy) {
+        if (!active) break;
+        att_out[out_plane + (long long)yy * row + x] = 0.f;
+        if (WRITE_ROT) {
+            const double l1 = (double)yy;
+            const double py = 0.0 * a.m[4] + l1 * a.m[5] + l2 * a.m[6] + a.m[7];
+            const double pz = 0.0 * a.m[8] + l1 * a.m[9] + l2 * a.m[10] + a.m[11];
+            const double fy = floor(py), fz = floor(pz);
+            float o = 0.f;
+            if (fy >= -1.0 && fz >= -1.0 && fy < (double)ny && fz < (double)nz) {
+                const int sy = (int)fy, sz = (int)fz;
+                const double w1 = py - fy, w2 = pz - fz;
+                const double w1n = 1.0 - w1, w2n = 1.0 - w2;
+                const double q00 = 1.0 * w1n * w2n, q10 = 1.0 * w1 * w2n, q11 = 1.0 * w1 * w2, q01 = 1.0 * w1n * w2;
+                const bool ya = sy >= 0, yb = sy + 1 < ny, za = sz >= 0, zb = sz + 1 < nz;
+                const float* __restrict__ pin = in + x;
+                const float a00 = (ya && za) ? pin[row * (sy + (long long)ny * sz)] : 0.f;
+                const float a10 = (yb && za) ? pin[row * (sy + 1 + (long long)ny * sz)] : 0.f;
+                const float a11 = (yb && zb) ? pin[row * (sy + 1 + (long long)ny * (sz + 1))] : 0.f;
+                const float a01 = (ya && zb) ? pin[row * (sy + (long long)ny * (sz + 1))] : 0.f;
+                o = (float)((double)a00 * q00); o += (float)((double)a10 * q10);
+                o += (float)((double)a11 * q11); o += (float)((double)a01 * q01);
+            }
+            rot_out[out_plane + (long long)yy * row + x] = o;
+        }
+    }
+}
+
 // returns MVSIM_OK and sets *fused = false when the fast-path conditions do not hold (caller runs the two kernels)
 int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
-                            const Affine& inv, double delta, bool allow_fused, bool* fused)
+                            const Affine& inv, double delta, int fused_mode, bool* fused)
 {
-    return launch_rotate_attenuate_planes(s, in, rot_or_null, att, dim, inv, delta, 0, (int)dim[2], allow_fused, fused);
+    return launch_rotate_attenuate_planes(s, in, rot_or_null, att, dim, inv, delta, 0, (int)dim[2], fused_mode, fused);
 }
 
 // planes [z_begin, z_begin + z_count) of the view into buffers that start at plane z_begin
 int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
-                                   const Affine& inv, double delta, int z_begin, int z_count, bool allow_fused, bool* fused)
+                                   const Affine& inv, double delta, int z_begin, int z_count, int fused_mode, bool* fused)
 {
     const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
     const bool x_identity = inv.m[0] == 1.0 && inv.m[1] == 0.0 && inv.m[2] == 0.0 && inv.m[3] == 0.0 &&
                             inv.m[4] == 0.0 && inv.m[8] == 0.0;
-    *fused = x_identity && allow_fused;
+    // fused_mode: 0 separate kernels, 1 geometry table in LDS (production), 2 every lane recomputes the row geometry
+    *fused = x_identity && fused_mode != 0;
     if (!*fused) return MVSIM_OK;
+    if (fused_mode == 1) {
+        // one block per plane and 1024-column stripe: nx / 64 waves (at most 16) share one geometry table
+        const int waves = (nx + 63) / 64 < 16 ? (nx + 63) / 64 : 16;
+        dim3 grid_l((nx + waves * 64 - 1) / (waves * 64), z_count), block_l(waves * 64);
+        if (rot_or_null)
+            hipLaunchKernelGGL((k_rotate_attenuate_axis0_lds<8, true>), grid_l, block_l, 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin);
+        else
+            hipLaunchKernelGGL((k_rotate_attenuate_axis0_lds<8, false>), grid_l, block_l, 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin);
+        MVSIM_HIP(hipGetLastError());
+        return MVSIM_OK;
+    }
     dim3 grid((nx + 63) / 64, z_count);
     if (rot_or_null)
         hipLaunchKernelGGL((k_rotate_attenuate_axis0<8, true>), grid, dim3(64), 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin);

@@ -405,7 +405,10 @@ def normalize_weights(weights: list, osem: float) -> None:
         raise ValueError("normalize_weights")
 
 
-def simulate_view(gt, psf, angle_deg: int, *, axis: int = 0, delta: float = 0.01, min_value: float = 1e-4,
+REF_ATTENUATION = float(np.float32(0.01))     # `final float attenuation = 0.01f`, widened to double at the call (SMVD:533,573)
+
+
+def simulate_view(gt, psf, angle_deg: int, *, axis: int = 0, delta: float = REF_ATTENUATION, min_value: float = 1e-4,
                   avg: float = 1.0, inc: int = 1, snr: float = 25.0, seed: int = 464232194, stream: int = 0,
                   conv: str = "direct"):
     """One iteration of the loop body SMVD:567-585 (rotate -> attenuate -> convolve -> adjust ->

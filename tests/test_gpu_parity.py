@@ -416,7 +416,7 @@ def test_fused_view_equals_staged_ops(ctx, orc, synth, method, inc, snr):
     only = ctx.simulate_view(gt, psf0.copy(), p, want=("acq",))
     # staged through the individual entry points
     rot = ctx.rotate_around_axis(gt, 0, 60)
-    att = ctx.attenuate3d(rot, 0.01)
+    att = ctx.attenuate3d(rot, p.delta)
     con = ctx.convolve(att, psf0.copy(), method=method)
     corr = ctx.adjust_image(con, 1e-4, 1.0)
     acq = ctx.extract_slices(con, inc, snr, SEED, 3)
@@ -597,7 +597,7 @@ def test_fused_view_other_axes_and_odd_dims(ctx, orc):
         p = ctx.view_params(axis=axis, degrees=deg, inc=2, snr=25.0, seed=SEED, stream=2, conv_method=1)
         res = ctx.simulate_view(gt, psf0.copy(), p, want=("rot", "att", "con", "acq"))
         rot = orc.rotate_around_axis(gt, axis, deg)
-        att = orc.attenuate3d(rot, 0.01)
+        att = orc.attenuate3d(rot, p.delta)
         assert np.array_equal(res["rot"], rot) and np.array_equal(res["att"], att)
         con = orc.convolve_direct(att, psf0.copy())
         orc.adjust_image(con, 1e-4, 1.0)
