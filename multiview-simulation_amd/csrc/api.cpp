@@ -41,7 +41,11 @@ int parse_option(Options& o, const char* name, const char* value)
         else if (v == "2" || v == "lane") o.fused_rotate = 2; else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
-    if (n == "poisson_queue") return flag(&o.poisson_queue);
+    if (n == "poisson_queue") {
+        if (v == "1" || v == "on") o.poisson_queue = 1; else if (v == "0" || v == "off") o.poisson_queue = 0;
+        else if (v == "2" || v == "v1") o.poisson_queue = 2; else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
     if (n == "early_sum") return flag(&o.early_sum);
     if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
     if (n == "broadcast") {
@@ -69,7 +73,7 @@ const Options& env_options()
         if (const char* e = getenv("MVSIM_FFT_BACKEND")) (void)parse_option(o, "fft_backend", e);
         if (const char* e = getenv("MVSIM_FFT_PAD")) (void)parse_option(o, "fft_pad", e);
         if (getenv("MVSIM_NO_FUSED_ROTATE")) o.fused_rotate = 0;
-        if (getenv("MVSIM_POISSON_NOQUEUE")) o.poisson_queue = false;
+        if (getenv("MVSIM_POISSON_NOQUEUE")) o.poisson_queue = 0;
         if (getenv("MVSIM_NO_EARLY_SUM")) o.early_sum = false;
         if (const char* e = getenv("MVSIM_GRAPH")) (void)parse_option(o, "graph", e);
         if (const char* e = getenv("MVSIM_BROADCAST")) (void)parse_option(o, "broadcast", e);
@@ -255,16 +259,17 @@ static int pick_method(int method, const int64_t kdim[3])
 }
 
 static int convolve_dev_impl(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const int64_t kdim[3],
-                             int method, float* out)
+                             int method, float* out, ConvTail* tail = nullptr)
 {
     MVSIM_CHECK_ARG(img != out, "convolve cannot run in place");
     if (pick_method(method, kdim) == 2) {
+        if (tail) tail->zstride = 1;
         ev_begin(ctx, ST_CONVOLVE);
         MVSIM_TRY(launch_stencil(ctx, img, dim, ctx->psf_dev.as<float>(), kdim, out));
         ev_end(ctx, ST_CONVOLVE);
         return MVSIM_OK;
     }
-    return fft_convolve(ctx, img, dim, ctx->psf_dev.as<float>(), kdim, out, true);
+    return fft_convolve(ctx, img, dim, ctx->psf_dev.as<float>(), kdim, out, tail);
 }
 
 static int scal_ptr(mvsim_ctx* ctx, double** partial, double** scal)
@@ -659,21 +664,33 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     double *partial, *scal;
     MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
     const int method = pick_method(p->conv_method, kdim);
-    MVSIM_TRY(convolve_dev_impl(ctx, att, dim, kdim, method, con));
+    const bool materialise = o->con != nullptr;
+    const bool noise = p->snr >= 0.0f;
+    // only every inc-th plane is acquired: when the adjusted volume itself is not asked for, the last two passes of the
+    // convolution need not produce the other planes (the convolution says whether it could honour that)
+    ConvTail tail;
+    const long long plane_vox = (long long)dim[0] * dim[1];
+    tail.zstride = (!materialise && p->inc > 1 && plane_vox % 4 == 0 && (!noise || ctx->opt.poisson_queue == 1)) ? p->inc : 1;
+    MVSIM_TRY(convolve_dev_impl(ctx, att, dim, kdim, method, con, &tail));
 
     ev_begin(ctx, ST_ADJUST);
     if (method == 2) MVSIM_TRY(launch_sum(ctx->stream, con, n, partial, scal));   // FFT path sums in its crop epilogue
     MVSIM_TRY(launch_adjust_corr(ctx->stream, scal, n, p->min_value, p->target_average));
-    const bool materialise = o->con != nullptr;
     if (materialise) MVSIM_TRY(launch_adjust_apply(ctx->stream, con, n, scal, p->min_value));
     ev_end(ctx, ST_ADJUST);
 
-    const bool noise = p->snr >= 0.0f;
     void* qws = nullptr;
     if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc), nullptr))); qws = ctx->pqueue.p; }
     ev_begin(ctx, ST_EXTRACT);
-    MVSIM_TRY(launch_extract(ctx->stream, con, o->acq, dim, p->inc, !materialise, scal, p->min_value, noise,
-                             mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws, ctx->opt.poisson_queue));
+    if (tail.zstride > 1) {
+        // `con` holds the acquired planes only: read them in order, count the RNG in source planes
+        const int64_t cdim[3] = {dim[0], dim[1], mvsim_extract_nz(dim[2], p->inc)};
+        MVSIM_TRY(launch_extract(ctx->stream, con, o->acq, cdim, 1, true, scal, p->min_value, noise,
+                                 mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws, ctx->opt.poisson_queue, p->inc));
+    } else {
+        MVSIM_TRY(launch_extract(ctx->stream, con, o->acq, dim, p->inc, !materialise, scal, p->min_value, noise,
+                                 mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws, ctx->opt.poisson_queue));
+    }
     ev_end(ctx, ST_EXTRACT);
 
     if (correction) {
@@ -734,7 +751,7 @@ int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t 
     }
     const SlabRange slab{(int)za, (int)(zb - za), (int)z0, (int)(z1 - z0)};
     MVSIM_TRY(custom_fft_convolve_slab(ctx, ctx->vol_b.as<float>(), dim, ctx->psf_dev.as<float>(), kdim, P, slab,
-                                       ctx->vol_a.as<float>()));
+                                       ctx->vol_a.as<float>(), nullptr));
     double *partial, *scal;
     MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
     MVSIM_HIP(hipMemcpyAsync(slab_sum, scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -93,7 +93,8 @@ struct Options {
     bool    rocfft = false;            // library fallback instead of the hand-written passes
     int     fused_rotate = 1;          // rotate+attenuate as one kernel when the rotation is about x: 0 off, 1 row geometry
                                        // shared through LDS (production), 2 recomputed per lane (kept for A/B runs)
-    bool    poisson_queue = true;      // two-launch Poisson (streaming kernel + work-queue resolver)
+    int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
+                                       // resolver, production), 2: its predecessor (per-slot divergent phase 1), 0: one kernel
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
     int     graph = 0;                 // replay simulate_view_dev from a captured hipGraph (small, launch-bound volumes)
     bool    bcast_ring = false;        // ground-truth broadcast as one ncclBroadcast instead of scatter + all-gather
@@ -131,6 +132,8 @@ struct mvsim_ctx {
     mvsim::DevBuf cfft_g1, cfft_g2;         // compact PSF intermediates [Kz][Ky][Hxp], [Kz][Py][Hxp]
     mvsim::Options opt;
     std::unordered_set<const void*> lds_attr_set;   // kernels whose dynamic-LDS limit has been raised on this device
+    std::map<std::string, void*> box_weights;   // early-sum weights (fft_kernels.hip: ensure_box_weights)
+    mvsim::DevBuf partials_z;               // per-block sums of the z pass
     std::map<int, void*> twiddles;          // 2*length + kind -> device twiddle table (fft_kernels.hip)
     std::map<std::string, mvsim::FftPlan> plans;
     bool   fft_ready = false;
@@ -185,7 +188,7 @@ int launch_norm_apply(hipStream_t s, float* img, int64_t n, const double* scal);
 // extract (+ optional adjust using scal[1]) (+ optional Poisson).  in: Nx*Ny*Nz, out: Nx*Ny*nzo
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                   uint32_t stream, uint64_t index_offset, void* queue_ws, bool use_queue);
+                   uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc = 0);
 // bytes of the Poisson work queue (HBM) for n_out output voxels
 size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity);
 int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc);
@@ -211,14 +214,21 @@ int launch_stencil(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const
 // raise a kernel's dynamic-LDS limit once per context (hipFuncSetAttribute is not free on a launch path)
 int ensure_lds_attr(mvsim_ctx* ctx, const void* kernel, size_t bytes);
 
+// What the caller would like the tail of the convolution to do beyond "write the convolved volume"; every request is
+// optional for the implementation, which reports back what it did.
+struct ConvTail {
+    // in: produce only the planes k * zstride (the planes extractSlices will read) into a COMPACT out[nk][Ny][Nx].
+    // Possible when adjustImage's sum comes from the spectrum side (early sum); out: the stride actually applied (1 = full).
+    int zstride = 1;
+};
 int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,
-                 const int64_t kdim[3], float* out_dev, bool want_sum);
+                 const int64_t kdim[3], float* out_dev, ConvTail* tail);
 void fft_release(mvsim_ctx* ctx);
 void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3], const Options& opt);
 // hand-written LDS FFT path (fft_kernels.hip)
 bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3], const Options& opt);
 int  custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
-                         const int64_t kdim[3], const int64_t P[3], float* out);
+                         const int64_t kdim[3], const int64_t P[3], float* out, ConvTail* tail);
 // z-slab form (direct z pass only): `img` holds the planes [z_in0, z_in0 + nz_in) of a volume with dim[2] planes,
 // `out` receives the planes [z_out0, z_out0 + nz_out); every plane the Kz taps reach (mirrored at the global faces)
 // must lie inside the input range.  The sum left in the context's scalar slot is the sum of the output planes.
@@ -226,7 +236,7 @@ struct SlabRange {
     int z_in0, nz_in, z_out0, nz_out;
 };
 int  custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
-                              const int64_t kdim[3], const int64_t P[3], const SlabRange& slab, float* out);
+                              const int64_t kdim[3], const int64_t P[3], const SlabRange& slab, float* out, ConvTail* tail);
 void custom_fft_release(mvsim_ctx* ctx);
 bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[5], const Options& opt);
 

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
 }
 
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partial, long long count,
-                                                          double* __restrict__ scal)
+                                                          double* __restrict__ scal, double factor)
 {
     __shared__ double sh[16];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < 16; ++w) t += sh[w];
-        scal[0] = t;
+        scal[0] = t * factor;
     }
 }
 
@@ -754,6 +754,13 @@ struct ZConvArgs {
     // z-slab tiling: the mirror boundary acts on the GLOBAL plane index; src holds the global planes from z_in0 on,
     // dst plane 0 is global plane z_out0 (whole volume: nz_global = nz, both offsets 0)
     int           nz_global, z_in0, z_out0;
+    // adjustImage's sum taken from the spectrum side (null: not wanted).  The sum of the cropped convolved volume is a
+    // linear functional of this pass's output: sum = scale * SUM_{z, ky, kx <= M} Re( F[z][ky][kx] * wx[kx] * wy[ky] ) with
+    // wx[kx] = c(kx) * SUM_{x < Nx} e^{+2 pi i kx x / Px} (c = 1 for kx = 0 and M, else 2: Hermitian half), wy[ky] alike
+    // without c.  One partial (double) per block.
+    const double2* wx;
+    const double2* wy;
+    double*       sum_partial;
 };
 
 __device__ __forceinline__ int mirror_index(int i, int n)
@@ -821,6 +828,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     __syncthreads();
     const int line = tid & (NLZ - 1);
     const int nzb = (zn + ZU - 1) / ZU;
+    double sre = 0.0, sim = 0.0;                          // this lane's sum over z of its line's outputs
     for (int zb = tid / NLZ; zb < nzb; zb += ZT / NLZ) {
         const int z0 = zb * ZU;
         v2f acc[ZU];
@@ -863,6 +871,37 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
         for (int u = 0; u < ZU; ++u) {
             if (z0 + u < zn) *d = make_float2(acc[u].x, acc[u].y);
             d += p.plane;
+        }
+        if (p.sum_partial) {
+            // pairwise in single precision over the (at most) 16 outputs, then double: error ~2 roundings of fp32
+            v2f t8[ZU / 2];
+#pragma unroll
+            for (int u = 0; u < ZU / 2; ++u) {
+                const v2f a = (z0 + 2 * u < zn) ? acc[2 * u] : v2f{0.f, 0.f};
+                const v2f b = (z0 + 2 * u + 1 < zn) ? acc[2 * u + 1] : v2f{0.f, 0.f};
+                t8[u] = a + b;
+            }
+#pragma unroll
+            for (int w = ZU / 4; w >= 1; w >>= 1)
+#pragma unroll
+                for (int u = 0; u < w; ++u) t8[u] = t8[u] + t8[u + w];
+            sre += (double)t8[0].x;
+            sim += (double)t8[0].y;
+        }
+    }
+    if (p.sum_partial) {
+        __shared__ double red[ZT / 64];
+        const double2 a = p.wx[(int)blockIdx.y * NLZ + line], b = p.wy[blockIdx.z];
+        const double wr = a.x * b.x - a.y * b.y, wi = a.x * b.y + a.y * b.x;
+        double t = sre * wr - sim * wi;                   // Re( s * W )
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = t;
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int w = 0; w < ZT / 64; ++w) sum += red[w];
+            p.sum_partial[((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sum;
         }
     }
 }
@@ -1132,10 +1171,48 @@ static int ensure_twiddles(mvsim_ctx* ctx, int L, int kind, const float2** out)
     return MVSIM_OK;
 }
 
+// Weights of the early sum (see ZConvArgs): w[k] = c(k) * SUM_{n < N} e^{+2 pi i k n / P}, k < len; c(k) = 1 unless `half`,
+// where c = 1 for k = 0 and k = P/2, 2 for 0 < k < P/2 and 0 beyond (the half spectrum's padding columns).  Built on the
+// host in double from an exact P-entry table of e^{2 pi i j / P} (the angle index k n mod P is integer arithmetic).
+static int ensure_box_weights(mvsim_ctx* ctx, int N, int P, int len, bool half, const double2** out)
+{
+    char key[64];
+    snprintf(key, sizeof(key), "%d/%d/%d/%d", N, P, len, half ? 1 : 0);
+    auto it = ctx->box_weights.find(key);
+    if (it != ctx->box_weights.end()) { *out = reinterpret_cast<const double2*>(it->second); return MVSIM_OK; }
+    std::vector<double> ct((size_t)P), st((size_t)P);
+    for (int j = 0; j < P; ++j) {
+        const double a = 2.0 * M_PI * (double)j / (double)P;
+        ct[j] = std::cos(a); st[j] = std::sin(a);
+    }
+    std::vector<double2> h((size_t)len, make_double2(0.0, 0.0));
+    for (int k = 0; k < len; ++k) {
+        if (half && k > P / 2) break;
+        if (!half && k >= P) break;
+        long double re = 0.0L, im = 0.0L;
+        for (int n = 0; n < N; ++n) {
+            const int j = (int)(((long long)k * n) % P);
+            re += ct[j]; im += st[j];
+        }
+        const double c = half ? ((k == 0 || 2 * k == P) ? 1.0 : 2.0) : 1.0;
+        h[k] = make_double2(c * (double)re, c * (double)im);
+    }
+    void* d = nullptr;
+    MVSIM_HIP(hipMalloc(&d, h.size() * sizeof(double2)));
+    hipError_t e = hipMemcpy(d, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); set_error("weight upload failed: %s", hipGetErrorString(e)); return MVSIM_EHIP; }
+    ctx->box_weights[key] = d;
+    *out = reinterpret_cast<const double2*>(d);
+    return MVSIM_OK;
+}
+
 void custom_fft_release(mvsim_ctx* ctx)
 {
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     ctx->twiddles.clear();
+    for (auto& kv : ctx->box_weights) (void)hipFree(kv.second);
+    ctx->box_weights.clear();
+    ctx->partials_z.release();
     ctx->cfft_f.release();
     ctx->cfft_g.release();
     ctx->cfft_g1.release();
@@ -1160,14 +1237,14 @@ bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[
 }
 
 int custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
-                        const int64_t kdim[3], const int64_t P[3], float* out)
+                        const int64_t kdim[3], const int64_t P[3], float* out, ConvTail* tail)
 {
     const SlabRange whole{0, (int)dim[2], 0, (int)dim[2]};
-    return custom_fft_convolve_slab(ctx, img, dim, psf, kdim, P, whole, out);
+    return custom_fft_convolve_slab(ctx, img, dim, psf, kdim, P, whole, out, tail);
 }
 
 int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
-                             const int64_t kdim[3], const int64_t P[3], const SlabRange& slab, float* out)
+                             const int64_t kdim[3], const int64_t P[3], const SlabRange& slab, float* out, ConvTail* tail)
 {
     using namespace fft;
     const bool is_slab = slab.nz_in != (int)dim[2] || slab.nz_out != (int)dim[2];
@@ -1177,6 +1254,10 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     const int tile_y = lines_per_tile(py), tile_z = lines_per_tile(pz);
     // z pass: direct convolution with the Kz taps (k_zconv) unless the PSF is deep or the FFT formulation is asked for
     const bool zdirect = ctx->opt.zpass == 2 ? false : kz <= 64;
+    const bool early = zdirect && ctx->opt.early_sum;             // adjustImage's sum from pass C' instead of pass E
+    // with the sum known before passes D and E, they only have to produce the planes extractSlices reads
+    int zstride = (tail && early && !is_slab && tail->zstride > 1) ? tail->zstride : 1;
+    if (tail) tail->zstride = zstride;
     if (is_slab && !zdirect) {
         set_error("z-slab tiling needs the direct z pass (PSF depth %d > 64 or option fft_zpass=fft)", kz);
         return MVSIM_EINVAL;
@@ -1279,7 +1360,21 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             z.src = F; z.dst = G; z.taps = G2; z.plane = plane; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
             z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
             z.zc = zconv_chunk(nzo, kz);
+            const float scale_f = (float)(0.25 / ((double)px * (double)py));
+            long long zblocks = 0;
+            if (early) {
+                MVSIM_TRY(ensure_box_weights(ctx, (int)dim[0], px, hxp, true, &z.wx));
+                MVSIM_TRY(ensure_box_weights(ctx, (int)dim[1], py, py, false, &z.wy));
+                zblocks = (long long)((nzo + z.zc - 1) / z.zc) * (hxp / NLZ) * py;
+                MVSIM_TRY(ctx->partials_z.reserve((size_t)zblocks * sizeof(double)));
+                z.sum_partial = ctx->partials_z.as<double>();
+            }
             MVSIM_TRY(launch_zconv(ctx, z, py));
+            if (early) {
+                // same factor pass E applies to every voxel (a float), so that the two sums estimate the same quantity
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, z.sum_partial, zblocks, scal, (double)scale_f);
+                MVSIM_HIP(hipGetLastError());
+            }
             Fz = G;
         } else {
         LinesArgs c{};
@@ -1295,16 +1390,19 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         b.src = b.dst = Fz;
         b.tw = tw_py;
         b.store_limit = (int)dim[1];                                  // pass E only reads rows y < Ny
+        const int nzd = zdirect ? nzo : (int)dim[2];                  // planes z >= Nz are never read
+        const int nk = (nzd - 1) / zstride + 1;                       // planes 0, zstride, 2 zstride, ...
+        b.src_outer = b.dst_outer = plane * zstride;
         ev_begin(ctx, ST_PASS_D);
-        MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, zdirect ? nzo : (int)dim[2]));   // planes z >= Nz are never read
+        MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, nk));
         ev_end(ctx, ST_PASS_D);
         ev_begin(ctx, ST_PASS_E);
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
         const float scale = (float)(0.25 / ((double)px * (double)py * (zdirect ? 1.0 : (double)pz)));
         int nblk = 0;
-        MVSIM_TRY(launch_c2r(ctx, M, Fz, out, tw_m, tw_px, hxp, py, (int)dim[0], (int)dim[1], rows_out, scale,
+        MVSIM_TRY(launch_c2r(ctx, M, Fz, out, tw_m, tw_px, hxp, py * zstride, (int)dim[0], (int)dim[1], (long long)dim[1] * nk, scale,
                              ctx->partials_e.as<double>(), &nblk));
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal);
+        if (!early) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal, 1.0);
         MVSIM_HIP(hipGetLastError());
         ev_end(ctx, ST_PASS_E);
     }

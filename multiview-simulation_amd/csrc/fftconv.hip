@@ -251,10 +251,11 @@ void fft_release(mvsim_ctx* ctx)
 
 
 int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,
-                 const int64_t kdim[3], float* out_dev, bool want_sum)
+                 const int64_t kdim[3], float* out_dev, ConvTail* tail)
 {
     int64_t P[3];
-    if (custom_fft_sizes(dim, kdim, P, ctx->opt)) return custom_fft_convolve(ctx, img_dev, dim, psf_dev, kdim, P, out_dev);
+    if (custom_fft_sizes(dim, kdim, P, ctx->opt)) return custom_fft_convolve(ctx, img_dev, dim, psf_dev, kdim, P, out_dev, tail);
+    if (tail) tail->zstride = 1;                       // the library path produces the whole volume
     choose_padded(dim, kdim, P, ctx->opt);
     FftPlan* pl = nullptr;
     MVSIM_TRY(get_plan(ctx, P, &pl));
@@ -301,7 +302,6 @@ int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], con
         MVSIM_FFT(rocfft_execute(pl->inv, in, out, pl->info));
     }
     const float scale = (float)(1.0 / ((double)P[0] * (double)P[1] * (double)P[2]));
-    (void)want_sum;
     MVSIM_TRY(launch_crop_scale_sum(ctx->stream, real, P, out_dev, dim, scale, partial, scal));
     ev_end(ctx, ST_CONVOLVE);
     return MVSIM_OK;

@@ -637,7 +637,7 @@ int launch_norm_apply(hipStream_t s, float* img, int64_t n, const double* scal)
 // ------------------------------------------------------------------------------------------------
 template <bool ADJUST, bool NOISE>
 __global__ __launch_bounds__(256) void k_extract(const float* __restrict__ in, float* __restrict__ out,
-                                                 long long plane, long long nzo, int inc,
+                                                 long long plane, long long nzo, int inc, int idx_inc,
                                                  const double* __restrict__ scal, float min_value, double mul,
                                                  uint32_t k0, uint32_t k1, uint32_t stream,
                                                  unsigned long long index_offset)
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void k_extract(const float* __restrict__ in, f
         const long long src = k * inc * plane + i;
         float v = in[src];
         if (ADJUST) v = adjust_one(v, corr, min_value);
-        if (NOISE) v = poisson_counter((double)v * mul, k0, k1, stream, index_offset + (unsigned long long)src);
+        if (NOISE) v = poisson_counter((double)v * mul, k0, k1, stream, index_offset + (unsigned long long)(k * idx_inc * plane + i));
         out[o] = v;
     }
 }
@@ -702,15 +702,6 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
 //                      every lane starts with real work -- the divergent fp64 code (logs, divisions) no longer
 //                      runs once per voxel slot with 1-in-7 lanes active.
 // Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.
-struct PItem {
-    unsigned long long index;     // source voxel index (RNG counter)
-    unsigned long long out;       // element index in the output
-    float v;                      // adjusted voxel value (lambda = v * mul)
-    unsigned int attempt;         // first attempt still to evaluate (0: exact test of attempt 0 pending)
-};
-
-constexpr unsigned int kSmallLambdaItem = 0xFFFFFFFFu;   // PItem::attempt of an inversion (lambda < 10) work item
-
 template <bool ADJUST>
 __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict__ in, float* __restrict__ out,
                                                         long long plane4, long long nzo, int inc,
@@ -820,6 +811,65 @@ __global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict_
     }
 }
 
+// Production form of the streaming kernel: same walk, phase 1 by poisson_phase1 (wave-level compaction of the bright
+// voxels, fp32 execution shortcuts).  Bit-identical counts; k_extract4_noise above is kept for A/B runs
+// (option poisson_phase1=v1).
+template <bool ADJUST>
+__global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict__ in, float* __restrict__ out,
+                                                         long long plane4, long long nzo, int inc, int idx_inc,
+                                                         const double* __restrict__ scal, float min_value, double mul,
+                                                         uint32_t k0, uint32_t k1, uint32_t stream,
+                                                         unsigned long long index_offset, PItem* __restrict__ queue,
+                                                         unsigned int* __restrict__ qcount, unsigned int segcap)
+{
+    __shared__ unsigned int nq, nqs;
+    __shared__ P1Scratch scratch[4];
+    if (threadIdx.x == 0) { nq = 0u; nqs = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    P1Args pa;
+    pa.mul = mul; pa.mulf = (float)mul; pa.k0 = k0; pa.k1 = k1; pa.stream = stream;
+    pa.seg = queue + (unsigned long long)blockIdx.x * segcap; pa.segcap = segcap; pa.nq = &nq; pa.nqs = &nqs;
+    double corr = 1.0;
+    if (ADJUST) corr = scal[1];
+    const long long total4 = plane4 * nzo;
+    const long long nthreads = (long long)gridDim.x * 256;
+    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+    const bool small32 = total4 < (1ll << 32);
+    // the trip count is uniform per wave (lanes past the end carry invalid voxels): ballots need every lane
+    const long long wave_first = (long long)blockIdx.x * 256 + wave * 64;
+    for (long long o0 = wave_first; o0 < total4; o0 += nthreads) {
+        const long long o = o0 + lane;
+        const bool valid = o < total4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        long long src4 = o, idx4 = o;                 // where the voxels are read / what the RNG counter says they are
+        if (valid) {
+            if (inc != 1 || idx_inc != 1) {
+                const long long k = small32 ? (long long)((unsigned)o / (unsigned)plane4) : o / plane4;
+                src4 = k * inc * plane4 + (o - k * plane4);
+                idx4 = k * idx_inc * plane4 + (o - k * plane4);
+            }
+            v = in4[src4];
+            if (ADJUST) {
+                v.x = adjust_one(v.x, corr, min_value);
+                v.y = adjust_one(v.y, corr, min_value);
+                v.z = adjust_one(v.z, corr, min_value);
+                v.w = adjust_one(v.w, corr, min_value);
+            }
+        }
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float ov[4];
+        poisson_phase1(vv, valid, index_offset + 4ull * (unsigned long long)idx4, 4ull * (unsigned long long)o, pa, &scratch[wave], lane, ov);
+        if (valid) out4[o] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        qcount[2 * blockIdx.x] = nq;
+        qcount[2 * blockIdx.x + 1] = nqs;
+    }
+}
+
 // One block per queue segment (same grid as k_extract4_noise; the grid-stride walk of that kernel spreads the
 // bright voxels evenly over the segments).
 __global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out, const PItem* __restrict__ queue,
@@ -881,8 +931,12 @@ size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)
 
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                   uint32_t stream, uint64_t index_offset, void* queue_ws, bool use_queue)
+                   uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc)
 {
+    // index_inc: plane stride of the RNG counter when it differs from the plane stride of the reads (a compact input
+    // that holds only the planes k * index_inc of the source volume); 0 = the same as inc
+    if (index_inc <= 0) index_inc = inc;
+    const bool use_queue = queue_mode != 0, use_queue_v1 = queue_mode == 2;
     const long long plane = (long long)dim[0] * dim[1];
     const long long nzo = (dim[2] - 1) / inc + 1;
     const long long total = plane * nzo;
@@ -901,12 +955,20 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
             poisson_geometry(total, &qblocks, &segcap);
             unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
             PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int));
-            if (adjust)
-                hipLaunchKernelGGL((k_extract4_noise<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
+            if (use_queue_v1) {
+                if (adjust)
+                    hipLaunchKernelGGL((k_extract4_noise<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
+                                       scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
+                else
+                    hipLaunchKernelGGL((k_extract4_noise<false>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
+                                       scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
+            } else if (adjust) {
+                hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
                                    scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
-            else
-                hipLaunchKernelGGL((k_extract4_noise<false>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
+            } else {
+                hipLaunchKernelGGL((k_extract4_noise2<false>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
                                    scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
+            }
             hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks), dim3(256), 0, s, out, queue, qcount, segcap, mul, k0, k1, stream);
         }
         else if (adjust && noise) MVSIM_LAUNCH_EX4(true, true);
@@ -920,7 +982,7 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
     long long want = (total + 255) / 256;
     int blocks = (int)(want < 1 ? 1 : (want > 256 * 32 ? 256 * 32 : want));
 #define MVSIM_LAUNCH_EX(A, N)                                                                             \
-    hipLaunchKernelGGL((k_extract<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane, nzo, inc, scal, \
+    hipLaunchKernelGGL((k_extract<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, \
                        min_value, mul, k0, k1, stream, (unsigned long long)index_offset)
     if (adjust && noise) MVSIM_LAUNCH_EX(true, true);
     else if (adjust) MVSIM_LAUNCH_EX(true, false);

@@ -398,4 +398,147 @@ __device__ __forceinline__ float4 poisson_counter4(double l0, double l1, double 
     return out;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Phase 1 of the production sampler, one wave at a time (used by k_extract4_noise and by the adjust + Poisson
+// epilogue of the convolution's last pass).  Every lane brings 4 consecutive voxels (one Philox group).  What is
+// cheap is decided here, everything else becomes a work item for k_poisson_resolve:
+//   * lambda <= 0 / NaN                       -> 0
+//   * 0 < lambda < 10 (inversion)             -> the "count is 0" shortcut; a possible count >= 1 is queued
+//   * lambda >= 10 (PTRS)                     -> the bright voxels of the wave are COMPACTED into a wave-private LDS list
+//                                                (ballot + prefix count) and the attempt-0 squeeze then runs one voxel per
+//                                                lane with all lanes busy; what needs the exact test or a retry is queued
+// Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.  Two things are pure execution
+// shortcuts that cannot change a decision:
+//   - the regime (small / bright) is read off an fp32 product with a guard band; inside the band the fp64 product decides;
+//   - the shortcut of the inversion regime, "u < exp(-lambda)" whenever u < 1 - lambda - 1e-12, is tested in fp32 with a
+//     margin (1e-6) that covers every fp32 rounding involved, so it fires only where the fp64 statement holds.
+// ------------------------------------------------------------------------------------------------------------
+struct PItem {
+    unsigned long long index;     // source voxel index (RNG counter)
+    unsigned long long out;       // element index in the output
+    float v;                      // adjusted voxel value (lambda = v * mul)
+    unsigned int attempt;         // first attempt still to evaluate (0: exact test of attempt 0 pending)
+};
+constexpr unsigned int kSmallLambdaItem = 0xFFFFFFFFu;   // PItem::attempt of an inversion (lambda < 10) work item
+
+struct __attribute__((aligned(8))) BrightItem {
+    unsigned int local;           // 4 * lane + component inside the wave's slot
+    float v;
+};
+
+// wave-private LDS scratch of phase 1 (4 KB)
+struct P1Scratch {
+    BrightItem list[256];
+    float outb[256];
+    unsigned long long index4[64], out4[64];
+};
+
+struct P1Args {                   // wave-uniform
+    double mul;
+    float mulf;
+    uint32_t k0, k1, stream;
+    PItem* seg;                   // this block's queue segment
+    unsigned int segcap;
+    unsigned int* nq;             // LDS append counters of the block: bright items (front), inversion items (back)
+    unsigned int* nqs;
+};
+
+__device__ __forceinline__ void p1_wave_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, unsigned long long index4, unsigned long long out4,
+                                               const P1Args& a, P1Scratch* ws, int lane, float ov[4])
+{
+    int cls[4];                   // 0: lambda <= 0 or NaN, 1: inversion regime, 2: PTRS regime
+    float lf[4];
+    bool small_any = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        lf[c] = vv[c] * a.mulf;
+        int k;
+        if (!valid || !(vv[c] > 0.f) || !(a.mul > 0.0)) k = 0;
+        else if (lf[c] < 9.99f) k = 1;
+        else if (lf[c] > 10.01f) k = 2;
+        else k = ((double)vv[c] * a.mul >= 10.0) ? 2 : 1;
+        cls[c] = k;
+        small_any |= k == 1;
+        ov[c] = 0.f;
+    }
+    if (small_any) {
+        const unsigned long long g = index4 >> 2;
+        const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), a.stream, 0u, a.k0, a.k1);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (cls[c] == 1) {
+                const float uf = (float)w[c] * 0x1.0p-32f;
+                if (!(lf[c] < 1.0f && uf < (1.0f - lf[c]) - 1.0e-6f)) {
+                    const unsigned int pos = atomicAdd(a.nqs, 1u);
+                    PItem it;
+                    it.index = index4 + (unsigned long long)c;
+                    it.out = out4 + (unsigned long long)c;
+                    it.v = vv[c];
+                    it.attempt = kSmallLambdaItem;
+                    a.seg[a.segcap - 1u - pos] = it;
+                }
+            }
+    }
+    // bright voxels of the wave -> dense list
+    unsigned int nb = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool b = cls[c] == 2;
+        const unsigned long long m = __ballot(b);
+        if (m != 0ull) {
+            const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            if (b) {
+                BrightItem bi;
+                bi.local = 4u * (unsigned int)lane + (unsigned int)c;
+                bi.v = vv[c];
+                ws->list[nb + pre] = bi;
+            }
+            nb += (unsigned int)__popcll(m);
+        }
+    }
+    if (nb == 0u) return;                                   // wave-uniform
+    ws->index4[lane] = index4;
+    ws->out4[lane] = out4;
+    p1_wave_order();
+    for (unsigned int i = (unsigned int)lane; i < nb; i += 64u) {
+        const BrightItem bi = ws->list[i];
+        const unsigned int owner = bi.local >> 2, comp = bi.local & 3u;
+        const unsigned long long idx = ws->index4[owner] + comp;
+        const double lam = (double)bi.v * a.mul;
+        const unsigned long long pr = idx >> 1;
+        const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), a.stream, 1u, a.k0, a.k1);
+        const bool odd = (idx & 1ull) != 0ull;
+        double us, V, kd;
+        // (the fp32 screen of the exact test stays in the resolver: run here it costs the wave its ~60 instructions
+        // for the ~18 % of lanes that need it -- measured: +120 us here against -100 us there)
+        const int st = ptrs_fast(ptrs_setup(lam), lam, odd ? r.z : r.x, odd ? r.w : r.y, us, V, kd);
+        float res = 0.f;
+        if (st == 0) {
+            res = (float)(long long)kd;
+        } else {
+            // the segment holds every voxel of the block (worst case: all pending), so this cannot overflow
+            const unsigned int pos = atomicAdd(a.nq, 1u);
+            PItem it;
+            it.index = idx;
+            it.out = ws->out4[owner] + comp;
+            it.v = bi.v;
+            it.attempt = st == 2 ? 0u : 1u;                 // exact test of attempt 0, or straight to a retry
+            a.seg[pos] = it;
+        }
+        ws->outb[bi.local] = res;
+    }
+    p1_wave_order();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (cls[c] == 2) ov[c] = ws->outb[4 * lane + c];
+    p1_wave_order();                                        // the scratch is reused by the wave's next slot
+}
+
 }  // namespace mvsim

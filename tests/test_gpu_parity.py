@@ -408,7 +408,8 @@ def test_golden_view_fixture(ctx, golden_dir):
 
 @pytest.mark.parametrize("method", [1, 2])
 @pytest.mark.parametrize("inc,snr", [(1, 25.0), (3, 25.0), (4, -1.0)])
-def test_fused_view_equals_staged_ops(ctx, orc, synth, method, inc, snr):
+def test_fused_view_equals_staged_ops(ctx, orc, synth, options, method, inc, snr):
+    options(early_sum=0)      # adjustImage's sum from pass E: the only difference to the staged sum is its summation order
     gt = synth.sphere_phantom(32)
     psf0 = synth.gaussian_psf(7, 7, 9, sigma=(1.2, 1.4, 2.5))
     p = ctx.view_params(degrees=60, inc=inc, snr=snr, seed=SEED, stream=3, conv_method=method)
@@ -1020,3 +1021,41 @@ def test_view_from_z_slab_host_buffers(ctx, synth):
     assert np.array_equal(np.concatenate(acq, axis=0), ref["acq"])
     with pytest.raises(ValueError):
         ctx.simulate_view_zslabs([gt[:7], gt[7:30]], psf.copy(), p, [14])          # slabs do not add up to the volume
+
+
+@pytest.mark.parametrize("shape,kshape", [((32, 32, 32), (9, 7, 7)), ((24, 40, 36), (5, 8, 6)), ((17, 23, 19), (7, 3, 5)),
+                                          ((64, 48, 48), (31, 5, 5)), ((40, 30, 30), (3, 3, 3))])
+def test_early_sum_from_the_spectrum_matches_pass_e(ctx, synth, options, shape, kshape):
+    """adjustImage needs the sum of the convolved volume BEFORE the last pass can adjust on the fly; it is taken from the
+    spectrum side (epilogue of the z pass: a weighted sum of the half spectrum) instead of from the voxels pass E
+    produces.  Both estimate the same quantity from the same float32 spectrum; they must agree to ~1e-7, which moves
+    isolated float roundings of the adjusted volume by one ulp and (rarely) a count."""
+    rng = np.random.default_rng(sum(shape))
+    gt = rng.random(shape, dtype=np.float32) * (rng.random(shape) < 0.3)
+    psf = rng.random(kshape, dtype=np.float32) + 0.05
+    p = ctx.view_params(degrees=20, inc=1, snr=25.0, seed=SEED, stream=1, conv_method=1)
+    options(early_sum=1)
+    a = ctx.simulate_view(gt, psf.copy(), p, want=("con", "acq"))
+    options(early_sum=0)
+    b = ctx.simulate_view(gt, psf.copy(), p, want=("con", "acq"))
+    assert abs(a["corr"] - b["corr"]) <= 3e-7 * b["corr"], (a["corr"], b["corr"])
+    assert np.max(np.abs(a["con"] - b["con"]) / b["con"]) <= 2.4e-7              # at most one ulp of float per voxel
+    assert (a["acq"] != b["acq"]).mean() < 2e-3
+
+
+@pytest.mark.parametrize("inc", [2, 3, 4, 7])
+def test_compact_planes_view_equals_full_view(ctx, synth, options, inc):
+    """With the sum known before the last two passes of the convolution (early sum), a view that does not return the
+    adjusted volume only produces the planes k * inc that extractSlices reads.  The acquisition must equal the one of a
+    view that materialises the whole volume (same planes through the same per-plane transforms, same RNG counters)."""
+    gt = synth.sphere_phantom(40)
+    psf = synth.gaussian_psf(7, 9, 11, sigma=(1.2, 1.4, 2.2))
+    for snr in (25.0, -1.0):
+        p = ctx.view_params(degrees=35, inc=inc, snr=snr, seed=SEED, stream=4, conv_method=1)
+        full = ctx.simulate_view(gt, psf.copy(), p, want=("con", "acq"))          # con requested: every plane is produced
+        compact = ctx.simulate_view(gt, psf.copy(), p, want=("acq",))
+        assert compact["acq"].shape == ((40 - 1) // inc + 1, 40, 40)
+        assert np.array_equal(compact["acq"], full["acq"])
+        assert compact["corr"] == full["corr"]
+        if snr < 0:
+            assert np.array_equal(compact["acq"], full["con"][::inc])
