@@ -47,6 +47,7 @@ int parse_option(Options& o, const char* name, const char* value)
         return MVSIM_OK;
     }
     if (n == "early_sum") return flag(&o.early_sum);
+    if (n == "fuse_tail") return flag(&o.fuse_tail);
     if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
     if (n == "broadcast") {
         if (v == "scatter_allgather" || v == "auto") o.bcast_ring = false; else if (v == "ring") o.bcast_ring = true; else return MVSIM_EINVAL;
@@ -75,6 +76,7 @@ const Options& env_options()
         if (getenv("MVSIM_NO_FUSED_ROTATE")) o.fused_rotate = 0;
         if (getenv("MVSIM_POISSON_NOQUEUE")) o.poisson_queue = 0;
         if (getenv("MVSIM_NO_EARLY_SUM")) o.early_sum = false;
+        if (getenv("MVSIM_NO_FUSE_TAIL")) o.fuse_tail = false;
         if (const char* e = getenv("MVSIM_GRAPH")) (void)parse_option(o, "graph", e);
         if (const char* e = getenv("MVSIM_BROADCAST")) (void)parse_option(o, "broadcast", e);
         // MVSIM_OPTIONS="name=value;name=value": any option by its mvsim_set_option name (experiments, A/B runs)
@@ -671,7 +673,26 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     ConvTail tail;
     const long long plane_vox = (long long)dim[0] * dim[1];
     tail.zstride = (!materialise && p->inc > 1 && plane_vox % 4 == 0 && (!noise || ctx->opt.poisson_queue == 1)) ? p->inc : 1;
+    if (method == 1 && ctx->opt.fuse_tail && (!noise || ctx->opt.poisson_queue == 1)) {
+        const size_t qb = noise ? fused_tail_queue_bytes(dim, kdim, p->inc, materialise, ctx->opt) : 0;
+        if (!noise || qb > 0) {
+            if (qb) MVSIM_TRY(ctx->pqueue.reserve(qb));
+            tail.want_fuse = true;
+            tail.min_value = p->min_value; tail.target_average = p->target_average;
+            tail.con_adj = materialise ? con : nullptr;
+            tail.acq = o->acq; tail.inc = p->inc; tail.noise = noise;
+            tail.mul = mvsim_poisson_mul((double)p->snr); tail.seed = p->seed; tail.stream = p->stream;
+        }
+    }
     MVSIM_TRY(convolve_dev_impl(ctx, att, dim, kdim, method, con, &tail));
+    if (tail.fused) {
+        // pass E adjusted, extracted and sampled (phase 1); the resolver has been enqueued behind it
+        if (correction) {
+            MVSIM_HIP(hipMemcpyAsync(correction, scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return MVSIM_OK;
+    }
 
     ev_begin(ctx, ST_ADJUST);
     if (method == 2) MVSIM_TRY(launch_sum(ctx->stream, con, n, partial, scal));   // FFT path sums in its crop epilogue

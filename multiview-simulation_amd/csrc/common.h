@@ -96,6 +96,10 @@ struct Options {
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
                                        // resolver, production), 2: its predecessor (per-slot divergent phase 1), 0: one kernel
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
+    bool    fuse_tail = false;         // adjust + extract + Poisson phase 1 in the epilogue of the convolution's last pass: saves
+                                       // the 8 N bytes of the convolved volume's round trip, but the merged kernel is bound by
+                                       // vector issue (0.61 ms against 0.25 + 0.36 ms for pass E and the streaming Poisson kernel
+                                       // at 512^3): measured neutral to slightly slower, so off by default
     int     graph = 0;                 // replay simulate_view_dev from a captured hipGraph (small, launch-bound volumes)
     bool    bcast_ring = false;        // ground-truth broadcast as one ncclBroadcast instead of scatter + all-gather
     int64_t fft_pad[3] = {0, 0, 0};    // explicit padded sizes on the rocFFT path (0: choose)
@@ -220,7 +224,24 @@ struct ConvTail {
     // in: produce only the planes k * zstride (the planes extractSlices will read) into a COMPACT out[nk][Ny][Nx].
     // Possible when adjustImage's sum comes from the spectrum side (early sum); out: the stride actually applied (1 = full).
     int zstride = 1;
+    // in: the caller would like the last pass to adjust (Tools.adjustImage), extract (every inc-th plane) and run phase 1 of
+    // the Poisson sampler itself instead of writing the convolved volume: everything below describes that request.
+    bool     want_fuse = false;
+    float    min_value = 0.f, target_average = 1.f;
+    float*   con_adj = nullptr;        // adjusted volume (all planes) if the caller wants it, else null
+    float*   acq = nullptr;            // acquisition
+    int      inc = 1;
+    bool     noise = false;
+    double   mul = 0.0;
+    uint64_t seed = 0;
+    uint32_t stream = 0;
+    // out: true when the convolution did all of that (sum, factor in the context's scalar slots; acquisition complete)
+    bool     fused = false;
 };
+// bytes of queue workspace the fused tail needs for this geometry (0: the geometry has no fused tail)
+size_t fused_tail_queue_bytes(const int64_t dim[3], const int64_t kdim[3], int inc, bool con_wanted, const Options& opt);
+int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
+                           double mul, uint64_t seed, uint32_t stream);
 int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,
                  const int64_t kdim[3], float* out_dev, ConvTail* tail);
 void fft_release(mvsim_ctx* ctx);

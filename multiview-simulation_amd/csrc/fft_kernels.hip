@@ -16,6 +16,7 @@
 // staging (and around the spectrum product of pass C).  Twiddles come from a host-computed (double
 // precision, rounded once) table staged in LDS.  Inverse transforms use conj(FFT(conj(.))).
 #include "common.h"
+#include "poisson_dev.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -169,6 +170,13 @@ template <> __device__ __forceinline__ void dft<9>(float2* u)
         u[k2 + 3] = b[1];
         u[k2 + 6] = b[2];
     }
+}
+
+// Tools.adjustImage on one voxel: (float)(v * corr), then + minValue as a second float rounding (Tools.java:150-155)
+__device__ __forceinline__ float adjust_one_f(float v, double corr, float min_value)
+{
+    const float t = (float)((double)v * corr);
+    return t + min_value;
 }
 
 // ---------------------------------------------------------------------------------- Stockham passes in LDS
@@ -566,13 +574,32 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* _
 
 // E: half spectrum rows -> real rows, cropped to nx, scaled; one partial sum (double) per block.
 // Wave-private rows as in pass A; rows are processed in batches of RB to bound register use.
-template <class PLAN>
+// FUSE: the rows do not go to HBM as the convolved volume; the epilogue applies adjustImage (the mean is known from the
+// z pass), stores the adjusted row only if the caller wants the volume, and turns the rows of acquired planes into the
+// acquisition: a copy (no noise) or phase 1 of the Poisson sampler (poisson_phase1; the rest is queued for
+// k_poisson_resolve).  Saves the 8 N bytes of the convolved volume's round trip and a launch.
+struct C2RFuse {
+    const double* scal;           // scal[1] = adjustImage's factor
+    float         min_value;
+    float*        con;            // adjusted volume, rows as this pass produces them (null: not wanted)
+    float*        acq;            // acquisition [planes][ny][nx]
+    int           acq_every;      // plane k of this pass is acquired iff k % acq_every == 0, as acquisition plane k / acq_every
+    int           idx_zstride;    // plane k of this pass is plane k * idx_zstride of the source volume (RNG counter)
+    int           noise;
+    double        mul;
+    uint32_t      k0, k1, stream;
+    PItem*        queue;          // per-block segments of `segcap` items
+    unsigned int* qcount;
+    unsigned int  segcap;
+};
+
+template <class PLAN, bool FUSE>
 __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* __restrict__ srcc,
                                                                  float* __restrict__ out,
                                                                  const float2* __restrict__ twg,
                                                                  const float2* __restrict__ twx, int hxp, int py,
                                                                  int nx, int ny, long long rows, float scale,
-                                                                 double* __restrict__ partial)
+                                                                 double* __restrict__ partial, C2RFuse f)
 {
     constexpr int M = PLAN::len;
     using C = CfgX<M>;
@@ -582,6 +609,10 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     double* red = reinterpret_cast<double*>(lds + NR * LP + M);              // NW doubles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2* wbuf = lds + wave * LW * LP;
+    // FUSE: behind the 32 doubles of `red`: two append counters, then one P1Scratch per wave
+    unsigned int* qctr = reinterpret_cast<unsigned int*>(red + 32);
+    P1Scratch* scratch = reinterpret_cast<P1Scratch*>(red + 34);
+    if (FUSE && tid == 0) { qctr[0] = 0u; qctr[1] = 0u; }
     for (int i = tid; i < M; i += T) tw[i] = twg[i];
     const long long row0 = (long long)blockIdx.x * NR + wave * LW;           // output rows (y < ny, z < nz)
 
@@ -662,6 +693,51 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     __syncthreads();                                  // twiddle table complete (rows are wave-private)
     PLAN::template run<LW>(wbuf, tw, lane);
     // z[n] = conj(buf[n]) = x[2n] + i x[2n+1]; lane q writes x[4q..4q+3]
+    if (FUSE) {
+        // nx % 4 == 0 and 16-byte aligned outputs are guaranteed by the launcher
+        const double corr = f.scal[1];
+        P1Args pa;
+        pa.mul = f.mul; pa.mulf = (float)f.mul; pa.k0 = f.k0; pa.k1 = f.k1; pa.stream = f.stream;
+        pa.seg = f.queue + (unsigned long long)blockIdx.x * f.segcap; pa.segcap = f.segcap; pa.nq = &qctr[0]; pa.nqs = &qctr[1];
+        const int nq4 = nx >> 2;
+        for (int j = 0; j < LW; ++j) {
+            const long long row = row0 + j;
+            if (row >= rows) break;                                          // wave-uniform
+            const unsigned urow = (unsigned)row;
+            const int k = (int)(urow / (unsigned)ny), y = (int)(urow - (unsigned)k * (unsigned)ny);
+            const bool acquired = (k % f.acq_every) == 0;
+            const float2* __restrict__ zrow = wbuf + j * LP;
+            const unsigned long long idx_row = (unsigned long long)nx * ((unsigned long long)y + (unsigned long long)ny * ((unsigned long long)k * (unsigned long long)f.idx_zstride));
+            const unsigned long long acq_row = (unsigned long long)nx * ((unsigned long long)y + (unsigned long long)ny * (unsigned long long)(k / f.acq_every));
+            for (int q0 = 0; q0 < nq4; q0 += 64) {                           // uniform trip count: phase 1 needs every lane
+                const int q = q0 + lane;
+                const bool valid = q < nq4;
+                float vv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (valid) {
+                    const float2 z0 = zrow[2 * q];
+                    const float2 z1 = (2 * q + 1 < M) ? zrow[2 * q + 1] : make_float2(0.f, 0.f);
+                    vv[0] = adjust_one_f(z0.x * scale, corr, f.min_value);
+                    vv[1] = adjust_one_f(-z0.y * scale, corr, f.min_value);
+                    vv[2] = adjust_one_f(z1.x * scale, corr, f.min_value);
+                    vv[3] = adjust_one_f(-z1.y * scale, corr, f.min_value);
+                    if (f.con) *reinterpret_cast<float4*>(f.con + row * nx + 4 * q) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
+                if (acquired) {
+                    float ov[4] = {vv[0], vv[1], vv[2], vv[3]};
+                    if (f.noise)
+                        poisson_phase1(vv, valid, idx_row + 4ull * (unsigned long long)q, acq_row + 4ull * (unsigned long long)q, pa,
+                                       &scratch[wave], lane, ov);
+                    if (valid) *reinterpret_cast<float4*>(f.acq + acq_row + 4 * q) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && f.noise) {                                           // no queue without noise (qcount is null then)
+            f.qcount[2 * blockIdx.x] = qctr[0];
+            f.qcount[2 * blockIdx.x + 1] = qctr[1];
+        }
+        return;
+    }
     double acc = 0.0;
     const bool vec_out = (nx & 3) == 0;
     for (int j = 0; j < LW; ++j) {
@@ -736,9 +812,18 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
 constexpr int NLZ = 16, ZU = 16, ZJ = 8, ZT = 256, ZPITCH = NLZ + 1;
 constexpr int ZLPR = NLZ / 2;                    // lanes per staged row (16 B each)
 constexpr int ZRPI = ZT / ZLPR;                  // rows per staging iteration
-constexpr int ZNIT = 9;                          // staged rows <= ZNIT * ZRPI = 224 (zconv_chunk keeps the tile below that)
-constexpr int ZBLOCKS_PER_CU = 3;
-constexpr size_t ZLDS_TARGET = 44 * 1024;       // four resident blocks per CU
+#ifndef MVSIM_ZNIT
+#define MVSIM_ZNIT 9
+#endif
+#ifndef MVSIM_ZBLK
+#define MVSIM_ZBLK 3
+#endif
+#ifndef MVSIM_ZLDS
+#define MVSIM_ZLDS (44 * 1024)
+#endif
+constexpr int ZNIT = MVSIM_ZNIT;                 // staged rows <= ZNIT * ZRPI (zconv_chunk keeps the tile below that)
+constexpr int ZBLOCKS_PER_CU = MVSIM_ZBLK;
+constexpr size_t ZLDS_TARGET = MVSIM_ZLDS;
 // float2 elements of the staged input region (rounded to 16 bytes: the tap region behind it is accessed as float4)
 __host__ __device__ constexpr size_t zconv_frows(int zc, int kz, int kzp)
 {
@@ -778,8 +863,11 @@ constexpr int TNIT = 64 / ZRPI;                       // kzp <= 64 rows of taps
 
 // One block per tile = (z chunk, 16-column group, row ky): grid (chunks, Hxp/16, Py) -- the chunks of a column are
 // dispatched together, so a chunk's halo rows are usually still in L2 / Infinity Cache from its neighbour.
-// (A persistent variant that prefetches the next tile into registers was measured and is not faster: the FMA loop
-// and the two memory phases each take ~0.2-0.3 ms of this kernel and already overlap across the resident blocks.)
+// (Measured and dropped: a persistent variant that prefetches the next tile into registers, and a wave-private
+// sliding-ring formulation -- one wave per column group, taps in registers, every input plane read once, no barriers:
+// 16 % fewer vector instructions and no halo re-reads, yet 0.38 ms against 0.34 ms.  The SQ counters say why: with the
+// packed FMAs at 4 cycles each the vector pipe is the co-bottleneck (about 0.2 ms of issue against a 0.23 ms byte floor),
+// and at the 3 waves per SIMD either kernel's registers allow the two do not overlap better than this.)
 __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
 {
     extern __shared__ __align__(16) float2 lds[];
@@ -993,6 +1081,12 @@ static int zconv_chunk(int nz, int kz)
     return even < zc ? even : zc;
 }
 
+// blocks (= partial sums) of the z pass for this geometry
+static long long zconv_blocks(const ZConvArgs& a, int py)
+{
+    return (long long)((a.nz + a.zc - 1) / a.zc) * (a.hxp / NLZ) * py;
+}
+
 static int launch_zconv(mvsim_ctx* ctx, const ZConvArgs& a, int py)
 {
     hipStream_t s = ctx->stream;
@@ -1039,18 +1133,37 @@ static int launch_r2c_t(mvsim_ctx* ctx, const float* src, const SrcMap& map, flo
 
 template <class PLAN>
 static int launch_c2r_t(mvsim_ctx* ctx, const float2* srcc, float* out, const float2* tw, const float2* twx, int hxp,
-                        int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks)
+                        int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks, const C2RFuse* fuse)
 {
     using C = CfgX<PLAN::len>;
     const long long groups = (rows + C::NL - 1) / C::NL;
     const int blocks = (int)groups;
     *nblocks = blocks;
     hipStream_t s = ctx->stream;
-    MVSIM_TRY(set_lds(ctx, k_fft_x_c2r<PLAN>, C::LDS));
-    hipLaunchKernelGGL((k_fft_x_c2r<PLAN>), dim3((unsigned)blocks), dim3(C::T), C::LDS, s, srcc, out, tw, twx, hxp, py, nx, ny,
-                       rows, scale, partial);
+    if (fuse) {
+        const size_t lds = C::LDS + 16 + (size_t)C::NW * sizeof(P1Scratch);
+        MVSIM_TRY(set_lds(ctx, k_fft_x_c2r<PLAN, true>, lds));
+        hipLaunchKernelGGL((k_fft_x_c2r<PLAN, true>), dim3((unsigned)blocks), dim3(C::T), lds, s, srcc, out, tw, twx, hxp, py, nx, ny,
+                           rows, scale, partial, *fuse);
+    } else {
+        MVSIM_TRY(set_lds(ctx, k_fft_x_c2r<PLAN, false>, C::LDS));
+        hipLaunchKernelGGL((k_fft_x_c2r<PLAN, false>), dim3((unsigned)blocks), dim3(C::T), C::LDS, s, srcc, out, tw, twx, hxp, py, nx, ny,
+                           rows, scale, partial, C2RFuse{});
+    }
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
+}
+
+// rows per block of pass E for this half length (the queue segments of the fused tail are per block)
+template <class PLAN> static int c2r_rows_per_block_t() { return CfgX<PLAN::len>::NL; }
+static int c2r_rows_per_block(int M)
+{
+    switch (M) {
+#define X(LL, ...) case LL: return c2r_rows_per_block_t<Plan<LL, __VA_ARGS__>>();
+        MVSIM_FFT_SIZES(X)
+#undef X
+    }
+    return 0;
 }
 
 static int launch_lines(mvsim_ctx* s, int L, int mode, bool sparse, const LinesArgs& a, int tiles, int nouter)
@@ -1079,11 +1192,11 @@ static int launch_r2c(mvsim_ctx* s, int M, const float* src, const SrcMap& map, 
 }
 
 static int launch_c2r(mvsim_ctx* s, int M, const float2* srcc, float* out, const float2* tw, const float2* twx, int hxp,
-                      int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks)
+                      int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks, const C2RFuse* fuse)
 {
     switch (M) {
 #define X(LL, ...) \
-    case LL: return launch_c2r_t<Plan<LL, __VA_ARGS__>>(s, srcc, out, tw, twx, hxp, py, nx, ny, rows, scale, partial, nblocks);
+    case LL: return launch_c2r_t<Plan<LL, __VA_ARGS__>>(s, srcc, out, tw, twx, hxp, py, nx, ny, rows, scale, partial, nblocks, fuse);
         MVSIM_FFT_SIZES(X)
 #undef X
     }
@@ -1206,6 +1319,32 @@ static int ensure_box_weights(mvsim_ctx* ctx, int N, int P, int len, bool half, 
     return MVSIM_OK;
 }
 
+// Geometry of the fused tail: pass E blocks own queue segments that can hold every voxel of their rows.
+static bool fused_tail_geometry(const int64_t dim[3], const int64_t kdim[3], int inc, bool con_wanted, const Options& opt,
+                                long long* blocks, unsigned int* segcap)
+{
+    int64_t P[3];
+    if (!custom_fft_sizes(dim, kdim, P, opt)) return false;
+    const bool zdirect = opt.zpass == 2 ? false : kdim[2] <= 64;
+    if (!zdirect || !opt.early_sum || (dim[0] & 3) != 0) return false;
+    const int nr = fft::c2r_rows_per_block((int)(P[0] / 2));
+    if (nr <= 0) return false;
+    const long long nk = con_wanted ? dim[2] : (dim[2] - 1) / inc + 1;
+    const long long rows = dim[1] * nk;
+    *blocks = (rows + nr - 1) / nr;
+    *segcap = (unsigned int)(nr * dim[0]);
+    return true;
+}
+
+size_t fused_tail_queue_bytes(const int64_t dim[3], const int64_t kdim[3], int inc, bool con_wanted, const Options& opt)
+{
+    long long blocks = 0;
+    unsigned int segcap = 0;
+    if (!fused_tail_geometry(dim, kdim, inc, con_wanted, opt, &blocks, &segcap)) return 0;
+    const size_t counts = ((size_t)2 * blocks * sizeof(unsigned int) + 255) & ~(size_t)255;
+    return counts + (size_t)blocks * segcap * sizeof(PItem);
+}
+
 void custom_fft_release(mvsim_ctx* ctx)
 {
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
@@ -1257,7 +1396,14 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     const bool early = zdirect && ctx->opt.early_sum;             // adjustImage's sum from pass C' instead of pass E
     // with the sum known before passes D and E, they only have to produce the planes extractSlices reads
     int zstride = (tail && early && !is_slab && tail->zstride > 1) ? tail->zstride : 1;
-    if (tail) tail->zstride = zstride;
+    // fused tail: pass E adjusts, extracts and samples (needs the sum first, whole rows of float4 groups, aligned outputs)
+    long long fblocks = 0;
+    unsigned int fsegcap = 0;
+    bool fuse = tail && tail->want_fuse && early && !is_slab && tail->acq &&
+                fused_tail_geometry(dim, kdim, tail->inc, tail->con_adj != nullptr, ctx->opt, &fblocks, &fsegcap) &&
+                ((reinterpret_cast<uintptr_t>(tail->acq) | reinterpret_cast<uintptr_t>(tail->con_adj)) & 15) == 0;
+    if (fuse) zstride = tail->con_adj ? 1 : tail->inc;
+    if (tail) { tail->zstride = zstride; tail->fused = fuse; }
     if (is_slab && !zdirect) {
         set_error("z-slab tiling needs the direct z pass (PSF depth %d > 64 or option fft_zpass=fft)", kz);
         return MVSIM_EINVAL;
@@ -1365,7 +1511,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             if (early) {
                 MVSIM_TRY(ensure_box_weights(ctx, (int)dim[0], px, hxp, true, &z.wx));
                 MVSIM_TRY(ensure_box_weights(ctx, (int)dim[1], py, py, false, &z.wy));
-                zblocks = (long long)((nzo + z.zc - 1) / z.zc) * (hxp / NLZ) * py;
+                zblocks = zconv_blocks(z, py);
                 MVSIM_TRY(ctx->partials_z.reserve((size_t)zblocks * sizeof(double)));
                 z.sum_partial = ctx->partials_z.as<double>();
             }
@@ -1396,15 +1542,43 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         ev_begin(ctx, ST_PASS_D);
         MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, nk));
         ev_end(ctx, ST_PASS_D);
+        C2RFuse fz{};
+        if (fuse) {
+            // adjustImage's factor must exist before pass E runs: (target - min) / (sum / n) from the early sum
+            ev_begin(ctx, ST_ADJUST);
+            MVSIM_TRY(launch_adjust_corr(s, scal, (int64_t)dim[0] * dim[1] * dim[2], tail->min_value, tail->target_average));
+            ev_end(ctx, ST_ADJUST);
+            fz.scal = scal; fz.min_value = tail->min_value; fz.con = tail->con_adj; fz.acq = tail->acq;
+            fz.acq_every = tail->con_adj ? tail->inc : 1; fz.idx_zstride = zstride; fz.noise = tail->noise ? 1 : 0;
+            fz.mul = tail->mul; fz.k0 = (uint32_t)tail->seed; fz.k1 = (uint32_t)(tail->seed >> 32); fz.stream = tail->stream;
+            if (tail->noise) {
+                const size_t counts = ((size_t)2 * fblocks * sizeof(unsigned int) + 255) & ~(size_t)255;
+                if (ctx->pqueue.bytes < counts + (size_t)fblocks * fsegcap * sizeof(PItem)) {
+                    set_error("fused tail: queue workspace not reserved");
+                    return MVSIM_EINVAL;
+                }
+                fz.qcount = ctx->pqueue.as<unsigned int>();
+                fz.queue = reinterpret_cast<PItem*>(ctx->pqueue.as<char>() + counts);
+                fz.segcap = fsegcap;
+            }
+        }
         ev_begin(ctx, ST_PASS_E);
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
         const float scale = (float)(0.25 / ((double)px * (double)py * (zdirect ? 1.0 : (double)pz)));
         int nblk = 0;
         MVSIM_TRY(launch_c2r(ctx, M, Fz, out, tw_m, tw_px, hxp, py * zstride, (int)dim[0], (int)dim[1], (long long)dim[1] * nk, scale,
-                             ctx->partials_e.as<double>(), &nblk));
+                             ctx->partials_e.as<double>(), &nblk, fuse ? &fz : nullptr));
+        if (fuse && nblk != (int)fblocks) { set_error("fused tail: block count mismatch"); return MVSIM_EINVAL; }
         if (!early) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal, 1.0);
         MVSIM_HIP(hipGetLastError());
         ev_end(ctx, ST_PASS_E);
+        if (fuse && tail->noise) {
+            ev_end(ctx, ST_CONVOLVE);
+            ev_begin(ctx, ST_EXTRACT);
+            MVSIM_TRY(launch_poisson_resolve(s, tail->acq, fz.queue, fz.qcount, (int)fblocks, fsegcap, tail->mul, tail->seed, tail->stream));
+            ev_end(ctx, ST_EXTRACT);
+            return MVSIM_OK;
+        }
     }
     ev_end(ctx, ST_CONVOLVE);
     return MVSIM_OK;

@@ -908,6 +908,15 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out
     }
 }
 
+int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
+                           double mul, uint64_t seed, uint32_t stream)
+{
+    hipLaunchKernelGGL(k_poisson_resolve, dim3(segments), dim3(256), 0, s, out, reinterpret_cast<const PItem*>(queue_items), qcount, segcap,
+                       mul, (uint32_t)seed, (uint32_t)(seed >> 32), stream);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
 // Work-queue geometry for n_out output voxels: `blocks` blocks of 256 lanes x 4 voxels walk the volume with a
 // grid stride; each owns a segment that can hold all of its voxels (24 B per output voxel of HBM workspace).
 constexpr int POISSON_MAX_BLOCKS = 256 * 64;

@@ -648,7 +648,7 @@ def options(ctx):
             ctx.set_option(k, v)
     yield set_
     for k, v in (("fft_zpass", "auto"), ("fft_backend", "custom"), ("fft_pad", "auto"), ("fused_rotate", 1),
-                 ("poisson_queue", 1), ("early_sum", 1), ("graph", 0)):
+                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0)):
         ctx.set_option(k, v)
 
 
@@ -1059,3 +1059,22 @@ def test_compact_planes_view_equals_full_view(ctx, synth, options, inc):
         assert compact["corr"] == full["corr"]
         if snr < 0:
             assert np.array_equal(compact["acq"], full["con"][::inc])
+
+
+@pytest.mark.parametrize("inc,want_con", [(1, False), (1, True), (3, False), (3, True)])
+def test_fused_tail_option_gives_the_same_view(ctx, synth, options, inc, want_con):
+    """Option fuse_tail (off by default: measured neutral): pass E of the convolution adjusts, extracts and runs
+    phase 1 of the Poisson sampler in its epilogue instead of writing the convolved volume.  Same adjusted voxels, same
+    RNG counters: identical acquisition, with and without noise, with and without the volume being returned."""
+    gt = synth.sphere_phantom(48)
+    psf = synth.gaussian_psf(9, 7, 11, sigma=(1.3, 1.2, 2.4))
+    want = ("con", "acq") if want_con else ("acq",)
+    for snr in (25.0, -1.0):
+        p = ctx.view_params(degrees=70, inc=inc, snr=snr, seed=SEED, stream=6, conv_method=1)
+        options(fuse_tail=0)
+        a = ctx.simulate_view(gt, psf.copy(), p, want=want)
+        options(fuse_tail=1)
+        b = ctx.simulate_view(gt, psf.copy(), p, want=want)
+        assert a["corr"] == b["corr"]
+        for k in want:
+            assert np.array_equal(a[k], b[k]), (k, snr)
