@@ -59,8 +59,10 @@ int  mvsim_synchronize(mvsim_ctx* ctx);
  * variables of the same meaning, read once per process: "fft_zpass" = auto|direct|fft (MVSIM_FFT_ZPASS),
  * "fft_backend" = custom|rocfft (MVSIM_FFT_BACKEND), "fft_pad" = "px,py,pz"|auto (MVSIM_FFT_PAD), "fused_rotate" = 1|0|2
  * (MVSIM_NO_FUSED_ROTATE; 2 = the variant that recomputes the row geometry in every lane), "poisson_queue" = 1|0 (MVSIM_POISSON_NOQUEUE), "early_sum" = 1|0 (MVSIM_NO_EARLY_SUM),
- * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST).  Unknown names or values:
- * MVSIM_EINVAL. */
+ * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "fuse_tail" = 0|1 (adjust +
+ * extract + Poisson phase 1 in the epilogue of the convolution's last pass), "attenuate" = serial|scan (mvsim_attenuate3d
+ * as a wavefront-level prefix scan along the illumination axis: parallel in y, not bit-identical to the serial walk).
+ * MVSIM_OPTIONS="name=value;name=value" sets any of them process-wide.  Unknown names or values: MVSIM_EINVAL. */
 int  mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value);
 /* Release cached FFT plans / workspaces / PSF spectra held by the context. */
 int  mvsim_release_caches(mvsim_ctx* ctx);

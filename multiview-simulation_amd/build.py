@@ -81,7 +81,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if failed:
         raise RuntimeError("hipcc failed")
     link = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + [
-        "-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib"),
+        "-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-lrccl", "-lroctx64", "-Wl,-rpath," + os.path.join(ROCM, "lib"),
     ]
     if verbose:
         print(" ".join(link), file=sys.stderr)

@@ -43,7 +43,11 @@ int parse_option(Options& o, const char* name, const char* value)
     }
     if (n == "poisson_queue") {
         if (v == "1" || v == "on") o.poisson_queue = 1; else if (v == "0" || v == "off") o.poisson_queue = 0;
-        else if (v == "2" || v == "v1") o.poisson_queue = 2; else return MVSIM_EINVAL;
+        else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
+    if (n == "attenuate") {
+        if (v == "serial") o.attenuate_scan = false; else if (v == "scan") o.attenuate_scan = true; else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
     if (n == "early_sum") return flag(&o.early_sum);
@@ -503,7 +507,8 @@ int mvsim_attenuate3d_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[3],
     MVSIM_CHECK_ARG(in && out && in != out, "null or aliased buffers");
     MVSIM_CHECK_ARG(dim[0] <= dim[1], "attenuate3d: Nx > Ny walks outside the interval in the reference (steps = dimension(0))");
     ev_begin(ctx, ST_ATTENUATE);
-    MVSIM_TRY(launch_attenuate(ctx->stream, in, out, dim, delta));
+    if (ctx->opt.attenuate_scan) MVSIM_TRY(launch_attenuate_scan(ctx->stream, in, out, dim, delta));
+    else MVSIM_TRY(launch_attenuate(ctx->stream, in, out, dim, delta));
     ev_end(ctx, ST_ATTENUATE);
     return MVSIM_OK;
 }

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
+#include <roctracer/roctx.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -93,8 +94,10 @@ struct Options {
     bool    rocfft = false;            // library fallback instead of the hand-written passes
     int     fused_rotate = 1;          // rotate+attenuate as one kernel when the rotation is about x: 0 off, 1 row geometry
                                        // shared through LDS (production), 2 recomputed per lane (kept for A/B runs)
+    bool    attenuate_scan = false;    // attenuate3d (stage operator) as a wavefront prefix scan along y: re-associates the
+                                       // fp64 products (float outputs differ from the serial walk by one ulp on < 1e-6 of the voxels)
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
-                                       // resolver, production), 2: its predecessor (per-slot divergent phase 1), 0: one kernel
+                                       // resolver, production), 0: one kernel
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
     bool    fuse_tail = false;         // adjust + extract + Poisson phase 1 in the epilogue of the convolution's last pass: saves
                                        // the 8 N bytes of the convolved volume's round trip, but the merged kernel is bound by
@@ -178,6 +181,7 @@ namespace mvsim {
 // ---- kernel launchers (each enqueues on `s`, returns MVSIM_* status) ----------------------------
 int launch_rotate(hipStream_t s, const float* in, float* out, const int64_t dim[3], const Affine& inv);
 int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta);
+int launch_attenuate_scan(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta);
 int launch_rotate_attenuate(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
                             const Affine& inv, double delta, int fused_mode, bool* fused);
 int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or_null, float* att, const int64_t dim[3],
@@ -261,13 +265,24 @@ int  custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t di
 void custom_fft_release(mvsim_ctx* ctx);
 bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[5], const Options& opt);
 
-// stage timing helpers (events are recorded on the stream the kernels run on)
+// stage markers: a roctx range per stage (what rocprofv3 --marker-trace / a timeline shows around the launches; the reference
+// prints a time stamp per stage, SimulateMultiViewDataset.java:553-590) and, when timing is on, HIP events recorded on the
+// stream the kernels run on.  begin/end pairs nest strictly.
+inline const char* stage_name(int st)
+{
+    static const char* const names[ST_COUNT] = {"mvsim:rotate", "mvsim:attenuate", "mvsim:psf_spectrum", "mvsim:convolve", "mvsim:adjust",
+                                               "mvsim:extract_poisson", "mvsim:pass_A_x_r2c", "mvsim:pass_B_y_fwd", "mvsim:pass_C_z",
+                                               "mvsim:pass_D_y_inv", "mvsim:pass_E_x_c2r"};
+    return names[st];
+}
 inline void ev_begin(mvsim_ctx* ctx, int st)
 {
+    (void)roctxRangePushA(stage_name(st));
     if (ctx->timing) (void)hipEventRecord(ctx->evr[ctx->ev_cur][st][0], ctx->stream);
 }
 inline void ev_end(mvsim_ctx* ctx, int st)
 {
+    (void)roctxRangePop();
     if (ctx->timing) {
         (void)hipEventRecord(ctx->evr[ctx->ev_cur][st][1], ctx->stream);
         ctx->ev_used[ctx->ev_cur][st] = true;

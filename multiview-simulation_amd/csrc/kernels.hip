@@ -164,6 +164,77 @@ __global__ __launch_bounds__(64) void k_attenuate(const float* __restrict__ in, 
     for (; y >= 0; --y) pout[(long long)y * nx] = 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// attenuate3d as a wavefront-level prefix scan (option attenuate=scan; north_star's formulation).  In exact arithmetic
+// the recurrence n <- max(n - v delta n, 0) is n_k = PROD_{j<=k} max(1 - v_j delta, 0): lanes run ALONG the illumination
+// axis (64 consecutive y per wave), every lane forms its factor, an inclusive product scan across the wave (6 shuffle
+// steps in fp64) gives the prefix products, and the product of the chunk carries into the next 64 rows.  Tiles of
+// 64 (y) x 64 (x) go through LDS so that HBM sees whole rows although lanes walk columns.  This re-associates the fp64
+// roundings of the reference's serial loop: results agree with k_attenuate to ~1e-15 relative in n, i.e. the float outputs
+// are identical except where v*n falls within that distance of a rounding boundary (measured: < 1e-6 of the voxels, by one
+// ulp).  Parallelism comes from y as well as from (x, z): the form for thin volumes; the serial kernels, which are
+// bit-exact against the oracle, stay the default.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_attenuate_scan(const float* __restrict__ in, float* __restrict__ out, int nx, int ny,
+                                                        int steps, double delta)
+{
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, z = blockIdx.y;
+    const long long plane = (long long)nx * ny;
+    const float* __restrict__ pin = in + plane * z;
+    float* __restrict__ pout = out + plane * z;
+    const bool xin = x0 + lane < nx;
+    double carry[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) carry[i] = 1.0;
+    for (int j0 = 0; j0 < steps; j0 += 64) {
+        // rows y = ny - 1 - (j0 + r), r = 0..63: wave w brings in rows 16 w .. 16 w + 15, lanes along x
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int r = wave * 16 + rr;
+            float v = 0.f;
+            if (j0 + r < steps && xin) v = pin[(long long)(ny - 1 - (j0 + r)) * nx + x0 + lane];
+            tile[r][lane] = v;
+        }
+        __syncthreads();
+        const bool live = j0 + lane < steps;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = wave * 16 + i;
+            const double dv = (double)tile[lane][c];
+            double p = live ? fmax(1.0 - dv * delta, 0.0) : 1.0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double t = __shfl_up(p, d, 64);
+                if (lane >= d) p *= t;
+            }
+            const double n = carry[i] * p;
+            tile[lane][c] = (float)(dv * n);
+            carry[i] = carry[i] * __shfl(p, 63, 64);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int r = wave * 16 + rr;
+            if (j0 + r < steps && xin) pout[(long long)(ny - 1 - (j0 + r)) * nx + x0 + lane] = tile[r][lane];
+        }
+        __syncthreads();
+    }
+    // rows the reference never visits (Ny > Nx): the attenuated image stays zero there
+    for (int yy = ny - 1 - steps - wave; yy >= 0; yy -= 4)
+        if (xin) pout[(long long)yy * nx + x0 + lane] = 0.f;
+}
+
+int launch_attenuate_scan(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta)
+{
+    const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
+    dim3 grid((nx + 63) / 64, nz);
+    hipLaunchKernelGGL(k_attenuate_scan, grid, dim3(256), 0, s, in, out, nx, ny, nx, delta);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
 int launch_attenuate(hipStream_t s, const float* in, float* out, const int64_t dim[3], double delta)
 {
     const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
@@ -694,126 +765,17 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
 }
 
 // Noise form for production sizes, two launches.
-//   k_extract4_noise : every lane busy -- adjust, the "count is 0" shortcut of the low-lambda inversion and the
-//                      attempt-0 squeeze of PTRS for the lane's 4 voxels.  The ~1/3 of bright voxels that still need
-//                      the exact test or a retry, and the few low-lambda voxels whose count may be >= 1, are
-//                      appended to a work queue in HBM (per-block segments, LDS append counter).
+//   k_extract4_noise2: every lane busy -- adjust, then phase 1 of the sampler (poisson_dev.h: poisson_phase1): the
+//                      "count is 0" shortcut of the low-lambda inversion, and the attempt-0 squeeze of PTRS run densely
+//                      over the wave's bright voxels (ballot compaction into a wave-private LDS list).  The ~1/3 of
+//                      bright voxels that still need the exact test or a retry, and the few low-lambda voxels whose
+//                      count may be >= 1, are appended to a work queue in HBM (per-block segments, LDS append counters:
+//                      one global counter would serialise at ~88 atomics/us chip-wide; bright items grow from the front
+//                      of the segment, inversion items from its back).
 //   k_poisson_resolve: one queue item per lane, looped until resolved; no LDS, no barriers, full occupancy, and
 //                      every lane starts with real work -- the divergent fp64 code (logs, divisions) no longer
 //                      runs once per voxel slot with 1-in-7 lanes active.
 // Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.
-template <bool ADJUST>
-__global__ __launch_bounds__(256) void k_extract4_noise(const float* __restrict__ in, float* __restrict__ out,
-                                                        long long plane4, long long nzo, int inc,
-                                                        const double* __restrict__ scal, float min_value, double mul,
-                                                        uint32_t k0, uint32_t k1, uint32_t stream,
-                                                        unsigned long long index_offset, PItem* __restrict__ queue,
-                                                        unsigned int* __restrict__ qcount, unsigned int segcap)
-{
-    // every block appends to its OWN queue segment: the append counter lives in LDS (one global counter would
-    // serialise at ~88 atomics/us chip-wide)
-    // bright (PTRS) items grow from the front of the segment, inversion items from its back: the resolver walks two
-    // homogeneous ranges instead of one mixed one (every voxel queues at most one item, so the ends cannot meet)
-    __shared__ unsigned int nq, nqs;
-    if (threadIdx.x == 0) { nq = 0u; nqs = 0u; }
-    __syncthreads();
-    PItem* __restrict__ seg = queue + (unsigned long long)blockIdx.x * segcap;
-    double corr = 1.0;
-    if (ADJUST) corr = scal[1];
-    const long long total4 = plane4 * nzo;
-    const long long nthreads = (long long)gridDim.x * 256;
-    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
-    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
-    const bool small32 = total4 < (1ll << 32);
-    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total4; o += nthreads) {
-        long long src4 = o;                                  // inc == 1: extracted planes are the source planes
-        if (inc != 1) {
-            // 64-bit division by a run-time value costs ~100 instructions: avoid it whenever the index fits 32 bits
-            const long long k = small32 ? (long long)((unsigned)o / (unsigned)plane4) : o / plane4;
-            src4 = k * inc * plane4 + (o - k * plane4);
-        }
-        float4 v = in4[src4];
-        if (ADJUST) {
-            v.x = adjust_one(v.x, corr, min_value);
-            v.y = adjust_one(v.y, corr, min_value);
-            v.z = adjust_one(v.z, corr, min_value);
-            v.w = adjust_one(v.w, corr, min_value);
-        }
-        const unsigned long long index4 = index_offset + 4ull * (unsigned long long)src4;
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        double lam[4];
-        bool small_any = false;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            lam[c] = (double)vv[c] * mul;
-            small_any |= lam[c] > 0.0 && lam[c] < 10.0;
-        }
-        const bool bright01 = lam[0] >= 10.0 || lam[1] >= 10.0;
-        const bool bright23 = lam[2] >= 10.0 || lam[3] >= 10.0;
-        float ov[4] = {0.f, 0.f, 0.f, 0.f};
-        if (small_any) {
-            const unsigned long long g = index4 >> 2;
-            const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream, 0u, k0, k1);
-            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (lam[c] > 0.0 && lam[c] < 10.0) {
-                    // Inversion returns 0 iff u < exp(-lambda) (poisson_small).  exp(-lambda) >= 1 - lambda, and the
-                    // bit-defined exponential is within 1e-15 of the true one, so u < 1 - lambda - 1e-12 decides
-                    // "0" without evaluating it: 98.8 % of the background voxels (lambda = minValue * mul) end here.
-                    // Everything else -- a count >= 1 is possible -- joins the work queue, so that no wave of this
-                    // kernel runs the exponential and the search loop for a handful of its lanes.
-                    if (!(lam[c] < 1.0 && u32_open(w[c]) < (1.0 - lam[c]) - 1e-12)) {
-                        const unsigned int pos = atomicAdd(&nqs, 1u);
-                        PItem it;
-                        it.index = index4 + (unsigned long long)c;
-                        it.out = 4ull * (unsigned long long)o + (unsigned long long)c;
-                        it.v = vv[c];
-                        it.attempt = kSmallLambdaItem;
-                        seg[segcap - 1u - pos] = it;
-                    }
-                }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h == 0 ? bright01 : bright23) {
-                const unsigned long long pr = (index4 >> 1) + (unsigned long long)h;
-                const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
-                const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int c = 2 * h + e;
-                    if (lam[c] >= 10.0) {
-                        double us, V, kd;
-                        const int st = ptrs_fast(ptrs_setup(lam[c]), lam[c], w[2 * e], w[2 * e + 1], us, V, kd);
-                        if (st == 0) {
-                            ov[c] = (float)(long long)kd;
-                        } else {
-                            // the segment holds every voxel of the block (worst case: all pending), so this cannot overflow
-                            const unsigned int pos = atomicAdd(&nq, 1u);
-                            PItem it;
-                            it.index = index4 + (unsigned long long)c;
-                            it.out = 4ull * (unsigned long long)o + (unsigned long long)c;
-                            it.v = vv[c];
-                            it.attempt = st == 2 ? 0u : 1u;       // exact test of attempt 0, or straight to a retry
-                            seg[pos] = it;
-                        }
-                    }
-                }
-            }
-        }
-        out4[o] = make_float4(ov[0], ov[1], ov[2], ov[3]);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        qcount[2 * blockIdx.x] = nq;
-        qcount[2 * blockIdx.x + 1] = nqs;
-    }
-}
-
-// Production form of the streaming kernel: same walk, phase 1 by poisson_phase1 (wave-level compaction of the bright
-// voxels, fp32 execution shortcuts).  Bit-identical counts; k_extract4_noise above is kept for A/B runs
-// (option poisson_phase1=v1).
 template <bool ADJUST>
 __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict__ in, float* __restrict__ out,
                                                          long long plane4, long long nzo, int inc, int idx_inc,
@@ -945,7 +907,7 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
     // index_inc: plane stride of the RNG counter when it differs from the plane stride of the reads (a compact input
     // that holds only the planes k * index_inc of the source volume); 0 = the same as inc
     if (index_inc <= 0) index_inc = inc;
-    const bool use_queue = queue_mode != 0, use_queue_v1 = queue_mode == 2;
+    const bool use_queue = queue_mode != 0;
     const long long plane = (long long)dim[0] * dim[1];
     const long long nzo = (dim[2] - 1) / inc + 1;
     const long long total = plane * nzo;
@@ -964,14 +926,7 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
             poisson_geometry(total, &qblocks, &segcap);
             unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
             PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int));
-            if (use_queue_v1) {
-                if (adjust)
-                    hipLaunchKernelGGL((k_extract4_noise<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
-                                       scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
-                else
-                    hipLaunchKernelGGL((k_extract4_noise<false>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc,
-                                       scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
-            } else if (adjust) {
+            if (adjust) {
                 hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
                                    scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
             } else {

@@ -648,7 +648,7 @@ def options(ctx):
             ctx.set_option(k, v)
     yield set_
     for k, v in (("fft_zpass", "auto"), ("fft_backend", "custom"), ("fft_pad", "auto"), ("fused_rotate", 1),
-                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0)):
+                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial")):
         ctx.set_option(k, v)
 
 
@@ -1078,3 +1078,22 @@ def test_fused_tail_option_gives_the_same_view(ctx, synth, options, inc, want_co
         assert a["corr"] == b["corr"]
         for k in want:
             assert np.array_equal(a[k], b[k]), (k, snr)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 64), (3, 200, 130), (5, 70, 70), (2, 300, 33), (6, 16, 16)])
+@pytest.mark.parametrize("delta", [0.0, 0.01, 0.3])
+def test_attenuate_prefix_scan_variant(ctx, orc, options, shape, delta):
+    """Option attenuate=scan: the sweep as a wavefront-level prefix scan along y (products of the per-voxel factors) instead
+    of one serial fp64 walk per column.  Same quantity, re-associated roundings: the float outputs equal the oracle's
+    except for isolated one-ulp differences."""
+    v = np.random.default_rng(2).random(shape, dtype=np.float32) * 4
+    options(attenuate="scan")
+    got = ctx.attenuate3d(v, delta)
+    want = orc.attenuate3d(v, delta)
+    diff = got != want
+    assert diff.mean() < 1e-4, diff.mean()
+    if diff.any():
+        assert np.max(np.abs(got[diff] - want[diff]) / np.maximum(np.abs(want[diff]), 1e-30)) <= 1.2e-7
+    if delta == 0.0:
+        nz, ny, nx = shape
+        assert np.array_equal(got[:, ny - nx:, :], v[:, ny - nx:, :]) and not got[:, :ny - nx, :].any()
