@@ -848,12 +848,27 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out
         const uint32_t lane = (uint32_t)it.index & 3u;
         out[it.out] = poisson_small((double)it.v * mul, lane == 0 ? r.x : (lane == 1 ? r.y : (lane == 2 ? r.z : r.w)));
     }
-    for (unsigned int i = threadIdx.x; i < n; i += 256u) {
-        const PItem it = seg[i];
+    // PTRS items.  A lane works on ONE ATTEMPT per trip and, the moment its item is resolved, takes the next item of the
+    // segment (LDS ticket): every trip has every lane on a live attempt, instead of the wave idling until its unluckiest
+    // item -- retries come in geometrically distributed numbers -- has been accepted.  The loop ends when the tickets run
+    // out: each attempt succeeds with probability > 0.8 and the attempt count is capped, so every lane gets there.
+    __shared__ unsigned int ticket;
+    if (threadIdx.x == 0) ticket = 256u;
+    __syncthreads();
+    unsigned int i = threadIdx.x;
+    PItem it;
+    it.index = 0ull; it.out = 0ull; it.v = 0.f; it.attempt = 0u;
+    bool have = i < n;
+    if (have) it = seg[i];
+    uint32_t a = it.attempt;
+    while (have) {
         const double lam = (double)it.v * mul;
         float val = 0.f;
-        for (uint32_t a = it.attempt;; ++a) {
-            if (a >= kPtrsMaxAttempts) { val = (float)(long long)lam; break; }
+        bool done;
+        if (a >= kPtrsMaxAttempts) {
+            val = (float)(long long)lam;
+            done = true;
+        } else {
             uint32_t w0, w1;
             if (a == 0u) {
                 const unsigned long long pr = it.index >> 1;
@@ -864,9 +879,16 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out
             } else {
                 ptrs_retry_words(it.index, a, k0, k1, stream, w0, w1);
             }
-            if (ptrs_step_words(lam, w0, w1, val)) break;
+            done = ptrs_step_words(lam, w0, w1, val);
         }
-        out[it.out] = val;
+        if (done) {
+            out[it.out] = val;
+            i = atomicAdd(&ticket, 1u);
+            have = i < n;
+            if (have) { it = seg[i]; a = it.attempt; }
+        } else {
+            a += 1u;
+        }
     }
 }
 
