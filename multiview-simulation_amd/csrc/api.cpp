@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 
 namespace mvsim {
@@ -110,9 +111,14 @@ int ensure_lds_attr(mvsim_ctx* ctx, const void* kernel, size_t bytes)
     return MVSIM_OK;
 }
 
+// Bumped whenever a workspace moves or goes away: captured view graphs hold raw workspace addresses and must not be
+// replayed across such a change (view_graph_launch compares the epoch it captured under).
+static std::atomic<unsigned long long> g_alloc_epoch{1};
+
 int DevBuf::reserve(size_t need)
 {
     if (need <= bytes) return MVSIM_OK;
+    g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
     if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
     hipError_t e = hipMalloc(&p, need);
     if (e != hipSuccess) {
@@ -126,6 +132,7 @@ int DevBuf::reserve(size_t need)
 
 void DevBuf::release()
 {
+    if (p) g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
     if (p) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
@@ -235,9 +242,22 @@ static int psf_prepare(mvsim_ctx* ctx, float* psf_host, const int64_t kdim[3], c
     MVSIM_CHECK_ARG(kdim[0] >= 1 && kdim[1] >= 1 && kdim[2] >= 1, "psf dimensions must be >= 1");
     (void)dim;
     const int64_t n = kdim[0] * kdim[1] * kdim[2];
-    // pairwise (cascade) double summation: same order of magnitude of error as mpicbg RealSum
+    // pairwise (cascade) double summation: same order of magnitude of error as mpicbg RealSum.  A binary counter of
+    // partial sums (level l holds the sum of 2^l consecutive elements); aligned blocks of 16 enter it at level 4 with
+    // their balanced tree written out -- the same additions in the same association as 16 single pushes (IEEE addition is
+    // commutative), several times faster: this loop is on the host path of every view (29 791 taps for a 31^3 PSF).
     double lvl[64]; bool used[64] = {};
-    for (int64_t i = 0; i < n; ++i) {
+    int64_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const float* q = psf_host + i;
+        double t[8];
+        for (int k = 0; k < 8; ++k) t[k] = (double)q[2 * k] + (double)q[2 * k + 1];
+        double s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        int l = 4;
+        while (used[l]) { used[l] = false; s += lvl[l]; ++l; }
+        used[l] = true; lvl[l] = s;
+    }
+    for (; i < n; ++i) {
         double s = (double)psf_host[i];
         int l = 0;
         while (used[l]) { used[l] = false; s += lvl[l]; ++l; }
@@ -291,6 +311,7 @@ static int scal_ptr(mvsim_ctx* ctx, double** partial, double** scal)
 using namespace mvsim;
 
 static void async_release(mvsim_ctx* ctx);
+static void view_graphs_release(mvsim_ctx* ctx);
 
 extern "C" {
 
@@ -343,6 +364,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     mvsim_comm_destroy(ctx);
     async_release(ctx);
+    view_graphs_release(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
     ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release();
@@ -385,6 +407,7 @@ int mvsim_release_caches(mvsim_ctx* ctx)
     MVSIM_TRY(set_device(ctx));
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
     async_release(ctx);
+    view_graphs_release(ctx);                             // captured launches point into the workspaces released below
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
     ctx->pqueue.release(); ctx->psf_dev.release(); ctx->sphere_list.release();
@@ -625,28 +648,17 @@ int mvsim_normalize_weights(mvsim_ctx* ctx, float* const* weights, int n_views, 
 }
 
 // ---- fused per-view pipeline ------------------------------------------------------------------------
-int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host,
-                            const int64_t kdim[3], const mvsim_view_params* p, const mvsim_view_outputs* o,
-                            double* correction)
+// Everything a view enqueues on the context stream behind the PSF upload: kernel launches only (no allocation once the
+// workspaces have their size, no host synchronisation) -- which is what makes it capturable into a hipGraph.
+static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], const int64_t kdim[3], const mvsim_view_params* p,
+                        const mvsim_view_outputs* o)
 {
-    MVSIM_TRY(set_device(ctx));
-    MVSIM_TRY(check_dim(dim));
-    MVSIM_CHECK_ARG(gt && p && o, "null pointer");
-    MVSIM_CHECK_ARG(o->acq != nullptr, "outputs.acq is required");
-    MVSIM_CHECK_ARG(p->axis >= 0 && p->axis <= 2, "axis must be 0, 1 or 2");
-    MVSIM_CHECK_ARG(p->inc >= 1, "inc must be >= 1");
-    MVSIM_CHECK_ARG(p->conv_method >= 0 && p->conv_method <= 2, "conv_method must be 0, 1 or 2");
-    MVSIM_CHECK_ARG(dim[0] <= dim[1], "attenuate3d: Nx > Ny walks outside the interval in the reference");
     const int64_t n = nvox(dim);
     const size_t vbytes = (size_t)n * sizeof(float);
-    ev_next(ctx);
-
     float* rot = o->rot;
     float* att = o->att;
     float* con = o->con;
     if (!att) { MVSIM_TRY(ctx->vol_b.reserve(vbytes)); att = ctx->vol_b.as<float>(); }
-
-    MVSIM_TRY(psf_prepare(ctx, psf_host, kdim, dim));
 
     double m[12];
     Affine inv;
@@ -690,14 +702,7 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
         }
     }
     MVSIM_TRY(convolve_dev_impl(ctx, att, dim, kdim, method, con, &tail));
-    if (tail.fused) {
-        // pass E adjusted, extracted and sampled (phase 1); the resolver has been enqueued behind it
-        if (correction) {
-            MVSIM_HIP(hipMemcpyAsync(correction, scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            MVSIM_HIP(hipStreamSynchronize(ctx->stream));
-        }
-        return MVSIM_OK;
-    }
+    if (tail.fused) return MVSIM_OK;   // pass E adjusted, extracted and sampled (phase 1); the resolver is enqueued behind it
 
     ev_begin(ctx, ST_ADJUST);
     if (method == 2) MVSIM_TRY(launch_sum(ctx->stream, con, n, partial, scal));   // FFT path sums in its crop epilogue
@@ -719,7 +724,117 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     }
     ev_end(ctx, ST_EXTRACT);
 
+    return MVSIM_OK;
+}
+
+
+// hipGraph replay of a view (option "graph"): host launch cost is what bounds small volumes (130 us to issue the 14
+// launches of a 128^3 view against ~0.1 ms of device time).  A captured view bakes in its pointers and by-value
+// parameters (affine model of the angle, seed, stream id), so the cache is keyed by ALL of them: the first call with a key
+// runs eagerly (workspaces, twiddles), the second is captured and instantiated, later ones replay.  The PSF upload stays
+// outside the graph (its pinned staging slot changes from call to call).
+static std::string view_graph_key(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], const int64_t kdim[3],
+                                  const mvsim_view_params* p, const mvsim_view_outputs* o)
+{
+    std::string k;
+    auto add = [&](const void* ptr, size_t bytes) { k.append(reinterpret_cast<const char*>(ptr), bytes); };
+    add(&gt, sizeof(gt)); add(dim, 3 * sizeof(int64_t)); add(kdim, 3 * sizeof(int64_t));
+    // field by field: the struct has padding bytes
+    add(&p->axis, sizeof(p->axis)); add(&p->degrees, sizeof(p->degrees)); add(&p->delta, sizeof(p->delta));
+    add(&p->min_value, sizeof(p->min_value)); add(&p->target_average, sizeof(p->target_average)); add(&p->inc, sizeof(p->inc));
+    add(&p->snr, sizeof(p->snr)); add(&p->seed, sizeof(p->seed)); add(&p->stream, sizeof(p->stream));
+    add(&p->conv_method, sizeof(p->conv_method));
+    add(&o->rot, sizeof(o->rot)); add(&o->att, sizeof(o->att)); add(&o->con, sizeof(o->con)); add(&o->acq, sizeof(o->acq));
+    add(&ctx->stream, sizeof(ctx->stream));
+    const Options& q = ctx->opt;
+    const int oo[8] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, 0, 0};
+    add(oo, sizeof(oo));
+    return k;
+}
+
+static void view_graphs_release(mvsim_ctx* ctx)
+{
+    for (auto& g : ctx->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    ctx->graphs.clear();
+    ctx->graph_seen.clear();
+}
+
+static int view_graph_launch(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], const int64_t kdim[3], const mvsim_view_params* p,
+                             const mvsim_view_outputs* o)
+{
+    const std::string key = view_graph_key(ctx, gt, dim, kdim, p, o);
+    ctx->graph_tick += 1;
+    const unsigned long long epoch = g_alloc_epoch.load(std::memory_order_relaxed);
+    if (ctx->graph_epoch != epoch) {
+        // some workspace was (re)allocated since the graphs were captured: their baked-in addresses may be stale
+        for (auto& g : ctx->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        ctx->graphs.clear();
+        ctx->graph_epoch = epoch;
+    }
+    for (auto& g : ctx->graphs)
+        if (g.key == key) {
+            g.last_use = ctx->graph_tick;
+            MVSIM_HIP(hipGraphLaunch(g.exec, ctx->stream));
+            return MVSIM_OK;
+        }
+    if (!ctx->graph_seen.count(key)) {
+        // first sight: run eagerly (this is also what sizes every workspace and table the capture must not allocate)
+        if (ctx->graph_seen.size() > 4096) ctx->graph_seen.clear();
+        ctx->graph_seen.insert(key);
+        return view_enqueue(ctx, gt, dim, kdim, p, o);
+    }
+    MVSIM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    const int rc = view_enqueue(ctx, gt, dim, kdim, p, o);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc != MVSIM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (g_alloc_epoch.load(std::memory_order_relaxed) != epoch) {
+        // an allocation slipped into the capture (a workspace grew): do not keep this graph; run the view eagerly
+        if (graph) (void)hipGraphDestroy(graph);
+        return view_enqueue(ctx, gt, dim, kdim, p, o);
+    }
+    if (e != hipSuccess || !graph) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return MVSIM_EHIP; }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess) { (void)hipGraphDestroy(graph); set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ei)); return MVSIM_EHIP; }
+    if (ctx->graphs.size() >= 32) {                       // evict the least recently used
+        size_t victim = 0;
+        for (size_t i = 1; i < ctx->graphs.size(); ++i) if (ctx->graphs[i].last_use < ctx->graphs[victim].last_use) victim = i;
+        (void)hipGraphExecDestroy(ctx->graphs[victim].exec);
+        (void)hipGraphDestroy(ctx->graphs[victim].graph);
+        ctx->graphs.erase(ctx->graphs.begin() + (long)victim);
+    }
+    ctx->graphs.push_back(mvsim_ctx::ViewGraph{key, graph, exec, ctx->graph_tick});
+    MVSIM_HIP(hipGraphLaunch(exec, ctx->stream));
+    return MVSIM_OK;
+}
+
+int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host,
+                            const int64_t kdim[3], const mvsim_view_params* p, const mvsim_view_outputs* o,
+                            double* correction)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(gt && p && o, "null pointer");
+    MVSIM_CHECK_ARG(o->acq != nullptr, "outputs.acq is required");
+    MVSIM_CHECK_ARG(p->axis >= 0 && p->axis <= 2, "axis must be 0, 1 or 2");
+    MVSIM_CHECK_ARG(p->inc >= 1, "inc must be >= 1");
+    MVSIM_CHECK_ARG(p->conv_method >= 0 && p->conv_method <= 2, "conv_method must be 0, 1 or 2");
+    MVSIM_CHECK_ARG(dim[0] <= dim[1], "attenuate3d: Nx > Ny walks outside the interval in the reference");
+    ev_next(ctx);
+    MVSIM_TRY(psf_prepare(ctx, psf_host, kdim, dim));
+    // a view replays from a graph when asked to, unless stage events are being recorded (they would be captured too) or
+    // the convolution would go through rocFFT (library calls inside a capture are not ours to vouch for)
+    int64_t P[3];
+    const bool capturable = pick_method(p->conv_method, kdim) == 2 || custom_fft_sizes(dim, kdim, P, ctx->opt);
+    if (ctx->opt.graph && !ctx->timing && capturable) MVSIM_TRY(view_graph_launch(ctx, gt, dim, kdim, p, o));
+    else MVSIM_TRY(view_enqueue(ctx, gt, dim, kdim, p, o));
     if (correction) {
+        double *partial, *scal;
+        MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
         MVSIM_HIP(hipMemcpyAsync(correction, scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MVSIM_HIP(hipStreamSynchronize(ctx->stream));
     }

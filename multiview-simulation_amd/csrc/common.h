@@ -171,6 +171,17 @@ struct mvsim_ctx {
     bool       async_ready = false;
     bool       async_twins_busy = false;      // the single-buffered rot/att/con twins are being downloaded
 
+    // hipGraph replay of views (option "graph"): cache keyed by every pointer and parameter of the view
+    struct ViewGraph {
+        std::string    key;
+        hipGraph_t     graph;
+        hipGraphExec_t exec;
+        unsigned long long last_use;
+    };
+    std::vector<ViewGraph> graphs;
+    std::unordered_set<std::string> graph_seen;
+    unsigned long long graph_tick = 0, graph_epoch = 0;
+
     // RCCL
     void* comm = nullptr;
     int   nranks = 1, rank = 0;

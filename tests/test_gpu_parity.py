@@ -1097,3 +1097,40 @@ def test_attenuate_prefix_scan_variant(ctx, orc, options, shape, delta):
     if delta == 0.0:
         nz, ny, nx = shape
         assert np.array_equal(got[:, ny - nx:, :], v[:, ny - nx:, :]) and not got[:, :ny - nx, :].any()
+
+
+def test_hipgraph_replay_of_views(mvs, synth):
+    """Option graph: the launches of a view are captured into a hipGraph (second call with the same pointers and
+    parameters) and replayed from the third call on; the PSF upload stays outside the graph.  Same voxels as the eager
+    path, for several views interleaved (one graph each), after a workspace has grown (stale graphs are dropped), and
+    with the PSF changing from call to call."""
+    gt = synth.sphere_phantom(48)
+    with mvs.Context(0) as c:
+        d_gt = _dev_volume(c, gt)
+        params = [c.view_params(degrees=20 + 70 * v, inc=1 + v, snr=25.0, seed=SEED, stream=v, conv_method=1) for v in range(3)]
+        nzo = [(48 - 1) // p.inc + 1 for p in params]
+        d_acq = [c.dev_alloc(k * 48 * 48 * 4) for k in nzo]
+        psfs = [synth.gaussian_psf(9, sigma=(1.2, 1.3, 2.0 + 0.3 * r)) for r in range(4)]
+        want = [[None] * 4 for _ in range(3)]
+        for v in range(3):
+            for r in range(4):
+                c.simulate_view_dev(d_gt, (48, 48, 48), psfs[r].copy(), params[v], d_acq[v])
+                want[v][r] = c.download(d_acq[v], (nzo[v], 48, 48))
+        c.set_option("graph", 1)
+        for r in range(4):                                  # round 0 eager, round 1 captures, rounds 2, 3 replay
+            for v in range(3):
+                c.simulate_view_dev(d_gt, (48, 48, 48), psfs[r].copy(), params[v], d_acq[v])
+                assert np.array_equal(c.download(d_acq[v], (nzo[v], 48, 48)), want[v][r]), (v, r)
+        # a larger view makes workspaces grow: the captured graphs (raw workspace addresses inside) must not be replayed
+        big = synth.sphere_phantom(64)
+        d_big = _dev_volume(c, big)
+        d_big_acq = c.dev_alloc(big.nbytes)
+        p_big = c.view_params(degrees=33, inc=1, snr=25.0, seed=SEED, stream=9, conv_method=1)
+        c.simulate_view_dev(d_big, (64, 64, 64), psfs[0].copy(), p_big, d_big_acq)
+        for v in range(3):
+            c.simulate_view_dev(d_gt, (48, 48, 48), psfs[1].copy(), params[v], d_acq[v])
+            assert np.array_equal(c.download(d_acq[v], (nzo[v], 48, 48)), want[v][1])
+        corr = c.simulate_view_dev(d_gt, (48, 48, 48), psfs[1].copy(), params[0], d_acq[0], want_corr=True)
+        assert corr > 0
+        for d in [d_gt, d_big, d_big_acq] + d_acq:
+            c.dev_free(d)
