@@ -57,8 +57,9 @@ int  mvsim_set_stream(mvsim_ctx* ctx, void* hip_stream);
 int  mvsim_synchronize(mvsim_ctx* ctx);
 /* Run-time switches of a context (tests and experiments; production needs none).  Defaults come from the environment
  * variables of the same meaning, read once per process: "fft_zpass" = auto|direct|fft (MVSIM_FFT_ZPASS),
- * "fft_backend" = custom|rocfft (MVSIM_FFT_BACKEND), "fft_pad" = "px,py,pz"|auto (MVSIM_FFT_PAD), "fused_rotate" = 1|0|2
- * (MVSIM_NO_FUSED_ROTATE; 2 = the variant that recomputes the row geometry in every lane), "poisson_queue" = 1|0 (MVSIM_POISSON_NOQUEUE), "early_sum" = 1|0 (MVSIM_NO_EARLY_SUM),
+ * "fft_backend" = custom|rocfft (MVSIM_FFT_BACKEND), "fft_pad" = "px,py,pz"|auto (MVSIM_FFT_PAD), "fused_rotate" = auto|1|0|2
+ * (MVSIM_NO_FUSED_ROTATE; auto = fused from 131072 columns up, separate kernels for small views; 2 = the variant that
+ * recomputes the row geometry in every lane), "poisson_queue" = 1|0 (MVSIM_POISSON_NOQUEUE), "early_sum" = 1|0 (MVSIM_NO_EARLY_SUM),
  * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "fuse_tail" = 0|1 (adjust +
  * extract + Poisson phase 1 in the epilogue of the convolution's last pass), "attenuate" = serial|scan (mvsim_attenuate3d
  * as a wavefront-level prefix scan along the illumination axis: parallel in y, not bit-identical to the serial walk).

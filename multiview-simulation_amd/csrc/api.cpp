@@ -39,7 +39,8 @@ int parse_option(Options& o, const char* name, const char* value)
     }
     if (n == "fused_rotate") {
         if (v == "1" || v == "on" || v == "lds") o.fused_rotate = 1; else if (v == "0" || v == "off") o.fused_rotate = 0;
-        else if (v == "2" || v == "lane") o.fused_rotate = 2; else return MVSIM_EINVAL;
+        else if (v == "2" || v == "lane") o.fused_rotate = 2; else if (v == "3" || v == "auto") o.fused_rotate = 3;
+        else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
     if (n == "poisson_queue") {
@@ -289,7 +290,7 @@ static int convolve_dev_impl(mvsim_ctx* ctx, const float* img, const int64_t dim
 {
     MVSIM_CHECK_ARG(img != out, "convolve cannot run in place");
     if (pick_method(method, kdim) == 2) {
-        if (tail) tail->zstride = 1;
+        if (tail) { tail->zstride = 1; tail->corr_done = false; }
         ev_begin(ctx, ST_CONVOLVE);
         MVSIM_TRY(launch_stencil(ctx, img, dim, ctx->psf_dev.as<float>(), kdim, out));
         ev_end(ctx, ST_CONVOLVE);
@@ -690,6 +691,7 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     ConvTail tail;
     const long long plane_vox = (long long)dim[0] * dim[1];
     tail.zstride = (!materialise && p->inc > 1 && plane_vox % 4 == 0 && (!noise || ctx->opt.poisson_queue == 1)) ? p->inc : 1;
+    tail.corr_n = n; tail.min_value = p->min_value; tail.target_average = p->target_average;
     if (method == 1 && ctx->opt.fuse_tail && (!noise || ctx->opt.poisson_queue == 1)) {
         const size_t qb = noise ? fused_tail_queue_bytes(dim, kdim, p->inc, materialise, ctx->opt) : 0;
         if (!noise || qb > 0) {
@@ -706,7 +708,7 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
 
     ev_begin(ctx, ST_ADJUST);
     if (method == 2) MVSIM_TRY(launch_sum(ctx->stream, con, n, partial, scal));   // FFT path sums in its crop epilogue
-    MVSIM_TRY(launch_adjust_corr(ctx->stream, scal, n, p->min_value, p->target_average));
+    if (!tail.corr_done) MVSIM_TRY(launch_adjust_corr(ctx->stream, scal, n, p->min_value, p->target_average));
     if (materialise) MVSIM_TRY(launch_adjust_apply(ctx->stream, con, n, scal, p->min_value));
     ev_end(ctx, ST_ADJUST);
 
@@ -885,7 +887,7 @@ int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t 
     affine_invert_host(m, inv.m);
     bool fused = false;
     MVSIM_TRY(launch_rotate_attenuate_planes(ctx->stream, gt, nullptr, ctx->vol_b.as<float>(), dim, inv, p->delta,
-                                             (int)za, (int)(zb - za), ctx->opt.fused_rotate, &fused));
+                                             (int)za, (int)(zb - za), ctx->opt.fused_rotate == 2 ? 2 : 1, &fused));   // planes [za, zb) exist only fused
     if (!fused) {
         set_error("slab tiling needs the fused rotate+attenuate kernel");
         return MVSIM_EINVAL;

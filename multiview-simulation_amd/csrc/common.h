@@ -92,8 +92,11 @@ struct PinnedRing {
 struct Options {
     int     zpass = 0;                 // z pass of the hand-written convolution: 0 auto (direct for Kz <= 64), 1 direct, 2 FFT
     bool    rocfft = false;            // library fallback instead of the hand-written passes
-    int     fused_rotate = 1;          // rotate+attenuate as one kernel when the rotation is about x: 0 off, 1 row geometry
-                                       // shared through LDS (production), 2 recomputed per lane (kept for A/B runs)
+    int     fused_rotate = 3;          // rotate+attenuate as one kernel when the rotation is about x: 0 off, 1 row geometry
+                                       // shared through LDS, 2 recomputed per lane (kept for A/B runs), 3 auto (production):
+                                       // 1 when the view has >= 2 waves per SIMD of columns to walk, else 0 -- one lane walks
+                                       // one (x, z) column, so a 128^3 view is 256 waves of serial latency (measured 30 us
+                                       // against 20 us for the two kernels; break-even at 256^3)
     bool    attenuate_scan = false;    // attenuate3d (stage operator) as a wavefront prefix scan along y: re-associates the
                                        // fp64 products (float outputs differ from the serial walk by one ulp on < 1e-6 of the voxels)
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
@@ -252,6 +255,10 @@ struct ConvTail {
     uint32_t stream = 0;
     // out: true when the convolution did all of that (sum, factor in the context's scalar slots; acquisition complete)
     bool     fused = false;
+    // in: voxels of the view (> 0: compute adjustImage's factor from min_value / target_average together with the sum);
+    // out: corr_done = the factor is in the context's scalar slot, no separate k_adjust_corr needed
+    long long corr_n = 0;
+    bool      corr_done = false;
 };
 // bytes of queue workspace the fused tail needs for this geometry (0: the geometry has no fused tail)
 size_t fused_tail_queue_bytes(const int64_t dim[3], const int64_t kdim[3], int inc, bool con_wanted, const Options& opt);

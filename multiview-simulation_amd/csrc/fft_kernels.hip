@@ -771,8 +771,11 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     }
 }
 
+// scal[0] = factor * sum of the partials; with corr_n > 0 also adjustImage's factor scal[1] = (target - min) / (scal[0] / n)
+// (Tools.java:146-147: the subtraction in float, the rest in double) -- one launch less per view than a separate kernel.
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partial, long long count,
-                                                          double* __restrict__ scal, double factor)
+                                                          double* __restrict__ scal, double factor, long long corr_n,
+                                                          float min_value, float target)
 {
     __shared__ double sh[16];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -792,7 +795,9 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < 16; ++w) t += sh[w];
-        scal[0] = t * factor;
+        const double sum = t * factor;
+        scal[0] = sum;
+        if (corr_n > 0) scal[1] = (double)(target - min_value) / (sum / (double)corr_n);
     }
 }
 
@@ -1404,6 +1409,10 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
                 ((reinterpret_cast<uintptr_t>(tail->acq) | reinterpret_cast<uintptr_t>(tail->con_adj)) & 15) == 0;
     if (fuse) zstride = tail->con_adj ? 1 : tail->inc;
     if (tail) { tail->zstride = zstride; tail->fused = fuse; }
+    // adjustImage's factor rides in the reduction of the sum when the caller described it (a view; not the stage operator)
+    const long long corr_n = (tail && tail->corr_n > 0 && !is_slab) ? tail->corr_n : 0;
+    const float corr_min = tail ? tail->min_value : 0.f, corr_target = tail ? tail->target_average : 1.f;
+    if (tail) tail->corr_done = corr_n > 0;
     if (is_slab && !zdirect) {
         set_error("z-slab tiling needs the direct z pass (PSF depth %d > 64 or option fft_zpass=fft)", kz);
         return MVSIM_EINVAL;
@@ -1518,7 +1527,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             MVSIM_TRY(launch_zconv(ctx, z, py));
             if (early) {
                 // same factor pass E applies to every voxel (a float), so that the two sums estimate the same quantity
-                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, z.sum_partial, zblocks, scal, (double)scale_f);
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, z.sum_partial, zblocks, scal, (double)scale_f,
+                                   corr_n, corr_min, corr_target);
                 MVSIM_HIP(hipGetLastError());
             }
             Fz = G;
@@ -1545,9 +1555,11 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         C2RFuse fz{};
         if (fuse) {
             // adjustImage's factor must exist before pass E runs: (target - min) / (sum / n) from the early sum
-            ev_begin(ctx, ST_ADJUST);
-            MVSIM_TRY(launch_adjust_corr(s, scal, (int64_t)dim[0] * dim[1] * dim[2], tail->min_value, tail->target_average));
-            ev_end(ctx, ST_ADJUST);
+            if (!tail->corr_done) {
+                ev_begin(ctx, ST_ADJUST);
+                MVSIM_TRY(launch_adjust_corr(s, scal, (int64_t)dim[0] * dim[1] * dim[2], tail->min_value, tail->target_average));
+                ev_end(ctx, ST_ADJUST);
+            }
             fz.scal = scal; fz.min_value = tail->min_value; fz.con = tail->con_adj; fz.acq = tail->acq;
             fz.acq_every = tail->con_adj ? tail->inc : 1; fz.idx_zstride = zstride; fz.noise = tail->noise ? 1 : 0;
             fz.mul = tail->mul; fz.k0 = (uint32_t)tail->seed; fz.k1 = (uint32_t)(tail->seed >> 32); fz.stream = tail->stream;
@@ -1569,7 +1581,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         MVSIM_TRY(launch_c2r(ctx, M, Fz, out, tw_m, tw_px, hxp, py * zstride, (int)dim[0], (int)dim[1], (long long)dim[1] * nk, scale,
                              ctx->partials_e.as<double>(), &nblk, fuse ? &fz : nullptr));
         if (fuse && nblk != (int)fblocks) { set_error("fused tail: block count mismatch"); return MVSIM_EINVAL; }
-        if (!early) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal, 1.0);
+        if (!early) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal, 1.0,
+                                       corr_n, corr_min, corr_target);
         MVSIM_HIP(hipGetLastError());
         ev_end(ctx, ST_PASS_E);
         if (fuse && tail->noise) {

@@ -255,7 +255,7 @@ int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], con
 {
     int64_t P[3];
     if (custom_fft_sizes(dim, kdim, P, ctx->opt)) return custom_fft_convolve(ctx, img_dev, dim, psf_dev, kdim, P, out_dev, tail);
-    if (tail) tail->zstride = 1;                       // the library path produces the whole volume
+    if (tail) { tail->zstride = 1; tail->corr_done = false; }   // the library path produces the whole volume
     choose_padded(dim, kdim, P, ctx->opt);
     FftPlan* pl = nullptr;
     MVSIM_TRY(get_plan(ctx, P, &pl));

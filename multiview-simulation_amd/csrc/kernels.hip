@@ -548,7 +548,9 @@ int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or
     const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
     const bool x_identity = inv.m[0] == 1.0 && inv.m[1] == 0.0 && inv.m[2] == 0.0 && inv.m[3] == 0.0 &&
                             inv.m[4] == 0.0 && inv.m[8] == 0.0;
-    // fused_mode: 0 separate kernels, 1 geometry table in LDS (production), 2 every lane recomputes the row geometry
+    // fused_mode: 0 separate kernels, 1 geometry table in LDS, 2 every lane recomputes the row geometry, 3 = 1 when the
+    // columns fill the chip (>= 2 waves per SIMD), else 0
+    if (fused_mode == 3) fused_mode = ((int64_t)nx * z_count >= 131072) ? 1 : 0;
     *fused = x_identity && fused_mode != 0;
     if (!*fused) return MVSIM_OK;
     if (fused_mode == 1) {

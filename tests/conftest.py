@@ -36,6 +36,9 @@ def orc():
 def ctx(mvs):
     """A GPU context; GPU tests fail (not skip) when the HIP library or device is missing."""
     c = mvs.Context(0)
+    # the small test volumes go through the fused rotate+attenuate kernel of the 512^3 workload as well (the default,
+    # "auto", hands volumes below 2 waves per SIMD to the two separate kernels)
+    c.set_option("fused_rotate", 1)
     yield c
     c.close()
 

@@ -379,8 +379,10 @@ def test_context_options_select_identical_variants(ctx, orc, synth, options):
     b = ctx.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
     options(fused_rotate=1, poisson_queue=0)
     c = ctx.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
+    options(fused_rotate="auto", poisson_queue=1)
+    d = ctx.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
     for k in ("rot", "att", "con", "acq"):
-        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]) and np.array_equal(a[k], d[k]), k
     with pytest.raises(ValueError):
         ctx.set_option("fft_zpass", "sideways")
     with pytest.raises(ValueError):

@@ -8,7 +8,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
-BENCH="bench.py --no-cpu-baseline --no-end-to-end --no-size-1024"
+BENCH="bench.py --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams"
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/trace -o run -- python3 $BENCH > $O/trace.log 2>&1
 python3 tools/kstats.py $O/trace 20 $O/kernel_stats.csv > $O/kernel_stats.txt

@@ -3,7 +3,11 @@ import numpy as np
 sys.path.insert(0, "/root/repo")
 mvs = importlib.import_module("multiview-simulation_amd")
 synth = importlib.import_module("multiview-simulation_amd.synthetic")
-for n, k, graph in ((128, 15, 0), (128, 15, 1), (64, 9, 0), (64, 9, 1)):
+# python tools/small_view_overhead.py [n k graph]  (one case only, e.g. under rocprofv3 --kernel-trace --stats)
+CASES = ((128, 15, 0), (128, 15, 1), (64, 9, 0), (64, 9, 1))
+if len(sys.argv) == 4:
+    CASES = (tuple(int(a) for a in sys.argv[1:4]),)
+for n, k, graph in CASES:
     gt = synth.sphere_phantom(n)
     ctx = mvs.Context(0)
     ctx.set_option("graph", graph)
