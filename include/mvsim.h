@@ -60,7 +60,8 @@ int  mvsim_synchronize(mvsim_ctx* ctx);
  * "fft_backend" = custom|rocfft (MVSIM_FFT_BACKEND), "fft_pad" = "px,py,pz"|auto (MVSIM_FFT_PAD), "fused_rotate" = auto|1|0|2
  * (MVSIM_NO_FUSED_ROTATE; auto = fused from 131072 columns up, separate kernels for small views; 2 = the variant that
  * recomputes the row geometry in every lane), "poisson_queue" = 1|0 (MVSIM_POISSON_NOQUEUE), "early_sum" = 1|0 (MVSIM_NO_EARLY_SUM),
- * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "fuse_tail" = 0|1 (adjust +
+ * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "psf_overlap" = 1|0 (the PSF's spectrum on a side
+ * stream of the context, concurrent with the image passes A and B), "fuse_tail" = 0|1 (adjust +
  * extract + Poisson phase 1 in the epilogue of the convolution's last pass), "attenuate" = serial|scan (mvsim_attenuate3d
  * as a wavefront-level prefix scan along the illumination axis: parallel in y, not bit-identical to the serial walk).
  * MVSIM_OPTIONS="name=value;name=value" sets any of them process-wide.  Unknown names or values: MVSIM_EINVAL. */
@@ -237,6 +238,8 @@ int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, con
 
 /* ---- per-stage device timings of the last simulate_view / stage call (milliseconds) ------ */
 typedef struct mvsim_timings {
+    /* psf_ms is 0 when the PSF spectrum ran on the context's side stream (option psf_overlap, views of >= 2^24 voxels):
+     * it then overlaps passes A and B and its time is part of convolve_ms */
     float rotate_ms, attenuate_ms, psf_ms, convolve_ms, adjust_ms, extract_ms, total_ms;
     /* the passes of the hand-written convolution, nested inside convolve_ms (0 on other paths): x real->complex,
      * y forward, z (direct convolution or FFT + product + inverse FFT), y inverse, x complex->real + crop + sum */

@@ -54,6 +54,7 @@ int parse_option(Options& o, const char* name, const char* value)
     }
     if (n == "early_sum") return flag(&o.early_sum);
     if (n == "fuse_tail") return flag(&o.fuse_tail);
+    if (n == "psf_overlap") return flag(&o.psf_overlap);
     if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
     if (n == "broadcast") {
         if (v == "scatter_allgather" || v == "auto") o.bcast_ring = false; else if (v == "ring") o.bcast_ring = true; else return MVSIM_EINVAL;
@@ -374,6 +375,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     if (ctx->ev_created)
         for (int k = 0; k < mvsim_ctx::TIMING_SLOTS; ++k)
             for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(ctx->evr[k][s][0]); (void)hipEventDestroy(ctx->evr[k][s][1]); }
+    if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MVSIM_OK;
@@ -749,7 +751,7 @@ static std::string view_graph_key(mvsim_ctx* ctx, const float* gt, const int64_t
     add(&o->rot, sizeof(o->rot)); add(&o->att, sizeof(o->att)); add(&o->con, sizeof(o->con)); add(&o->acq, sizeof(o->acq));
     add(&ctx->stream, sizeof(ctx->stream));
     const Options& q = ctx->opt;
-    const int oo[8] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, 0, 0};
+    const int oo[8] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, q.psf_overlap ? 1 : 0, 0};
     add(oo, sizeof(oo));
     return k;
 }
@@ -1364,6 +1366,8 @@ int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t)
     float total = 0.f;
     for (int s = 0; s < ST_COUNT; ++s) {
         ms[s] = cnt[s] ? (float)(sum[s] / cnt[s]) : 0.f;
+        // a PSF spectrum that ran on the side stream overlaps passes A and B: it is part of convolve_ms, not a stage of its own
+        if (s == ST_PSF && ctx->psf_on_side) ms[s] = 0.f;
         if (s < ST_PASS_A) total += ms[s];              // the passes are nested inside ST_CONVOLVE
     }
     t->rotate_ms = ms[ST_ROTATE]; t->attenuate_ms = ms[ST_ATTENUATE]; t->psf_ms = ms[ST_PSF];

@@ -102,6 +102,7 @@ struct Options {
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
                                        // resolver, production), 0: one kernel
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
+    bool    psf_overlap = true;        // PSF spectrum on the context's side stream, concurrent with passes A and B
     bool    fuse_tail = false;         // adjust + extract + Poisson phase 1 in the epilogue of the convolution's last pass: saves
                                        // the 8 N bytes of the convolved volume's round trip, but the merged kernel is bound by
                                        // vector issue (0.61 ms against 0.25 + 0.36 ms for pass E and the streaming Poisson kernel
@@ -163,6 +164,10 @@ struct mvsim_ctx {
     static constexpr int ASYNC_SLOTS = 2, ASYNC_HISTORY = 8;
     double     async_corr_done[ASYNC_HISTORY] = {};   // adjustImage factors of the views that have landed
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    // the PSF's (x,y) spectrum is independent of the image passes A and B: it runs on a side stream beside them
+    hipStream_t side_stream = nullptr;
+    hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
+    bool        psf_on_side = false;          // last convolution: PSF spectrum overlapped (its time is inside passes A/B)
     mvsim::DevBuf async_gt[ASYNC_SLOTS], async_acq[ASYNC_SLOTS];
     hipEvent_t ev_h2d[ASYNC_SLOTS] = {}, ev_compute[ASYNC_SLOTS] = {}, ev_d2h[ASYNC_SLOTS] = {};
     bool       async_inflight[ASYNC_SLOTS] = {};

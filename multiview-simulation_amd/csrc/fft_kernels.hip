@@ -611,7 +611,8 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     float2* wbuf = lds + wave * LW * LP;
     // FUSE: behind the 32 doubles of `red`: two append counters, then one P1Scratch per wave
     unsigned int* qctr = reinterpret_cast<unsigned int*>(red + 32);
-    P1Scratch* scratch = reinterpret_cast<P1Scratch*>(red + 34);
+    constexpr size_t SCR_OFF = ((size_t)(NR * LP + M) * sizeof(float2) + 34 * sizeof(double) + 15) & ~(size_t)15;
+    P1Scratch* scratch = reinterpret_cast<P1Scratch*>(reinterpret_cast<char*>(lds) + SCR_OFF);
     if (FUSE && tid == 0) { qctr[0] = 0u; qctr[1] = 0u; }
     for (int i = tid; i < M; i += T) tw[i] = twg[i];
     const long long row0 = (long long)blockIdx.x * NR + wave * LW;           // output rows (y < ny, z < nz)
@@ -1146,7 +1147,7 @@ static int launch_c2r_t(mvsim_ctx* ctx, const float2* srcc, float* out, const fl
     *nblocks = blocks;
     hipStream_t s = ctx->stream;
     if (fuse) {
-        const size_t lds = C::LDS + 16 + (size_t)C::NW * sizeof(P1Scratch);
+        const size_t lds = C::LDS + 32 + (size_t)C::NW * sizeof(P1Scratch);
         MVSIM_TRY(set_lds(ctx, k_fft_x_c2r<PLAN, true>, lds));
         hipLaunchKernelGGL((k_fft_x_c2r<PLAN, true>), dim3((unsigned)blocks), dim3(C::T), lds, s, srcc, out, tw, twx, hxp, py, nx, ny,
                            rows, scale, partial, *fuse);
@@ -1453,19 +1454,35 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     // ---- PSF spectrum G.  The embedded kernel is zero outside Kx*Ky*Kz taps, so the x pass runs on the
     //      Ky*Kz non-zero rows only, the y pass on the Kz non-zero planes only (sparse loads), and the z
     //      pass expands Kz planes to the full spectrum.
+    // It depends on nothing the image passes A and B produce and is a handful of small launches, so it runs on the
+    // context's side stream beside them (fork here, join before the z pass reads G2 / G).
+    // Only where it pays: the fork and the join cost ~10 us of cross-stream dependency, more than the spectrum of a small view.
+    const bool side = ctx->opt.psf_overlap && (int64_t)dim[0] * dim[1] * dim[2] >= (int64_t)1 << 24;
+    ctx->psf_on_side = side;
+    if (side) {
+        if (!ctx->side_stream) {
+            MVSIM_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        MVSIM_HIP(hipEventRecord(ctx->ev_fork, s));
+        MVSIM_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        ctx->stream = ctx->side_stream;                 // the launch helpers enqueue on ctx->stream
+    }
+    int psf_rc = MVSIM_OK;
     ev_begin(ctx, ST_PSF);
-    {
+    do {
         SrcMap m;
         m.x = DimMap{kx, px, kx - kx / 2, kx / 2, 1, kx / 2};   // embed along x with wrap-around
         m.y = DimMap{ky, ky, ky, 0, 1, 0};                       // compact: identity
         m.z = DimMap{kz, kz, kz, 0, 1, 0};
-        MVSIM_TRY(launch_r2c(ctx, M, psf, m, G1, tw_m, tw_px, hxp, (long long)ky * kz));
+        if ((psf_rc = launch_r2c(ctx, M, psf, m, G1, tw_m, tw_px, hxp, (long long)ky * kz)) != MVSIM_OK) break;
         LinesArgs a{};
         a.src = G1; a.dst = G2; a.spec = nullptr; a.tw = tw_py;
         a.src_es = hxp; a.src_outer = (long long)hxp * ky;          // per kz plane
         a.dst_es = hxp; a.dst_outer = plane;
         a.lmap = DimMap{ky, py, ky - ky / 2, ky / 2, 1, ky / 2};
-        MVSIM_TRY(launch_lines(ctx, py, FWD, true, a, hxp / tile_y, kz));
+        if ((psf_rc = launch_lines(ctx, py, FWD, true, a, hxp / tile_y, kz)) != MVSIM_OK) break;
         if (!zdirect) {
             LinesArgs c{};
             c.src = G2; c.dst = G; c.spec = nullptr; c.tw = tw_pz;
@@ -1473,10 +1490,16 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             c.dst_es = plane; c.dst_outer = hxp;
             c.lmap = DimMap{kz, pz, kz - kz / 2, kz / 2, 1, kz / 2};
             c.dst_tile_major = 1;                                         // consumed line by line in pass C
-            MVSIM_TRY(launch_lines(ctx, pz, FWD, true, c, hxp / tile_z, py));
+            psf_rc = launch_lines(ctx, pz, FWD, true, c, hxp / tile_z, py);
         }
-    }
+    } while (false);
     ev_end(ctx, ST_PSF);
+    if (side) {
+        // always joined, also after a failed launch: a stream capture must not end with the side stream dangling
+        ctx->stream = s;
+        MVSIM_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
+    }
+    MVSIM_TRY(psf_rc);
 
     // ---- image: A, B, C (with product), D, E
     ev_begin(ctx, ST_CONVOLVE);
@@ -1507,6 +1530,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         ev_begin(ctx, ST_PASS_B);
         MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
         ev_end(ctx, ST_PASS_B);
+        if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));    // the z pass reads the PSF spectrum
         ev_begin(ctx, ST_PASS_C);
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
         float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum

@@ -845,10 +845,7 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out
     // inversion items (0 < lambda < 10 that the shortcut of k_extract4_noise could not settle), from the back
     for (unsigned int i = threadIdx.x; i < ns; i += 256u) {
         const PItem it = seg[segcap - 1u - i];
-        const unsigned long long g = it.index >> 2;                  // the voxel's word of its group block
-        const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream, 0u, k0, k1);
-        const uint32_t lane = (uint32_t)it.index & 3u;
-        out[it.out] = poisson_small((double)it.v * mul, lane == 0 ? r.x : (lane == 1 ? r.y : (lane == 2 ? r.z : r.w)));
+        out[it.out] = poisson_small((double)it.v * mul, it.w0);     // w0: the voxel's word of its group block
     }
     // PTRS items.  A lane works on ONE ATTEMPT per trip and, the moment its item is resolved, takes the next item of the
     // segment (LDS ticket): every trip has every lane on a live attempt, instead of the wave idling until its unluckiest
@@ -859,7 +856,7 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out
     __syncthreads();
     unsigned int i = threadIdx.x;
     PItem it;
-    it.index = 0ull; it.out = 0ull; it.v = 0.f; it.attempt = 0u;
+    it.index = 0ull; it.out = 0ull; it.v = 0.f; it.attempt = 0u; it.w0 = 0u; it.w1 = 0u;
     bool have = i < n;
     if (have) it = seg[i];
     uint32_t a = it.attempt;
@@ -873,11 +870,8 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out
         } else {
             uint32_t w0, w1;
             if (a == 0u) {
-                const unsigned long long pr = it.index >> 1;
-                const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), stream, 1u, k0, k1);
-                const bool odd = (it.index & 1ull) != 0ull;
-                w0 = odd ? r.z : r.x;
-                w1 = odd ? r.w : r.y;
+                w0 = it.w0;                                          // the words phase 1 drew for attempt 0
+                w1 = it.w1;
             } else {
                 ptrs_retry_words(it.index, a, k0, k1, stream, w0, w1);
             }
@@ -904,7 +898,7 @@ int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const u
 }
 
 // Work-queue geometry for n_out output voxels: `blocks` blocks of 256 lanes x 4 voxels walk the volume with a
-// grid stride; each owns a segment that can hold all of its voxels (24 B per output voxel of HBM workspace).
+// grid stride; each owns a segment that can hold all of its voxels (32 B per output voxel of HBM workspace).
 constexpr int POISSON_MAX_BLOCKS = 256 * 64;
 static void poisson_geometry(int64_t n_out, int* blocks, unsigned int* segcap)
 {

@@ -404,32 +404,32 @@ __device__ __forceinline__ float4 poisson_counter4(double l0, double l1, double 
 // cheap is decided here, everything else becomes a work item for k_poisson_resolve:
 //   * lambda <= 0 / NaN                       -> 0
 //   * 0 < lambda < 10 (inversion)             -> the "count is 0" shortcut; a possible count >= 1 is queued
-//   * lambda >= 10 (PTRS)                     -> the bright voxels of the wave are COMPACTED into a wave-private LDS list
-//                                                (ballot + prefix count) and the attempt-0 squeeze then runs one voxel per
-//                                                lane with all lanes busy; what needs the exact test or a retry is queued
-// Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.  Two things are pure execution
+//   * lambda >= 10 (PTRS)                     -> the bright voxel PAIRS of the wave (a pair shares the Philox block of its
+//                                                attempt 0) are COMPACTED into a wave-private LDS list (ballot + prefix
+//                                                count) and the attempt-0 squeeze then runs one pair per lane with all lanes
+//                                                busy; what the squeeze does not accept is queued
+// Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.  Three things are pure execution
 // shortcuts that cannot change a decision:
 //   - the regime (small / bright) is read off an fp32 product with a guard band; inside the band the fp64 product decides;
 //   - the shortcut of the inversion regime, "u < exp(-lambda)" whenever u < 1 - lambda - 1e-12, is tested in fp32 with a
-//     margin (1e-6) that covers every fp32 rounding involved, so it fires only where the fp64 statement holds.
+//     margin (1e-6) that covers every fp32 rounding involved, so it fires only where the fp64 statement holds;
+//   - the squeeze of PTRS attempt 0 is evaluated in fp32 (ptrs_squeeze_f32) and only trusted with guard bands; whatever
+//     it cannot certify goes to the resolver as "attempt 0 not evaluated", where the fp64 recipe runs.
 // ------------------------------------------------------------------------------------------------------------
-struct PItem {
+struct __attribute__((aligned(16))) PItem {
     unsigned long long index;     // source voxel index (RNG counter)
     unsigned long long out;       // element index in the output
     float v;                      // adjusted voxel value (lambda = v * mul)
-    unsigned int attempt;         // first attempt still to evaluate (0: exact test of attempt 0 pending)
+    unsigned int attempt;         // first attempt still to evaluate (kSmallLambdaItem: inversion item)
+    unsigned int w0, w1;          // random words of attempt 0 (inversion item: w0 = the voxel's word of its group block)
 };
 constexpr unsigned int kSmallLambdaItem = 0xFFFFFFFFu;   // PItem::attempt of an inversion (lambda < 10) work item
 
-struct __attribute__((aligned(8))) BrightItem {
-    unsigned int local;           // 4 * lane + component inside the wave's slot
-    float v;
-};
-
-// wave-private LDS scratch of phase 1 (4 KB)
-struct P1Scratch {
-    BrightItem list[256];
+// wave-private LDS scratch of phase 1 (3.5 KB)
+struct __attribute__((aligned(16))) P1Scratch {
+    float vin[256];               // the slot's voxel values, [4 * lane + component]
     float outb[256];
+    unsigned int plist[128];      // bright pairs: 2 * lane + half
     unsigned long long index4[64], out4[64];
 };
 
@@ -449,90 +449,145 @@ __device__ __forceinline__ void p1_wave_order()
     __builtin_amdgcn_wave_barrier();
 }
 
+// regime of one voxel: 0: lambda <= 0 or NaN, 1: inversion, 2: PTRS
+__device__ __forceinline__ int p1_class(float v, const P1Args& a)
+{
+    const float lf = v * a.mulf;
+    if (!(v > 0.f) || !(a.mul > 0.0)) return 0;
+    if (lf < 9.99f) return 1;
+    if (lf > 10.01f) return 2;
+    return ((double)v * a.mul >= 10.0) ? 2 : 1;
+}
+
+// The squeeze of PTRS attempt 0 (ptrs_setup + ptrs_fast, outcome 0) in single precision.  Returns true only when the
+// fp64 recipe is CERTAIN to accept at the squeeze with the same k:
+//   b, a:  v_sqrt_f32 / constants / two roundings          -> relative error <= 4e-7 (b), 1e-6 (a)
+//   U, us: float(int32(w0 - 2^31)) * 2^-32                  -> absolute error <= 6e-8, so us >= 0.070001f implies us >= 0.07
+//   t = 2a/us + b (v_rcp_f32, 1 ulp)                         -> relative error <= 2.3e-6
+//   x = t U + 0.43                                           -> absolute error <= 1.1e-6 t + 5e-8
+//   k = floor(lambda + x) with lambda in fp64: certain when the fraction stays 4e-6 t + 1e-5 away from an integer (3.6 x the bound);
+//   V (b - 2) <= 0.9277 (b - 2) - 3.6224: both sides carry <= 1.2e-6 b; trusted with a margin of 4e-6 b + 1e-5.
+// Everything else (about a quarter of the bright voxels: the squeeze rejects them anyway) is left to the resolver.
+__device__ __forceinline__ bool ptrs_squeeze_f32(double lambda, uint32_t w0, uint32_t w1, float& res)
+{
+    const float slam = __builtin_amdgcn_sqrtf((float)lambda);
+    const float b = 0.931f + 2.53f * slam;
+    const float a = -0.059f + 0.02483f * b;
+    const float U = (float)(int)(w0 ^ 0x80000000u) * 0x1.0p-32f;
+    const float V = (float)w1 * 0x1.0p-32f;
+    const float us = 0.5f - fabsf(U);
+    const float bm2 = b - 2.0f;
+    const float t = (2.0f * a) * __builtin_amdgcn_rcpf(us) + b;
+    const float x = t * U + 0.43f;
+    const double y = lambda + (double)x;
+    const double fl = floor(y);
+    const float frac = (float)(y - fl);
+    const float g = 4.0e-6f * t + 1.0e-5f;
+    res = (float)(long long)fl;
+    return us >= 0.070001f && V * bm2 <= (0.9277f * bm2 - 3.6224f) - (4.0e-6f * b + 1.0e-5f) && frac >= g && frac <= 1.0f - g &&
+           lambda < 1.0e9;
+}
+
+__device__ __forceinline__ void p1_push(PItem* slot, unsigned long long index, unsigned long long out, float v, unsigned int attempt,
+                                        unsigned int w0, unsigned int w1)
+{
+    // two 16-byte stores
+    uint4* q = reinterpret_cast<uint4*>(slot);
+    q[0] = make_uint4((unsigned int)index, (unsigned int)(index >> 32), (unsigned int)out, (unsigned int)(out >> 32));
+    q[1] = make_uint4(__float_as_uint(v), attempt, w0, w1);
+}
+
 __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, unsigned long long index4, unsigned long long out4,
                                                const P1Args& a, P1Scratch* ws, int lane, float ov[4])
 {
-    int cls[4];                   // 0: lambda <= 0 or NaN, 1: inversion regime, 2: PTRS regime
-    float lf[4];
+    int cls[4];
     bool small_any = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        lf[c] = vv[c] * a.mulf;
-        int k;
-        if (!valid || !(vv[c] > 0.f) || !(a.mul > 0.0)) k = 0;
-        else if (lf[c] < 9.99f) k = 1;
-        else if (lf[c] > 10.01f) k = 2;
-        else k = ((double)vv[c] * a.mul >= 10.0) ? 2 : 1;
-        cls[c] = k;
-        small_any |= k == 1;
+        cls[c] = valid ? p1_class(vv[c], a) : 0;
+        small_any |= cls[c] == 1;
         ov[c] = 0.f;
     }
     if (small_any) {
         const unsigned long long g = index4 >> 2;
+#ifdef MVSIM_EXP_NOPHILOX
+        const Philox4 r = Philox4{(uint32_t)g * 2654435761u, (uint32_t)g * 40503u + 77u, (uint32_t)g ^ 0x9E3779B9u, (uint32_t)(g >> 3)};
+#else
         const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), a.stream, 0u, a.k0, a.k1);
+#endif
         const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (cls[c] == 1) {
-                const float uf = (float)w[c] * 0x1.0p-32f;
-                if (!(lf[c] < 1.0f && uf < (1.0f - lf[c]) - 1.0e-6f)) {
+                // count = 0  <=>  u = (w + 0.5) 2^-32 < exp(-lambda).  Sufficient, in integers: w < thr with
+                // thr = floor((1 - lf - 2e-6) 2^32): lf is lambda to 1.2e-7 and the two fp32 subtractions round by <= 1.2e-7,
+                // so w < thr implies u < 1 - lambda - 1.7e-6 < exp(-lambda).  (lf >= 1: thr = 0, never fires.)
+                const float tf = (1.0f - vv[c] * a.mulf) - 2.0e-6f;
+                const uint32_t thr = (uint32_t)(fmaxf(tf, 0.f) * 4294967296.0f);
+#ifndef MVSIM_EXP_NOSMALLPUSH
+                if (!(w[c] < thr)) {
                     const unsigned int pos = atomicAdd(a.nqs, 1u);
-                    PItem it;
-                    it.index = index4 + (unsigned long long)c;
-                    it.out = out4 + (unsigned long long)c;
-                    it.v = vv[c];
-                    it.attempt = kSmallLambdaItem;
-                    a.seg[a.segcap - 1u - pos] = it;
+                    p1_push(a.seg + (a.segcap - 1u - pos), index4 + (unsigned long long)c, out4 + (unsigned long long)c, vv[c],
+                            kSmallLambdaItem, w[c], 0u);
                 }
+#else
+                if (!(w[c] < thr)) ov[c] = 1.f;
+#endif
             }
     }
-    // bright voxels of the wave -> dense list
+    // bright pairs of the wave -> dense list
     unsigned int nb = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const bool b = cls[c] == 2;
+    for (int h = 0; h < 2; ++h) {
+        const bool b = cls[2 * h] == 2 || cls[2 * h + 1] == 2;
         const unsigned long long m = __ballot(b);
         if (m != 0ull) {
             const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-            if (b) {
-                BrightItem bi;
-                bi.local = 4u * (unsigned int)lane + (unsigned int)c;
-                bi.v = vv[c];
-                ws->list[nb + pre] = bi;
-            }
+            if (b) ws->plist[nb + pre] = 2u * (unsigned int)lane + (unsigned int)h;
             nb += (unsigned int)__popcll(m);
         }
     }
+#ifdef MVSIM_EXP_NOBRIGHT
+    nb = 0u;
+#endif
     if (nb == 0u) return;                                   // wave-uniform
+    *reinterpret_cast<float4*>(&ws->vin[4 * lane]) = make_float4(vv[0], vv[1], vv[2], vv[3]);
     ws->index4[lane] = index4;
     ws->out4[lane] = out4;
     p1_wave_order();
     for (unsigned int i = (unsigned int)lane; i < nb; i += 64u) {
-        const BrightItem bi = ws->list[i];
-        const unsigned int owner = bi.local >> 2, comp = bi.local & 3u;
-        const unsigned long long idx = ws->index4[owner] + comp;
-        const double lam = (double)bi.v * a.mul;
+        const unsigned int pid = ws->plist[i];
+        const unsigned int owner = pid >> 1, first = (pid & 1u) * 2u;
+        const float2 pv = *reinterpret_cast<const float2*>(&ws->vin[4u * owner + first]);
+        const unsigned long long idx = ws->index4[owner] + first;       // even: the pair's attempt-0 block is idx >> 1
         const unsigned long long pr = idx >> 1;
         const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), a.stream, 1u, a.k0, a.k1);
-        const bool odd = (idx & 1ull) != 0ull;
-        double us, V, kd;
-        // (the fp32 screen of the exact test stays in the resolver: run here it costs the wave its ~60 instructions
-        // for the ~18 % of lanes that need it -- measured: +120 us here against -100 us there)
-        const int st = ptrs_fast(ptrs_setup(lam), lam, odd ? r.z : r.x, odd ? r.w : r.y, us, V, kd);
-        float res = 0.f;
-        if (st == 0) {
-            res = (float)(long long)kd;
-        } else {
-            // the segment holds every voxel of the block (worst case: all pending), so this cannot overflow
-            const unsigned int pos = atomicAdd(a.nq, 1u);
-            PItem it;
-            it.index = idx;
-            it.out = ws->out4[owner] + comp;
-            it.v = bi.v;
-            it.attempt = st == 2 ? 0u : 1u;                 // exact test of attempt 0, or straight to a retry
-            a.seg[pos] = it;
+        float2 res = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float v = e ? pv.y : pv.x;
+            if (p1_class(v, a) == 2) {
+                const uint32_t w0 = e ? r.z : r.x, w1 = e ? r.w : r.y;
+                float k;
+#ifdef MVSIM_P1_F64
+                const double lam = (double)v * a.mul;
+                double us, V, kd;
+                const bool ok = ptrs_fast(ptrs_setup(lam), lam, w0, w1, us, V, kd) == 0;
+                k = (float)(long long)kd;
+#else
+                const bool ok = ptrs_squeeze_f32((double)v * a.mul, w0, w1, k);
+#endif
+                if (ok) {
+                    if (e) res.y = k; else res.x = k;
+                } else {
+                    // the segment holds every voxel of the block (worst case: all pending), so this cannot overflow.
+                    // (Measured: one LDS atomic per lane is cheaper here than a ballot-aggregated append.)
+                    const unsigned int pos = atomicAdd(a.nq, 1u);
+                    p1_push(a.seg + pos, idx + (unsigned long long)e, ws->out4[owner] + first + (unsigned long long)e, v, 0u, w0, w1);
+                }
+            }
         }
-        ws->outb[bi.local] = res;
+        *reinterpret_cast<float2*>(&ws->outb[4u * owner + first]) = res;
     }
     p1_wave_order();
 #pragma unroll

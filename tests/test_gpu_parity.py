@@ -379,7 +379,7 @@ def test_context_options_select_identical_variants(ctx, orc, synth, options):
     b = ctx.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
     options(fused_rotate=1, poisson_queue=0)
     c = ctx.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
-    options(fused_rotate="auto", poisson_queue=1)
+    options(fused_rotate="auto", poisson_queue=1, psf_overlap=0)      # PSF spectrum in line instead of on the side stream
     d = ctx.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
     for k in ("rot", "att", "con", "acq"):
         assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]) and np.array_equal(a[k], d[k]), k
@@ -650,7 +650,7 @@ def options(ctx):
             ctx.set_option(k, v)
     yield set_
     for k, v in (("fft_zpass", "auto"), ("fft_backend", "custom"), ("fft_pad", "auto"), ("fused_rotate", 1),
-                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial")):
+                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial"), ("psf_overlap", 1)):
         ctx.set_option(k, v)
 
 
