@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer (PCIe-inclusive) record")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the two_streams sub-record (N = 1 only)")
+    ap.add_argument("--tail-overlap", type=int, default=1, choices=(0, 1),
+                    help="option tail_overlap of the view contexts: extract + Poisson of view v beside rotate+attenuate of "
+                         "view v+1 (default 1 = the library's default; 0 = strictly serial stages, for clean per-stage times)")
     ap.add_argument("--no-size-1024", action="store_true", help="skip the 1024^3 sub-record")
     ap.add_argument("--cpu-slab", type=int, default=64, help="z extent of the CPU-baseline sample slab")
     ap.add_argument("--streams", type=int, default=1,
@@ -127,7 +130,8 @@ def load_traffic(n: int, psf: int, inc: int, streams: int, conv_method: int, ker
     return rec, None
 
 
-def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: int, conv_method: int, traffic, traffic_note):
+def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: int, conv_method: int, traffic, traffic_note,
+                    view_wall_ms: float | None = None, tail_overlap: bool = False):
     """Roofline object from per-stage HIP-event times (ms): algorithmic bytes of SURVEY.md 8d per reference stage."""
     k3 = psf_edge ** 3
     alg = {
@@ -171,6 +175,7 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
               "E k_fft_x_c2r": (cplx + 4 * nvox, stage["pass_e_ms"])}
         passes = {k: {"bytes": b, "ms": round(t, 4), "GBps": b / (t * 1e-3) / 1e9, "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
                   for k, (b, t) in pb.items() if t > 0}
+    view_ms = view_wall_ms if view_wall_ms else stage["total_ms"]
     rec = {
         "bound": "hbm", "kernel": names[dom],
         "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stages[dom]["frac"],
@@ -181,8 +186,10 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
         "hbm_measured": stages[dom].get("hbm_measured"),
         "algorithmic_bytes": alg[dom], "launch_ms": ms[dom],
         "stages": stages,
-        "whole_view": {"bytes": b_view, "ms": stage["total_ms"],
-                       "frac": b_view / (stage["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        # wall clock per view when the caller has it (with tail_overlap the stage events of consecutive views overlap, so
+        # their sum, total_ms, is no longer the time a view takes)
+        "whole_view": {"bytes": b_view, "ms": view_ms,
+                       "frac": b_view / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "convolve_noise": {"bytes": b_cn, "ms": cn_ms, "frac": b_cn / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         "passes": passes,
@@ -194,7 +201,11 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
                                  "views_profiled": traffic.get("views_profiled")}
         tv = sum(per_view.values())
         rec["whole_view"]["traffic"] = tv
-        rec["whole_view"]["hbm_measured"] = tv / (stage["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        rec["whole_view"]["hbm_measured"] = tv / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if tail_overlap:
+        rec["overlap_note"] = ("option tail_overlap: extract + Poisson of view v runs beside rotate+attenuate of view v+1, so the "
+                               "HIP-event times of THOSE two stages include each other's share of the chip (serial: bench.py "
+                               "--tail-overlap 0); the convolve stage between them -- the dominant one -- runs alone")
     return rec
 
 
@@ -241,7 +252,8 @@ def end_to_end_record(mvs, dev_index: int, gt_host: np.ndarray, psfs_raw: list, 
     return out
 
 
-def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.ndarray, inc: int, snr: float) -> dict:
+def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.ndarray, inc: int, snr: float,
+                     tail_overlap: int = 1) -> dict:
     """north_star's second size: one 1024^3 view (31^3 PSF, inc as the main run), device-resident, stage times by HIP
     events.  The ground truth is the 512^3 phantom up-sampled 2x on the device (spheres of twice the radius: the
     character of the phantom at that size, SimulateMultiViewDataset.java:436-522 scales the radii with the canvas)."""
@@ -251,6 +263,7 @@ def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.nd
     nzo = (n - 1) // inc + 1
     acq = torch.empty(n * n * nzo, dtype=torch.float32, device=dev)
     with mvs.Context(dev_index) as c:
+        c.set_option("tail_overlap", tail_overlap)
         p = c.view_params(degrees=60, inc=inc, snr=snr, seed=464232194, stream=0, conv_method=1)
         c.simulate_view_dev(g.data_ptr(), (n, n, n), psf_raw.copy(), p, acq.data_ptr())
         c.synchronize()
@@ -263,7 +276,8 @@ def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.nd
         wall = (time.perf_counter() - t0) / reps
         stage = c.timings()
         c.enable_timing(False)
-        rl = roofline_record(mvs, stage, n ** 3, n * n * nzo, n, psf_raw.shape[0], 1, None, "not profiled at this size")
+        rl = roofline_record(mvs, stage, n ** 3, n * n * nzo, n, psf_raw.shape[0], 1, None, "not profiled at this size",
+                             view_wall_ms=wall * 1e3, tail_overlap=bool(tail_overlap))
     mean_count = float(acq[: n * n].double().mean().item())
     del acq, g
     torch.cuda.empty_cache()
@@ -328,6 +342,11 @@ def main():
     # one context (own HIP stream + workspaces) per concurrent view pipeline
     ctxs = [mvs.Context(dev_index) for _ in range(max(1, args.streams))]
     ctx = ctxs[0]
+    for c in ctxs:
+        # on a caller's stream (N > 1 below) the overlap needs the explicit opt-in: nothing here reads a view's output from
+        # another stream before the final device-wide synchronisation, and the events that gate the next broadcast only
+        # protect the ground truth, which the tail does not read
+        c.set_option("tail_overlap", ("any" if world > 1 else 1) if args.tail_overlap else 0)
     view_streams = []
     bc_ctx = None
     if world > 1:
@@ -446,7 +465,7 @@ def main():
                        "volume": [n, n, n], "psf": [args.psf] * 3, "views_total": total_views,
                        "views_this_gpu": len(my_views), "inc": args.inc, "snr": args.snr,
                        "conv_method": "fft (hand-written LDS FFT passes in x and y, direct Kz-tap convolution in z; rocFFT only for unsupported sizes)" if args.conv_method == 1 else "direct stencil",
-                       "streams_per_gpu": len(ctxs),
+                       "streams_per_gpu": len(ctxs), "tail_overlap": args.tail_overlap,
                        "collective": ("none" if world == 1 else
                                       (f"mvsim_comm_broadcast_volume ({args.broadcast}, RCCL over xGMI)" if bc_ctx is not None
                                        else f"torch.distributed.broadcast ({args.backend})")
@@ -455,14 +474,15 @@ def main():
         if stage:
             kernel_sha = build.source_sha()
             traffic, note = load_traffic(n, args.psf, args.inc, len(ctxs), args.conv_method, kernel_sha)
-            out["roofline"] = roofline_record(mvs, stage, nvox, n * n * nzo, n, args.psf, args.conv_method, traffic, note)
+            wall_view = elapsed / args.steps / max(1, len(my_views)) * 1e3 if len(ctxs) == 1 else None
+            out["roofline"] = roofline_record(mvs, stage, nvox, n * n * nzo, n, args.psf, args.conv_method, traffic, note,
+                                              view_wall_ms=wall_view, tail_overlap=bool(args.tail_overlap))
             out["kernel_sha"] = kernel_sha
     if rank == 0 and world == 1 and len(ctxs) == 1 and not args.no_two_streams:
-        # the same K steps with the views alternating between two contexts (two HIP streams, two workspace sets): the
-        # drain/fill gaps between the 12 dependent kernels of one view are filled by the other view.  Reported beside
-        # `value`, which stays single-stream so that the per-kernel HIP-event durations of `roofline` are undisturbed.
-        try:
-            ctxs.append(mvs.Context(dev_index))
+        # The same K steps with stages of consecutive views overlapped -- the drain/fill gaps between the 12 dependent
+        # kernels of a view, and its latency-bound first stage, are filled by another view's work.  Reported beside
+        # `value`, which stays strictly serial so that the per-kernel HIP-event durations of `roofline` are undisturbed.
+        def timed_steps():
             for _ in range(max(1, args.warmup)):
                 step()
             sync()
@@ -471,9 +491,13 @@ def main():
                 step()
             sync()
             dt = time.perf_counter() - t0
-            out["two_streams"] = {"streams_per_gpu": 2, "ms_per_step": dt / args.steps * 1e3,
-                                  "value": total_views * args.steps / dt * nvox / 1e6, "unit": "Mvoxel/s",
-                                  "note": "views alternate between two contexts of the same GPU; same workload and timed-region rules as `value`"}
+            return {"ms_per_step": dt / args.steps * 1e3, "value": total_views * args.steps / dt * nvox / 1e6, "unit": "Mvoxel/s"}
+        try:
+            ctxs.append(mvs.Context(dev_index))
+            for c in ctxs:
+                c.set_option("tail_overlap", 0)
+            out["two_streams"] = dict(timed_steps(), streams_per_gpu=2,
+                                      note="views alternate between two contexts of the same GPU; same workload and timed-region rules as `value`")
         except Exception as e:
             out["two_streams"] = {"failed": repr(e)}
     for c in ctxs:
@@ -491,7 +515,7 @@ def main():
             try:
                 acq.clear()
                 torch.cuda.empty_cache()
-                out["size_1024"] = size_1024_record(mvs, torch, dev, dev_index, gt_bufs[0], psf_raw, args.inc, args.snr)
+                out["size_1024"] = size_1024_record(mvs, torch, dev, dev_index, gt_bufs[0], psf_raw, args.inc, args.snr, args.tail_overlap)
             except Exception as e:
                 out["size_1024"] = {"failed": repr(e)}
         if not args.no_cpu_baseline:

@@ -55,13 +55,19 @@ int  mvsim_destroy(mvsim_ctx* ctx);
  * the context's own stream. */
 int  mvsim_set_stream(mvsim_ctx* ctx, void* hip_stream);
 int  mvsim_synchronize(mvsim_ctx* ctx);
+/* Orders everything the context still has in flight on its internal streams (the extract + Poisson tail of the last
+ * device view, option "tail_overlap") in front of whatever is enqueued on its stream next; no host synchronisation.  Every
+ * entry point does this first, so only a caller that set its OWN stream (mvsim_set_stream), opted in with
+ * tail_overlap = any, and enqueues work of its own on that stream needs to call it. */
+int  mvsim_join(mvsim_ctx* ctx);
 /* Run-time switches of a context (tests and experiments; production needs none).  Defaults come from the environment
  * variables of the same meaning, read once per process: "fft_zpass" = auto|direct|fft (MVSIM_FFT_ZPASS),
  * "fft_backend" = custom|rocfft (MVSIM_FFT_BACKEND), "fft_pad" = "px,py,pz"|auto (MVSIM_FFT_PAD), "fused_rotate" = auto|1|0|2
  * (MVSIM_NO_FUSED_ROTATE; auto = fused from 131072 columns up, separate kernels for small views; 2 = the variant that
  * recomputes the row geometry in every lane), "poisson_queue" = 1|0 (MVSIM_POISSON_NOQUEUE), "early_sum" = 1|0 (MVSIM_NO_EARLY_SUM),
  * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "psf_overlap" = 1|0 (the PSF's spectrum on a side
- * stream of the context, concurrent with the image passes A and B), "fuse_tail" = 0|1 (adjust +
+ * stream of the context, concurrent with the image passes A and B), "tail_overlap" = 1|0|any (extract + Poisson of a device
+ * view concurrent with the next view's rotate+attenuate; 1 = only on the context's own stream, see mvsim_join), "fuse_tail" = 0|1 (adjust +
  * extract + Poisson phase 1 in the epilogue of the convolution's last pass), "attenuate" = serial|scan (mvsim_attenuate3d
  * as a wavefront-level prefix scan along the illumination axis: parallel in y, not bit-identical to the serial walk).
  * MVSIM_OPTIONS="name=value;name=value" sets any of them process-wide.  Unknown names or values: MVSIM_EINVAL. */

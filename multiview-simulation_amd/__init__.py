@@ -142,13 +142,18 @@ class Context:
 
     def set_option(self, name: str, value) -> None:
         """Run-time switch of this context (mvsim_set_option): fft_zpass, fft_backend, fft_pad, fused_rotate,
-        poisson_queue, early_sum, graph."""
+        poisson_queue, early_sum, graph, fuse_tail, psf_overlap, tail_overlap, attenuate, broadcast."""
         if isinstance(value, bool):
             value = "1" if value else "0"
         _lib.check(self._L.mvsim_set_option(self._h, name.encode(), str(value).encode()))
 
     def synchronize(self) -> None:
         _lib.check(self._L.mvsim_synchronize(self._h))
+
+    def join(self) -> None:
+        """mvsim_join: order the context's internal streams (the tail of the last device view) in front of whatever its
+        stream gets next; only a caller with a stream of its own and tail_overlap=any needs it."""
+        _lib.check(self._L.mvsim_join(self._h))
 
     def release_caches(self) -> None:
         _lib.check(self._L.mvsim_release_caches(self._h))

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mvsim_destroy": (C.c_int, [_vp]),
     "mvsim_set_stream": (C.c_int, [_vp, _vp]),
     "mvsim_synchronize": (C.c_int, [_vp]),
+    "mvsim_join": (C.c_int, [_vp]),
     "mvsim_set_option": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),
     "mvsim_release_caches": (C.c_int, [_vp]),
     "mvsim_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),

@@ -55,6 +55,11 @@ int parse_option(Options& o, const char* name, const char* value)
     if (n == "early_sum") return flag(&o.early_sum);
     if (n == "fuse_tail") return flag(&o.fuse_tail);
     if (n == "psf_overlap") return flag(&o.psf_overlap);
+    if (n == "tail_overlap") {
+        if (v == "0" || v == "off") o.tail_overlap = 0; else if (v == "1" || v == "on" || v == "own") o.tail_overlap = 1;
+        else if (v == "2" || v == "any") o.tail_overlap = 2; else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
     if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
     if (n == "broadcast") {
         if (v == "scatter_allgather" || v == "auto") o.bcast_ring = false; else if (v == "ring") o.bcast_ring = true; else return MVSIM_EINVAL;
@@ -229,10 +234,21 @@ static int check_dim(const int64_t dim[3])
 static int64_t nvox(const int64_t dim[3]) { return dim[0] * dim[1] * dim[2]; }
 
 
-static int set_device(mvsim_ctx* ctx)
+int join_tail(mvsim_ctx* ctx)
+{
+    if (ctx && ctx->tail_pending) {
+        MVSIM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail, 0));
+        ctx->tail_pending = false;
+    }
+    return MVSIM_OK;
+}
+
+// every entry point starts here: the device, and a pending tail ordered in front of what the call enqueues
+static int set_device(mvsim_ctx* ctx, bool keep_tail = false)
 {
     MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
     MVSIM_HIP(hipSetDevice(ctx->device));
+    if (!keep_tail) MVSIM_TRY(join_tail(ctx));
     return MVSIM_OK;
 }
 
@@ -363,6 +379,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
 {
     if (!ctx) return MVSIM_OK;
     (void)hipSetDevice(ctx->device);
+    (void)join_tail(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     mvsim_comm_destroy(ctx);
     async_release(ctx);
@@ -375,6 +392,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     if (ctx->ev_created)
         for (int k = 0; k < mvsim_ctx::TIMING_SLOTS; ++k)
             for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(ctx->evr[k][s][0]); (void)hipEventDestroy(ctx->evr[k][s][1]); }
+    if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamDestroy(ctx->tail_stream); (void)hipEventDestroy(ctx->ev_tail_fork); (void)hipEventDestroy(ctx->ev_tail); }
     if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -386,6 +404,11 @@ int mvsim_set_stream(mvsim_ctx* ctx, void* hip_stream)
     MVSIM_TRY(set_device(ctx));
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return MVSIM_OK;
+}
+
+int mvsim_join(mvsim_ctx* ctx)
+{
+    return set_device(ctx);                              // joins a pending tail; nothing else to do
 }
 
 int mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value)
@@ -653,8 +676,22 @@ int mvsim_normalize_weights(mvsim_ctx* ctx, float* const* weights, int n_views, 
 // ---- fused per-view pipeline ------------------------------------------------------------------------
 // Everything a view enqueues on the context stream behind the PSF upload: kernel launches only (no allocation once the
 // workspaces have their size, no host synchronisation) -- which is what makes it capturable into a hipGraph.
+struct StreamSwap {               // enqueue on another stream for a scope; the context's stream comes back on every exit path
+    mvsim_ctx* c;
+    hipStream_t saved;
+    StreamSwap(mvsim_ctx* ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { ctx->stream = s; }
+    ~StreamSwap() { c->stream = saved; }
+};
+
+static bool ranges_meet(const void* a, size_t abytes, const char* lo, const char* hi)
+{
+    const char* p = reinterpret_cast<const char*>(a);
+    return a && lo && p < hi && lo < p + abytes;
+}
+
+// overlap_ok: the tail (extract + Poisson) may stay pending on the tail stream when the call returns (join_tail)
 static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], const int64_t kdim[3], const mvsim_view_params* p,
-                        const mvsim_view_outputs* o)
+                        const mvsim_view_outputs* o, bool overlap_ok = false)
 {
     const int64_t n = nvox(dim);
     const size_t vbytes = (size_t)n * sizeof(float);
@@ -662,6 +699,15 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     float* att = o->att;
     float* con = o->con;
     if (!att) { MVSIM_TRY(ctx->vol_b.reserve(vbytes)); att = ctx->vol_b.as<float>(); }
+    if (ctx->tail_pending) {
+        // the previous view's tail still writes its acquisition and reads its convolved volume: this view's first stage
+        // may run beside it only if it touches neither
+        bool meet = false;
+        for (int r = 0; r < 2; ++r)
+            meet = meet || ranges_meet(gt, vbytes, ctx->tail_lo[r], ctx->tail_hi[r]) || ranges_meet(rot, vbytes, ctx->tail_lo[r], ctx->tail_hi[r]) ||
+                   ranges_meet(att, vbytes, ctx->tail_lo[r], ctx->tail_hi[r]);
+        if (meet) MVSIM_TRY(join_tail(ctx));
+    }
 
     double m[12];
     Affine inv;
@@ -672,10 +718,12 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     ev_begin(ctx, ST_ROTATE);
     MVSIM_TRY(launch_rotate_attenuate(ctx->stream, gt, rot, att, dim, inv, p->delta, ctx->opt.fused_rotate, &fused));
     if (!fused) {
+        MVSIM_TRY(join_tail(ctx));                      // the rotation scratch is the buffer a pending tail reads
         if (!rot) { MVSIM_TRY(ctx->vol_a.reserve(vbytes)); rot = ctx->vol_a.as<float>(); }
         MVSIM_TRY(launch_rotate(ctx->stream, gt, rot, dim, inv));
     }
     ev_end(ctx, ST_ROTATE);
+    MVSIM_TRY(join_tail(ctx));                          // everything below reuses the workspaces of the previous view
     if (!fused) {
         ev_begin(ctx, ST_ATTENUATE);
         MVSIM_TRY(launch_attenuate(ctx->stream, rot, att, dim, p->delta));
@@ -715,7 +763,22 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     ev_end(ctx, ST_ADJUST);
 
     void* qws = nullptr;
-    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc), nullptr))); qws = ctx->pqueue.p; }
+    const int64_t n_out = dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc);
+    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(n_out, nullptr))); qws = ctx->pqueue.p; }
+    // The tail runs on a stream of its own and is joined by whatever the context does next (join_tail): the next view's
+    // rotate+attenuate leaves most of the chip idle and runs beside it.
+    hipStream_t tail_on = ctx->stream;
+    if (overlap_ok) {
+        if (!ctx->tail_stream) {
+            MVSIM_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
+            MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_tail_fork, hipEventDisableTiming));
+            MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
+        }
+        MVSIM_HIP(hipEventRecord(ctx->ev_tail_fork, ctx->stream));
+        MVSIM_HIP(hipStreamWaitEvent(ctx->tail_stream, ctx->ev_tail_fork, 0));
+        tail_on = ctx->tail_stream;
+    }
+    StreamSwap swap(ctx, tail_on);
     ev_begin(ctx, ST_EXTRACT);
     if (tail.zstride > 1) {
         // `con` holds the acquired planes only: read them in order, count the RNG in source planes
@@ -727,7 +790,12 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
                                  mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws, ctx->opt.poisson_queue));
     }
     ev_end(ctx, ST_EXTRACT);
-
+    if (overlap_ok) {
+        MVSIM_HIP(hipEventRecord(ctx->ev_tail, ctx->tail_stream));
+        ctx->tail_pending = true;
+        ctx->tail_lo[0] = reinterpret_cast<const char*>(o->acq); ctx->tail_hi[0] = ctx->tail_lo[0] + (size_t)n_out * sizeof(float);
+        ctx->tail_lo[1] = reinterpret_cast<const char*>(con);    ctx->tail_hi[1] = ctx->tail_lo[1] + vbytes;
+    }
     return MVSIM_OK;
 }
 
@@ -820,7 +888,13 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
                             const int64_t kdim[3], const mvsim_view_params* p, const mvsim_view_outputs* o,
                             double* correction)
 {
-    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(set_device(ctx, /*keep_tail=*/true));
+    // The previous view's tail may stay in flight beside this view's first stage, and this view's tail behind the call,
+    // where nothing but this library can observe the difference: the context's own stream, no host-visible result, no graph.
+    const bool overlap = ctx->opt.tail_overlap != 0 && (ctx->opt.tail_overlap == 2 || ctx->stream == ctx->own_stream) &&
+                         !ctx->opt.graph && !correction && dim &&
+                         dim[0] > 0 && dim[1] > 0 && dim[2] > 0 && dim[0] * dim[1] * dim[2] >= ((int64_t)1 << 24);
+    if (!overlap) MVSIM_TRY(join_tail(ctx));
     MVSIM_TRY(check_dim(dim));
     MVSIM_CHECK_ARG(gt && p && o, "null pointer");
     MVSIM_CHECK_ARG(o->acq != nullptr, "outputs.acq is required");
@@ -835,7 +909,7 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     int64_t P[3];
     const bool capturable = pick_method(p->conv_method, kdim) == 2 || custom_fft_sizes(dim, kdim, P, ctx->opt);
     if (ctx->opt.graph && !ctx->timing && capturable) MVSIM_TRY(view_graph_launch(ctx, gt, dim, kdim, p, o));
-    else MVSIM_TRY(view_enqueue(ctx, gt, dim, kdim, p, o));
+    else MVSIM_TRY(view_enqueue(ctx, gt, dim, kdim, p, o, overlap));
     if (correction) {
         double *partial, *scal;
         MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
@@ -1133,6 +1207,7 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], f
     if (rc == MVSIM_OK) rc = ctx->out_buf.reserve(obytes);
     dev.acq = ctx->out_buf.as<float>();
     if (rc == MVSIM_OK) rc = mvsim_simulate_view_dev(ctx, gt_d.as<float>(), dim, psf_host, kdim, p, &dev, correction);
+    if (rc == MVSIM_OK) rc = join_tail(ctx);                  // the copies below read what the tail writes
     if (rc == MVSIM_OK && o->rot) rc = down(ctx, o->rot, dev.rot, vbytes);
     if (rc == MVSIM_OK && o->att) rc = down(ctx, o->att, dev.att, vbytes);
     if (rc == MVSIM_OK && o->con) rc = down(ctx, o->con, dev.con, vbytes);
@@ -1237,6 +1312,7 @@ int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt, uint64_t gt_gener
             if (ctx->async_inflight[q]) MVSIM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_d2h[q], 0));
     }
     int rc = mvsim_simulate_view_dev(ctx, ctx->async_gt[s].as<float>(), dim, psf_host, kdim, p, &dev, nullptr);
+    if (rc == MVSIM_OK) rc = join_tail(ctx);                  // the copies below read what the tail writes
     if (rc != MVSIM_OK) { ctx->async_gt_src[s] = nullptr; return rc; }
     {
         double *partial, *scal;
@@ -1300,6 +1376,7 @@ int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, con
     }
     mvsim_view_outputs dev = {nullptr, nullptr, nullptr, ctx->out_buf.as<float>()};
     int rc = mvsim_simulate_view_dev(ctx, ctx->host_gt.as<float>(), dim, psf_host, kdim, p, &dev, correction);
+    if (rc == MVSIM_OK) rc = join_tail(ctx);                  // the copies below read what the tail writes
     z = 0;
     for (int j = 0; j < n_acq_slabs && rc == MVSIM_OK; ++j) {
         if (hipMemcpyAsync(acq_slabs[j], dev.acq + plane * z, (size_t)(plane * acq_slab_nz[j]) * sizeof(float), hipMemcpyDeviceToHost,

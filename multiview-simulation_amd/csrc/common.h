@@ -103,6 +103,12 @@ struct Options {
                                        // resolver, production), 0: one kernel
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
     bool    psf_overlap = true;        // PSF spectrum on the context's side stream, concurrent with passes A and B
+    int     tail_overlap = 1;          // extract + Poisson of a view concurrent with the next view's rotate+attenuate (device
+                                       // views of >= 2^24 voxels; +3..6 % views/s at 512^3 -- the two stages then share the chip, so
+                                       // their own HIP-event times grow while the convolution between them is undisturbed):
+                                       // 0 off, 1 on the context's own stream only (nothing outside
+                                       // the library can observe the difference), 2 also on a caller's stream (the caller
+                                       // calls mvsim_join / any entry point before its stream touches the outputs)
     bool    fuse_tail = false;         // adjust + extract + Poisson phase 1 in the epilogue of the convolution's last pass: saves
                                        // the 8 N bytes of the convolved volume's round trip, but the merged kernel is bound by
                                        // vector issue (0.61 ms against 0.25 + 0.36 ms for pass E and the streaming Poisson kernel
@@ -168,6 +174,13 @@ struct mvsim_ctx {
     hipStream_t side_stream = nullptr;
     hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
     bool        psf_on_side = false;          // last convolution: PSF spectrum overlapped (its time is inside passes A/B)
+    // extract + Poisson of view v ("the tail") on a stream of its own, so that the next view's rotate+attenuate -- a
+    // latency-bound kernel that leaves most of the chip idle -- runs beside it.  While tail_pending, the tail's outputs are
+    // NOT yet ordered on ctx->stream: join_tail() restores that and every entry point does it first (set_device).
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t  ev_tail_fork = nullptr, ev_tail = nullptr;
+    bool        tail_pending = false;
+    const char *tail_lo[2] = {nullptr, nullptr}, *tail_hi[2] = {nullptr, nullptr};   // byte ranges the pending tail writes / reads
     mvsim::DevBuf async_gt[ASYNC_SLOTS], async_acq[ASYNC_SLOTS];
     hipEvent_t ev_h2d[ASYNC_SLOTS] = {}, ev_compute[ASYNC_SLOTS] = {}, ev_d2h[ASYNC_SLOTS] = {};
     bool       async_inflight[ASYNC_SLOTS] = {};
@@ -275,6 +288,9 @@ void fft_release(mvsim_ctx* ctx);
 void choose_padded(const int64_t dim[3], const int64_t kdim[3], int64_t P[3], const Options& opt);
 // hand-written LDS FFT path (fft_kernels.hip)
 bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3], const Options& opt);
+// orders a pending tail (extract + Poisson of the last view, on the tail stream) in front of whatever is enqueued on
+// ctx->stream next
+int  join_tail(mvsim_ctx* ctx);
 int  custom_fft_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                          const int64_t kdim[3], const int64_t P[3], float* out, ConvTail* tail);
 // z-slab form (direct z pass only): `img` holds the planes [z_in0, z_in0 + nz_in) of a volume with dim[2] planes,

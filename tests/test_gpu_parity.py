@@ -145,6 +145,22 @@ def test_poisson_counts_bit_exact_on_identical_lambda(ctx, orc, inc, stream):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("lo,hi", [(-3, 4), (1, 7), (6, 11)])
+def test_poisson_counts_bit_exact_over_the_lambda_range(ctx, orc, lo, hi):
+    """lambda log-uniform over decades (10^lo .. 10^hi): the single-precision squeeze of phase 1 (guard bands scaled with
+    sqrt(lambda); off above 1e9), the pair compaction, the inversion shortcut and the resolver against the oracle's
+    plain fp64 recipe -- identical counts, whatever the magnitude."""
+    rng = np.random.default_rng(70 + lo)
+    mul = orc.poisson_mul(25.0)
+    lam = 10.0 ** rng.uniform(lo, hi, size=(32, 64, 64))
+    v = (lam / mul).astype(np.float32)
+    v[3, :, ::7] = 0.0                                         # holes inside bright pairs / groups
+    v[5, ::3, :] = np.float32(10.0 / mul)                      # the regime boundary itself
+    got = ctx.extract_slices(v, 1, 25.0, SEED, 4)
+    want = orc.extract_slices_counter(v, 1, 25.0, SEED, 4)
+    assert np.array_equal(got, want)
+
+
 def test_poisson_process_in_place_and_offsets(ctx, orc):
     rng = np.random.default_rng(8)
     img = rng.random((40, 50), dtype=np.float32) * 2
@@ -650,7 +666,7 @@ def options(ctx):
             ctx.set_option(k, v)
     yield set_
     for k, v in (("fft_zpass", "auto"), ("fft_backend", "custom"), ("fft_pad", "auto"), ("fused_rotate", 1),
-                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial"), ("psf_overlap", 1)):
+                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial"), ("psf_overlap", 1), ("tail_overlap", 1)):
         ctx.set_option(k, v)
 
 
@@ -1136,3 +1152,65 @@ def test_hipgraph_replay_of_views(mvs, synth):
         assert corr > 0
         for d in [d_gt, d_big, d_big_acq] + d_acq:
             c.dev_free(d)
+
+
+def test_tail_overlap_keeps_stream_order_semantics(mvs, synth):
+    """Option tail_overlap (default on for device views of >= 2^24 voxels on the context's own stream): the extract +
+    Poisson tail of view v runs on a stream of its own beside the rotate+attenuate of view v+1.  Same voxels as the
+    serial order for back-to-back views into distinct and into shared outputs, for a view whose INPUT is the previous
+    view's output (the pending tail must be joined first), around a stage operator, a download and a caller's stream."""
+    n = 256
+    gt = synth.sphere_phantom(n)
+    psfs = [synth.gaussian_psf(15, sigma=(1.5, 1.7, 3.0 + 0.2 * v)) for v in range(4)]
+
+    def run(c):
+        d_gt = _dev_volume(c, gt)
+        acq = [c.dev_alloc(gt.nbytes) for _ in range(3)]
+        params = [c.view_params(degrees=15 + 45 * v, inc=1, snr=25.0, seed=SEED, stream=v, conv_method=1) for v in range(4)]
+        out = []
+        for v in range(3):                                              # distinct outputs, nothing in between
+            c.simulate_view_dev(d_gt, (n, n, n), psfs[v].copy(), params[v], acq[v])
+        out += [c.download(a, (n, n, n)) for a in acq]
+        for v in range(3):                                              # the same output three times: the last one stays
+            c.simulate_view_dev(d_gt, (n, n, n), psfs[v].copy(), params[v], acq[0])
+        out.append(c.download(acq[0], (n, n, n)))
+        c.simulate_view_dev(d_gt, (n, n, n), psfs[0].copy(), params[0], acq[1])
+        c.simulate_view_dev(acq[1], (n, n, n), psfs[1].copy(), params[1], acq[2])      # reads what the pending tail writes
+        c.rotate_around_axis_dev(acq[2], (n, n, n), 0, 30, acq[0])      # a stage operator right behind a view
+        out += [c.download(acq[2], (n, n, n)), c.download(acq[0], (n, n, n))]
+        c.simulate_view_dev(d_gt, (n, n, n), psfs[3].copy(), params[3], acq[1], att_dptr=acq[2])
+        c.simulate_view_dev(d_gt, (n, n, n), psfs[2].copy(), params[2], acq[0], att_dptr=acq[1])  # writes the pending tail's output
+        out += [c.download(acq[0], (n, n, n)), c.download(acq[1], (n, n, n))]
+        for d in [d_gt] + acq:
+            c.dev_free(d)
+        return out
+
+    with mvs.Context(0) as c:
+        c.set_option("tail_overlap", 0)
+        want = run(c)
+    with mvs.Context(0) as c:
+        c.set_option("tail_overlap", 1)
+        got = run(c)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a, b), i
+    # a caller's stream: off unless opted in; with "any", mvsim_join orders the tail in front of the caller's next work
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")                                 # the runtime libmvsim.so itself is linked against
+    stream = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+    with mvs.Context(0) as c:
+        c.set_stream(stream.value)
+        c.set_option("tail_overlap", "any")
+        d_gt = _dev_volume(c, gt)
+        acq, mine = c.dev_alloc(gt.nbytes), c.dev_alloc(gt.nbytes)
+        p = c.view_params(degrees=15, inc=1, snr=25.0, seed=SEED, stream=0, conv_method=1)
+        for _ in range(2):
+            c.simulate_view_dev(d_gt, (n, n, n), psfs[0].copy(), p, acq)
+        c.join()
+        # the caller's own work on its stream: a device-to-device copy of the acquisition (hipMemcpyDeviceToDevice = 3)
+        assert hip.hipMemcpyAsync(ctypes.c_void_p(mine), ctypes.c_void_p(acq), ctypes.c_size_t(gt.nbytes), 3, stream) == 0
+        assert hip.hipStreamSynchronize(stream) == 0
+        assert np.array_equal(c.download(mine, (n, n, n)), want[0])
+        for d in (d_gt, acq, mine):
+            c.dev_free(d)
+    assert hip.hipStreamDestroy(stream) == 0
