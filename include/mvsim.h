@@ -65,8 +65,8 @@ int  mvsim_join(mvsim_ctx* ctx);
  * "fft_backend" = custom|rocfft (MVSIM_FFT_BACKEND), "fft_pad" = "px,py,pz"|auto (MVSIM_FFT_PAD), "fused_rotate" = auto|1|0|2
  * (MVSIM_NO_FUSED_ROTATE; auto = fused from 131072 columns up, separate kernels for small views; 2 = the variant that
  * recomputes the row geometry in every lane), "poisson_queue" = 1|0 (MVSIM_POISSON_NOQUEUE), "early_sum" = 1|0 (MVSIM_NO_EARLY_SUM),
- * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "psf_overlap" = 1|0 (the PSF's spectrum on a side
- * stream of the context, concurrent with the image passes A and B), "tail_overlap" = 1|0|any (extract + Poisson of a device
+ * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "psf_overlap" = 0|1 (the PSF's spectrum on a side
+ * stream of the context, concurrent with the image passes A and B), "tail_overlap" = 0|1|any (extract + Poisson of a device
  * view concurrent with the next view's rotate+attenuate; 1 = only on the context's own stream, see mvsim_join), "fuse_tail" = 0|1 (adjust +
  * extract + Poisson phase 1 in the epilogue of the convolution's last pass), "attenuate" = serial|scan (mvsim_attenuate3d
  * as a wavefront-level prefix scan along the illumination axis: parallel in y, not bit-identical to the serial walk).

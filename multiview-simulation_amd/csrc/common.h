@@ -102,11 +102,13 @@ struct Options {
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
                                        // resolver, production), 0: one kernel
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
-    bool    psf_overlap = true;        // PSF spectrum on the context's side stream, concurrent with passes A and B
-    int     tail_overlap = 1;          // extract + Poisson of a view concurrent with the next view's rotate+attenuate (device
-                                       // views of >= 2^24 voxels; +3..6 % views/s at 512^3 -- the two stages then share the chip, so
-                                       // their own HIP-event times grow while the convolution between them is undisturbed):
-                                       // 0 off, 1 on the context's own stream only (nothing outside
+    bool    psf_overlap = false;       // PSF spectrum on the context's side stream, concurrent with passes A and B (views of
+                                       // >= 2^24 voxels; +1 % views/s at 512^3).  Opt-in like tail_overlap: overlapped kernels
+                                       // share the chip, so their own durations in a profile no longer add up to the stage time
+    int     tail_overlap = 0;          // extract + Poisson of a view concurrent with the next view's rotate+attenuate (device
+                                       // views of >= 2^24 voxels; measured +0..6 % views/s at 512^3 depending on the box -- the two
+                                       // stages then share the chip, so their own HIP-event times grow while the convolution
+                                       // between them is undisturbed): 0 off, 1 on the context's own stream only (nothing outside
                                        // the library can observe the difference), 2 also on a caller's stream (the caller
                                        // calls mvsim_join / any entry point before its stream touches the outputs)
     bool    fuse_tail = false;         // adjust + extract + Poisson phase 1 in the epilogue of the convolution's last pass: saves

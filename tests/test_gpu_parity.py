@@ -395,7 +395,7 @@ def test_context_options_select_identical_variants(ctx, orc, synth, options):
     b = ctx.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
     options(fused_rotate=1, poisson_queue=0)
     c = ctx.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
-    options(fused_rotate="auto", poisson_queue=1, psf_overlap=0)      # PSF spectrum in line instead of on the side stream
+    options(fused_rotate="auto", poisson_queue=1, psf_overlap=1)      # PSF spectrum on the side stream (taken from 2^24 voxels up)
     d = ctx.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
     for k in ("rot", "att", "con", "acq"):
         assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]) and np.array_equal(a[k], d[k]), k
@@ -666,7 +666,7 @@ def options(ctx):
             ctx.set_option(k, v)
     yield set_
     for k, v in (("fft_zpass", "auto"), ("fft_backend", "custom"), ("fft_pad", "auto"), ("fused_rotate", 1),
-                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial"), ("psf_overlap", 1), ("tail_overlap", 1)):
+                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial"), ("psf_overlap", 0), ("tail_overlap", 0)):
         ctx.set_option(k, v)
 
 
@@ -1155,7 +1155,7 @@ def test_hipgraph_replay_of_views(mvs, synth):
 
 
 def test_tail_overlap_keeps_stream_order_semantics(mvs, synth):
-    """Option tail_overlap (default on for device views of >= 2^24 voxels on the context's own stream): the extract +
+    """Option tail_overlap (opt-in; device views of >= 2^24 voxels on the context's own stream): the extract +
     Poisson tail of view v runs on a stream of its own beside the rotate+attenuate of view v+1.  Same voxels as the
     serial order for back-to-back views into distinct and into shared outputs, for a view whose INPUT is the previous
     view's output (the pending tail must be joined first), around a stage operator, a download and a caller's stream."""
@@ -1190,6 +1190,7 @@ def test_tail_overlap_keeps_stream_order_semantics(mvs, synth):
         want = run(c)
     with mvs.Context(0) as c:
         c.set_option("tail_overlap", 1)
+        c.set_option("psf_overlap", 1)
         got = run(c)
     for i, (a, b) in enumerate(zip(got, want)):
         assert np.array_equal(a, b), i

@@ -12,15 +12,10 @@ BENCH="bench.py --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-stream
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/trace -o run -- python3 $BENCH > $O/trace.log 2>&1
 python3 tools/kstats.py $O/trace 20 $O/kernel_stats.csv > $O/kernel_stats.txt
-# the same with the stages of consecutive views strictly serial (option tail_overlap off): undisturbed per-kernel durations
-# of rotate+attenuate and the two Poisson kernels
-python3 bench.py --tail-overlap 0 --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams > $O/bench_serial.json 2> $O/bench_serial.err
-rocprofv3 --kernel-trace --stats -d $O/trace_serial -o run -- python3 $BENCH --tail-overlap 0 > $O/trace_serial.log 2>&1
-python3 tools/kstats.py $O/trace_serial 20 $O/kernel_stats_serial.csv > $O/kernel_stats_serial.txt
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o run -- python3 $BENCH --steps 1 --warmup 1 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o run -- python3 $BENCH --steps 1 --warmup 1 > $O/write.log 2>&1
 python3 tools/pmc_traffic.py $O/fetch $O/write 16 --json $O/traffic.json > $O/pmc_hbm_traffic.txt
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/insts -o run -- python3 $BENCH --steps 1 --warmup 1 > $O/insts.log 2>&1
 python3 tools/pmc_insts.py $O/insts > $O/pmc_instructions.txt
-rm -rf $O/trace $O/trace_serial $O/fetch $O/write $O/insts
-cat $O/kernel_stats.txt; cat $O/kernel_stats_serial.txt; cat $O/pmc_hbm_traffic.txt; cat $O/pmc_instructions.txt
+rm -rf $O/trace $O/fetch $O/write $O/insts
+cat $O/kernel_stats.txt; cat $O/pmc_hbm_traffic.txt; cat $O/pmc_instructions.txt
