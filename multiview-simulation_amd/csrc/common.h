@@ -94,7 +94,8 @@ struct Options {
     bool    rocfft = false;            // library fallback instead of the hand-written passes
     int     fused_rotate = 3;          // rotate+attenuate as one kernel when the rotation is about x: 0 off, 1 row geometry
                                        // shared through LDS, 2 recomputed per lane (kept for A/B runs), 3 auto (production):
-                                       // 1 when the view has >= 2 waves per SIMD of columns to walk, else 0 -- one lane walks
+                                       // 1 when the view has >= 2 waves per SIMD of columns to walk or the separate rotate
+                                       // cannot use 16-byte rows (Nx % 4 != 0), else 0 -- one lane walks
                                        // one (x, z) column, so a 128^3 view is 256 waves of serial latency (measured 30 us
                                        // against 20 us for the two kernels; break-even at 256^3)
     bool    attenuate_scan = false;    // attenuate3d (stage operator) as a wavefront prefix scan along y: re-associates the

@@ -550,7 +550,12 @@ int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or
                             inv.m[4] == 0.0 && inv.m[8] == 0.0;
     // fused_mode: 0 separate kernels, 1 geometry table in LDS, 2 every lane recomputes the row geometry, 3 = 1 when the
     // columns fill the chip (>= 2 waves per SIMD), else 0
-    if (fused_mode == 3) fused_mode = ((int64_t)nx * z_count >= 131072) ? 1 : 0;
+    // (the separate rotate is only fast in its 16-byte form: Nx % 4 == 0, aligned rows; the generic one is 3x slower than
+    // the fused kernel -- the reference's own 289^3 volume: 0.38 ms against 0.10 ms)
+    if (fused_mode == 3) {
+        const bool vec4 = nx % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(att)) % 16 == 0);
+        fused_mode = ((int64_t)nx * z_count >= 131072 || !vec4) ? 1 : 0;
+    }
     *fused = x_identity && fused_mode != 0;
     if (!*fused) return MVSIM_OK;
     if (fused_mode == 1) {
