@@ -497,6 +497,8 @@ __device__ __forceinline__ void p1_push(PItem* slot, unsigned long long index, u
     q[1] = make_uint4(__float_as_uint(v), attempt, w0, w1);
 }
 
+// (MVSIM_EXP_NOPHILOX / _NOSMALLPUSH / _NOBRIGHT: instruction-attribution builds of tools/attribute_valu.sh -- each removes one
+// part of the work and with it the correctness of the counts; never defined in the product build.)
 __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, unsigned long long index4, unsigned long long out4,
                                                const P1Args& a, P1Scratch* ws, int lane, float ov[4])
 {

@@ -1,4 +1,4 @@
-# VALU instructions per wave of the Poisson kernels for experiment builds: bash tools/exp_variants.sh "<cflags 1>" "<cflags 2>" ...
+# VALU instructions per wave of the Poisson kernels for experiment builds: bash tools/attribute_valu.sh "<cflags 1>" "<cflags 2>" ...
 set -e
 for f in "$@"; do
   MVSIM_EXTRA_CFLAGS="$f" python -c "import importlib; b = importlib.import_module('multiview-simulation_amd.build'); b.build(force=True)"
@@ -12,3 +12,5 @@ for l in sys.stdin:
         s=json.loads(l)['roofline']['stage_ms']; print('   extract_ms', s['extract_ms'], 'total', s['total_ms'])
 "
 done
+# leave the product build behind, not the last experiment
+python -c "import importlib; b = importlib.import_module('multiview-simulation_amd.build'); b.build(force=True)"
