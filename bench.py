@@ -58,6 +58,10 @@ def parse_args():
     ap.add_argument("--conv-method", type=int, default=1, help="1 FFT, 2 direct stencil")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer (PCIe-inclusive) record")
+    ap.add_argument("--rehearse-multi", action="store_true",
+                    help="N = 1 only: run the data path of N > 1 on the one GPU -- two ground-truth buffers, torch-owned view and "
+                         "broadcast streams, the C ABI's RCCL communicator with one rank, one mvsim_comm_broadcast_volume per step "
+                         "issued one dataset ahead (a rehearsal of the control flow; the line it prints is not a result)")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the two_streams sub-record (N = 1 only)")
     ap.add_argument("--tail-overlap", type=int, default=0, choices=(0, 1),
                     help="options tail_overlap and psf_overlap of the view contexts for the MAIN line: extract + Poisson of view v "
@@ -313,6 +317,9 @@ def main():
     collective = args.collective
     if collective == "auto":
         collective = "mvsim" if args.backend == "nccl" else "torch"
+    multi = world > 1 or args.rehearse_multi              # the N > 1 data path (broadcast per step, double-buffered ground truth)
+    if args.rehearse_multi and world == 1:
+        collective = "mvsim"
 
     mvs = importlib.import_module("multiview-simulation_amd")
     synth = importlib.import_module("multiview-simulation_amd.synthetic")
@@ -329,7 +336,7 @@ def main():
     # synthetic inputs (rank 0 owns the ground truth; other ranks receive it by broadcast, once per step = dataset).
     # N > 1 keeps two ground-truth buffers so that the broadcast of the next dataset runs (RCCL, own stream) while
     # the views of the current one are being computed.
-    gt_bufs = [torch.empty(nvox, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    gt_bufs = [torch.empty(nvox, dtype=torch.float32, device=dev) for _ in range(2 if multi else 1)]
     gt_host = None
     if rank == 0:
         gt_host = synth.sphere_phantom(n)
@@ -348,11 +355,11 @@ def main():
         # on a caller's stream (N > 1 below) the overlap needs the explicit opt-in: nothing here reads a view's output from
         # another stream before the final device-wide synchronisation, and the events that gate the next broadcast only
         # protect the ground truth, which the tail does not read
-        c.set_option("tail_overlap", ("any" if world > 1 else 1) if args.tail_overlap else 0)
+        c.set_option("tail_overlap", ("any" if multi else 1) if args.tail_overlap else 0)
         c.set_option("psf_overlap", 1 if args.tail_overlap else 0)
     view_streams = []
     bc_ctx = None
-    if world > 1:
+    if multi:
         # the view pipelines run on torch-owned HIP streams so that torch events can order them against the
         # broadcast stream without blocking the host
         view_streams = [torch.cuda.Stream(device=dev) for _ in ctxs]
@@ -362,7 +369,8 @@ def main():
         if collective == "mvsim":
             # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed is only the messenger
             box = [mvs.Context.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
             bc_ctx = mvs.Context(dev_index)
             bc_ctx.set_stream(bc_stream.cuda_stream)
             bc_ctx.set_option("broadcast", args.broadcast)
@@ -388,7 +396,7 @@ def main():
 
     def step():
         cur = 0
-        if world > 1:
+        if multi:
             cur = step_no[0] % 2
             if args.serial_broadcast or bcast_done[cur] is None:
                 issue_broadcast(cur)                    # this dataset's ground truth (prologue / serial mode)
@@ -399,7 +407,7 @@ def main():
         gt_ptr = gt_bufs[cur].data_ptr()
         for i in range(len(my_views)):
             ctxs[i % len(ctxs)].simulate_view_dev(gt_ptr, dims, psfs[i].copy(), params[i], acq[i].data_ptr())
-        if world > 1:
+        if multi:
             views_done[cur] = []
             for vs in view_streams:
                 e = torch.cuda.Event()
@@ -452,6 +460,9 @@ def main():
     for c in ctxs:
         c.enable_timing(False)
 
+    if rank == 0 and args.rehearse_multi:
+        # the rehearsal's own check: both ground-truth buffers still hold the phantom, the views produced counts
+        assert all(torch.equal(b, gt_bufs[0]) for b in gt_bufs) and float(gt_bufs[0].max()) > 0 and float(acq[-1].max()) > 0
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         views_s = total_views * args.steps / elapsed
@@ -461,6 +472,7 @@ def main():
             "value": mvox_s, "unit": "Mvoxel/s", "views_per_s": views_s,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            **({"rehearsal": "N > 1 data path on one GPU (--rehearse-multi): a control-flow check, not a result"} if args.rehearse_multi else {}),
             "dtype": "f32 (f64 attenuation/reductions/Poisson)", "data": "synthetic",
             "config": {"workload": f"{n}^3 float volume x {total_views} views per dataset (one dataset per step), {args.psf}^3 PSF, "
                                    f"rotate+attenuate+FFT-convolve+adjust+extract(inc={args.inc})+Poisson(SNR {args.snr:g}), "
@@ -469,7 +481,7 @@ def main():
                        "views_this_gpu": len(my_views), "inc": args.inc, "snr": args.snr,
                        "conv_method": "fft (hand-written LDS FFT passes in x and y, direct Kz-tap convolution in z; rocFFT only for unsupported sizes)" if args.conv_method == 1 else "direct stencil",
                        "streams_per_gpu": len(ctxs), "tail_overlap": args.tail_overlap,
-                       "collective": ("none" if world == 1 else
+                       "collective": ("none" if not multi else
                                       (f"mvsim_comm_broadcast_volume ({args.broadcast}, RCCL over xGMI)" if bc_ctx is not None
                                        else f"torch.distributed.broadcast ({args.backend})")
                                       + ", one per step, " + ("serial" if args.serial_broadcast else "issued one dataset ahead"))},
@@ -481,7 +493,7 @@ def main():
             out["roofline"] = roofline_record(mvs, stage, nvox, n * n * nzo, n, args.psf, args.conv_method, traffic, note,
                                               view_wall_ms=wall_view, tail_overlap=bool(args.tail_overlap))
             out["kernel_sha"] = kernel_sha
-    if rank == 0 and world == 1 and len(ctxs) == 1 and not args.no_two_streams:
+    if rank == 0 and not multi and len(ctxs) == 1 and not args.no_two_streams:
         # The same K steps with stages of consecutive views overlapped -- the drain/fill gaps between the 12 dependent
         # kernels of a view, and its latency-bound first stage, are filled by another view's work.  Reported beside
         # `value`, which stays strictly serial so that the per-kernel HIP-event durations of `roofline` are undisturbed.
@@ -513,12 +525,12 @@ def main():
         bc_ctx.close()
 
     if rank == 0:
-        if world == 1 and not args.no_end_to_end:
+        if not multi and not args.no_end_to_end:
             try:
                 out["end_to_end"] = end_to_end_record(mvs, dev_index, gt_host, [psf_raw], angles, args.inc, args.snr)
             except Exception as e:  # reported extras never cost the GPU line
                 out["end_to_end"] = {"failed": repr(e)}
-        if world == 1 and not args.no_size_1024 and n == 512:
+        if not multi and not args.no_size_1024 and n == 512:
             try:
                 acq.clear()
                 torch.cuda.empty_cache()
