@@ -348,7 +348,21 @@ struct LinesArgs {
     int           outer_skip_lo, outer_skip_len;   // outer index by >= outer_skip_lo is shifted by outer_skip_len (skipped planes)
     int           store_limit;      // > 0: positions n >= store_limit are never read downstream and are not stored
     int           dst_tile_major;   // FWD: store tile (bx,by) as NL contiguous lines of L: dst[((by*gridDim.x+bx)*NL + c)*L + n]
+    // z-blocked layout of the spectrum between passes B, C' and D (0: off): position n of a line sits at
+    // (n >> ZBS) * blk + (n & (ZB - 1)) * es -- ZB rows of every plane stay together, so that the z pass, which walks the
+    // planes of ONE row, finds them ZB * Hxp elements apart instead of a whole plane apart (see line_off)
+    long long     src_blk, dst_blk;
 };
+
+#ifndef MVSIM_ZBS
+#define MVSIM_ZBS 4
+#endif
+constexpr int ZBS = MVSIM_ZBS, ZB = 1 << ZBS;        // rows per block of the z-blocked layout
+
+__device__ __forceinline__ long long line_off(int n, long long es, long long blk)
+{
+    return blk ? (long long)(n >> ZBS) * blk + (long long)(n & (ZB - 1)) * es : (long long)n * es;
+}
 
 // second launch bound: as many blocks as the LDS lets a CU hold (two, or one for the long lines) must stay resident
 // (w = blocks*T/256 waves per SIMD, rounded up) -- the register budget follows from that
@@ -384,7 +398,7 @@ void k_fft_lines(LinesArgs p)
                 const int sn = map_src(p.lmap, n);
                 if (sn >= 0) v[it] = *reinterpret_cast<const float4*>(sbase + sn * p.src_es);
             } else if (n < p.gap_lo || n >= p.gap_hi) {
-                v[it] = *reinterpret_cast<const float4*>(sbase + n * p.src_es);
+                v[it] = *reinterpret_cast<const float4*>(sbase + line_off(n, p.src_es, p.src_blk));
             }
         }
     }
@@ -428,7 +442,7 @@ void k_fft_lines(LinesArgs p)
         if (((L % ROWS == 0) || n < L) && n < nstore) {
             float2 a = buf[c2 * LP + n], b = buf[(c2 + 1) * LP + n];
             if (MODE != FWD) { a = cconj(a); b = cconj(b); }
-            *reinterpret_cast<float4*>(dbase + n * p.dst_es) = make_float4(a.x, a.y, b.x, b.y);
+            *reinterpret_cast<float4*>(dbase + line_off(n, p.dst_es, p.dst_blk)) = make_float4(a.x, a.y, b.x, b.y);
         }
     }
 }
@@ -837,10 +851,12 @@ __host__ __device__ constexpr size_t zconv_frows(int zc, int kz, int kzp)
 }
 
 struct ZConvArgs {
-    const float2* src;      // [Nz][Py][Hxp]
-    float2*       dst;      // [Nz][Py][Hxp]
+    const float2* src;      // z-blocked (see below)
+    float2*       dst;      // z-blocked
     const float2* taps;     // [Kz][Py][Hxp]
-    long long     plane;    // Hxp * Py
+    long long     plane;    // Hxp * Py: plane pitch of the taps
+    // src and dst in the z-blocked layout (LinesArgs::src_blk): element (z, ky, kx) at (ky >> ZBS) * blk + z * zs + (ky & (ZB-1)) * Hxp + kx
+    long long     src_blk, dst_blk, zs;
     int           hxp, nz, kz, c, zc;   // nz: output planes; zc: outputs per tile along z (multiple of ZU)
     // z-slab tiling: the mirror boundary acts on the GLOBAL plane index; src holds the global planes from z_in0 on,
     // dst plane 0 is global plane z_out0 (whole volume: nz_global = nz, both offsets 0)
@@ -885,7 +901,10 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     float2* f = lds;                                      // [rows][ZPITCH]
     float2* g = lds + zconv_frows(p.zc, p.kz, kzp);      // [kzp][NLZ]
     const int tid = threadIdx.x;
-    const long long col = (long long)blockIdx.z * p.hxp + (long long)blockIdx.y * NLZ;
+    const long long col = (long long)blockIdx.z * p.hxp + (long long)blockIdx.y * NLZ;     // in a plane of the taps
+    const int ky = (int)blockIdx.z;
+    const long long rowb = (long long)(ky & (ZB - 1)) * p.hxp + (long long)blockIdx.y * NLZ;
+    const long long scol = (long long)(ky >> ZBS) * p.src_blk + rowb, dcol = (long long)(ky >> ZBS) * p.dst_blk + rowb;
     const int c2 = (tid % ZLPR) * 2;                      // staging: ZLPR lanes x 16 B per row
     const int hl = p.kz - 1 - p.c;                        // halo below z = 0
     // all global loads of the tile are issued before anything waits
@@ -897,7 +916,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
         if (r >= padf && r < rows) {
             int z = p.z_out0 + zc0 + (r - padf) - hl;
             if ((unsigned)z >= (unsigned)p.nz_global) z = mirror_index(z, p.nz_global);
-            v[it] = *reinterpret_cast<const float4*>(p.src + (long long)(z - p.z_in0) * p.plane + col + c2);
+            v[it] = *reinterpret_cast<const float4*>(p.src + (long long)(z - p.z_in0) * p.zs + scol + c2);
         }
     }
 #pragma unroll
@@ -960,11 +979,11 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
                 for (int i = 0; i < ZJ; ++i) w[i] = f[max(base + i, 0) * ZPITCH + line];
             }
         }
-        float2* d = p.dst + (long long)(zc0 + z0) * p.plane + col + line;
+        float2* d = p.dst + (long long)(zc0 + z0) * p.zs + dcol + line;
 #pragma unroll
         for (int u = 0; u < ZU; ++u) {
             if (z0 + u < zn) *d = make_float2(acc[u].x, acc[u].y);
-            d += p.plane;
+            d += p.zs;
         }
         if (p.sum_partial) {
             // pairwise in single precision over the (at most) 16 outputs, then double: error ~2 roundings of fp32
@@ -1423,7 +1442,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     int tw_max = tile_y > tile_z ? tile_y : tile_z;
     if (zdirect) tw_max = tile_y > NLZ ? tile_y : NLZ;
     const int hxp = ((M + 1 + tw_max - 1) / tw_max) * tw_max;
-    const size_t cbytes = (size_t)hxp * py * (zdirect ? nzs : pz) * sizeof(float2);
+    const int pyb = (py + ZB - 1) / ZB * ZB;                        // rows of a plane in the z-blocked layout
+    const size_t cbytes = (size_t)hxp * (zdirect ? pyb : py) * (zdirect ? nzs : pz) * sizeof(float2);
     const long long rows_out_early = (long long)dim[1] * nzo;
     MVSIM_TRY(ctx->cfft_f.reserve(cbytes));
     MVSIM_TRY(ctx->cfft_g.reserve(cbytes));
@@ -1526,7 +1546,11 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         b.lmap = ident_none;
         b.gap_lo = ygap_lo; b.gap_hi = ygap_hi;
         b.outer_skip_lo = zgap_lo; b.outer_skip_len = zgap_hi > zgap_lo ? zgap_hi - zgap_lo : 0;
-        if (zdirect) { b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0; }
+        if (zdirect) {
+            // out of place into the z-blocked layout the z pass reads and writes: G[(ky >> ZBS)][z][ky & (ZB-1)][kx]
+            b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
+            b.dst = G; b.dst_outer = (long long)ZB * hxp; b.dst_blk = (long long)nzs * ZB * hxp;
+        }
         ev_begin(ctx, ST_PASS_B);
         MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
         ev_end(ctx, ST_PASS_B);
@@ -1536,7 +1560,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
         if (zdirect) {
             ZConvArgs z{};
-            z.src = F; z.dst = G; z.taps = G2; z.plane = plane; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
+            z.src = G; z.dst = F; z.taps = G2; z.plane = plane; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
+            z.zs = (long long)ZB * hxp; z.src_blk = (long long)nzs * ZB * hxp; z.dst_blk = (long long)nzo * ZB * hxp;
             z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
             z.zc = zconv_chunk(nzo, kz);
             const float scale_f = (float)(0.25 / ((double)px * (double)py));
@@ -1555,7 +1580,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
                                    corr_n, corr_min, corr_target);
                 MVSIM_HIP(hipGetLastError());
             }
-            Fz = G;
+            Fz = G;                                                   // pass D: F (z-blocked) -> G (plane-major), out of place
         } else {
         LinesArgs c{};
         c.src = F; c.dst = F; c.spec = G; c.tw = tw_pz;
@@ -1573,6 +1598,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         const int nzd = zdirect ? nzo : (int)dim[2];                  // planes z >= Nz are never read
         const int nk = (nzd - 1) / zstride + 1;                       // planes 0, zstride, 2 zstride, ...
         b.src_outer = b.dst_outer = plane * zstride;
+        b.dst_blk = 0;
+        if (zdirect) { b.src = F; b.src_outer = (long long)ZB * hxp * zstride; b.src_blk = (long long)nzo * ZB * hxp; }
         ev_begin(ctx, ST_PASS_D);
         MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, nk));
         ev_end(ctx, ST_PASS_D);
