@@ -352,6 +352,8 @@ struct LinesArgs {
     // (n >> ZBS) * blk + (n & (ZB - 1)) * es -- ZB rows of every plane stay together, so that the z pass, which walks the
     // planes of ONE row, finds them ZB * Hxp elements apart instead of a whole plane apart (see line_off)
     long long     src_blk, dst_blk;
+    int           src_mirror;       // != 0 (non-SPARSE): position n reads source position map_src(lmap, n) -- the mirrored halo rows
+                                    // of the padded image are the rows themselves, read twice instead of transformed twice
 };
 
 #ifndef MVSIM_ZBS
@@ -398,7 +400,8 @@ void k_fft_lines(LinesArgs p)
                 const int sn = map_src(p.lmap, n);
                 if (sn >= 0) v[it] = *reinterpret_cast<const float4*>(sbase + sn * p.src_es);
             } else if (n < p.gap_lo || n >= p.gap_hi) {
-                v[it] = *reinterpret_cast<const float4*>(sbase + line_off(n, p.src_es, p.src_blk));
+                const int sn = p.src_mirror ? map_src(p.lmap, n) : n;
+                v[it] = *reinterpret_cast<const float4*>(sbase + line_off(sn, p.src_es, p.src_blk));
             }
         }
     }
@@ -1534,8 +1537,13 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             *dm[d] = DimMap{n[d], Pd[d], n[d] + c, left, 0, 0};
         }
         if (zdirect) m.z = DimMap{nzs, nzs, nzs, 0, 0, 0};           // no z padding: k_zconv mirrors through an index map
+        // direct z pass: the mirrored halo rows along y are copies of rows pass A transforms anyway, so it transforms the Ny
+        // rows of a plane only and pass B reads the halo positions from their mirror images (same bytes, from L2)
+        SrcMap ma = m;
+        const bool ymirror = zdirect && m.y.n > 1 && m.y.a - m.y.n < m.y.n && m.y.b < m.y.n;   // one reflection reaches every halo row
+        if (ymirror) ma.y = DimMap{m.y.n, m.y.P, m.y.n, 0, 0, 0};
         ev_begin(ctx, ST_PASS_A);
-        MVSIM_TRY(launch_r2c(ctx, M, img, m, F, tw_m, tw_px, hxp, zdirect ? (long long)py * nzs : rows_all));
+        MVSIM_TRY(launch_r2c(ctx, M, img, ma, F, tw_m, tw_px, hxp, zdirect ? (long long)py * nzs : rows_all));
         ev_end(ctx, ST_PASS_A);
         // zero gap of the padded volume: y in [Ny + cy, Py - lefty), z in [Nz + cz, Pz - leftz).  Pass A does not
         // transform (or write) rows there, pass B skips the gap planes and does not load gap rows, pass C does
@@ -1544,6 +1552,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         LinesArgs b{};
         b.src = F; b.dst = F; b.tw = tw_py; b.src_es = b.dst_es = hxp; b.src_outer = b.dst_outer = plane;
         b.lmap = ident_none;
+        if (ymirror) { b.lmap = m.y; b.src_mirror = 1; }
         b.gap_lo = ygap_lo; b.gap_hi = ygap_hi;
         b.outer_skip_lo = zgap_lo; b.outer_skip_len = zgap_hi > zgap_lo ? zgap_hi - zgap_lo : 0;
         if (zdirect) {
@@ -1554,6 +1563,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         ev_begin(ctx, ST_PASS_B);
         MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
         ev_end(ctx, ST_PASS_B);
+        b.lmap = ident_none; b.src_mirror = 0;
         if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));    // the z pass reads the PSF spectrum
         ev_begin(ctx, ST_PASS_C);
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
