@@ -856,10 +856,9 @@ __host__ __device__ constexpr size_t zconv_frows(int zc, int kz, int kzp)
 struct ZConvArgs {
     const float2* src;      // z-blocked (see below)
     float2*       dst;      // z-blocked
-    const float2* taps;     // [Kz][Py][Hxp]
-    long long     plane;    // Hxp * Py: plane pitch of the taps
+    const float2* taps;     // z-blocked as well, Kz planes: (ky >> ZBS) * taps_blk + t * zs + (ky & (ZB-1)) * Hxp + kx
     // src and dst in the z-blocked layout (LinesArgs::src_blk): element (z, ky, kx) at (ky >> ZBS) * blk + z * zs + (ky & (ZB-1)) * Hxp + kx
-    long long     src_blk, dst_blk, zs;
+    long long     src_blk, dst_blk, taps_blk, zs;
     int           hxp, nz, kz, c, zc;   // nz: output planes; zc: outputs per tile along z (multiple of ZU)
     // z-slab tiling: the mirror boundary acts on the GLOBAL plane index; src holds the global planes from z_in0 on,
     // dst plane 0 is global plane z_out0 (whole volume: nz_global = nz, both offsets 0)
@@ -904,10 +903,10 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     float2* f = lds;                                      // [rows][ZPITCH]
     float2* g = lds + zconv_frows(p.zc, p.kz, kzp);      // [kzp][NLZ]
     const int tid = threadIdx.x;
-    const long long col = (long long)blockIdx.z * p.hxp + (long long)blockIdx.y * NLZ;     // in a plane of the taps
     const int ky = (int)blockIdx.z;
     const long long rowb = (long long)(ky & (ZB - 1)) * p.hxp + (long long)blockIdx.y * NLZ;
     const long long scol = (long long)(ky >> ZBS) * p.src_blk + rowb, dcol = (long long)(ky >> ZBS) * p.dst_blk + rowb;
+    const long long tcol = (long long)(ky >> ZBS) * p.taps_blk + rowb;
     const int c2 = (tid % ZLPR) * 2;                      // staging: ZLPR lanes x 16 B per row
     const int hl = p.kz - 1 - p.c;                        // halo below z = 0
     // all global loads of the tile are issued before anything waits
@@ -926,7 +925,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     for (int it = 0; it < TNIT; ++it) {
         const int r = (tid / ZLPR) + it * ZRPI;
         tv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < p.kz) tv[it] = *reinterpret_cast<const float4*>(p.taps + (long long)r * p.plane + col + c2);
+        if (r < p.kz) tv[it] = *reinterpret_cast<const float4*>(p.taps + (long long)r * p.zs + tcol + c2);
     }
 #pragma unroll
     for (int it = 0; it < ZNIT; ++it) {
@@ -1452,7 +1451,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     MVSIM_TRY(ctx->cfft_g.reserve(cbytes));
     // compact PSF intermediates: G1 [kz][ky][hxp] (x transformed), G2 [kz][py][hxp] (x,y transformed)
     MVSIM_TRY(ctx->cfft_g1.reserve((size_t)hxp * ky * kz * sizeof(float2)));
-    MVSIM_TRY(ctx->cfft_g2.reserve((size_t)hxp * py * kz * sizeof(float2)));
+    MVSIM_TRY(ctx->cfft_g2.reserve((size_t)hxp * pyb * kz * sizeof(float2)));
     MVSIM_TRY(ctx->partials.reserve((size_t)(SUM_BLOCKS + 8) * sizeof(double)));
     MVSIM_TRY(ctx->partials_e.reserve((size_t)((rows_out_early + 3) / 4 + 16) * sizeof(double)));
     double* scal = ctx->partials.as<double>() + SUM_BLOCKS;
@@ -1504,6 +1503,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         a.src = G1; a.dst = G2; a.spec = nullptr; a.tw = tw_py;
         a.src_es = hxp; a.src_outer = (long long)hxp * ky;          // per kz plane
         a.dst_es = hxp; a.dst_outer = plane;
+        if (zdirect) { a.dst_outer = (long long)ZB * hxp; a.dst_blk = (long long)kz * ZB * hxp; }   // the z pass reads its taps z-blocked
         a.lmap = DimMap{ky, py, ky - ky / 2, ky / 2, 1, ky / 2};
         if ((psf_rc = launch_lines(ctx, py, FWD, true, a, hxp / tile_y, kz)) != MVSIM_OK) break;
         if (!zdirect) {
@@ -1570,8 +1570,9 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
         if (zdirect) {
             ZConvArgs z{};
-            z.src = G; z.dst = F; z.taps = G2; z.plane = plane; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
+            z.src = G; z.dst = F; z.taps = G2; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
             z.zs = (long long)ZB * hxp; z.src_blk = (long long)nzs * ZB * hxp; z.dst_blk = (long long)nzo * ZB * hxp;
+            z.taps_blk = (long long)kz * ZB * hxp;
             z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
             z.zc = zconv_chunk(nzo, kz);
             const float scale_f = (float)(0.25 / ((double)px * (double)py));
