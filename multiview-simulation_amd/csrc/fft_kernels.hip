@@ -887,11 +887,12 @@ constexpr int TNIT = 64 / ZRPI;                       // kzp <= 64 rows of taps
 
 // One block per tile = (z chunk, 16-column group, row ky): grid (chunks, Hxp/16, Py) -- the chunks of a column are
 // dispatched together, so a chunk's halo rows are usually still in L2 / Infinity Cache from its neighbour.
-// (Measured and dropped: a persistent variant that prefetches the next tile into registers, and a wave-private
-// sliding-ring formulation -- one wave per column group, taps in registers, every input plane read once, no barriers:
-// 16 % fewer vector instructions and no halo re-reads, yet 0.38 ms against 0.34 ms.  The SQ counters say why: with the
-// packed FMAs at 4 cycles each the vector pipe is the co-bottleneck (about 0.2 ms of issue against a 0.23 ms byte floor),
-// and at the 3 waves per SIMD either kernel's registers allow the two do not overlap better than this.)
+// (Measured and dropped on the plane-major layout: a persistent variant that prefetches the next tile into registers, and a
+// wave-private sliding-ring formulation -- one wave per column group, taps in registers, every input plane read once, no
+// barriers: 16 % fewer vector instructions and no halo re-reads, yet 0.38 ms against 0.34 ms.  What bound all of them was
+// the distance between the rows of a tile -- a whole plane -- and not the vector pipe: with the z-blocked layout
+// (LinesArgs::src_blk) the rows of a tile are ZB * Hxp elements apart and this kernel runs in 0.32 ms; with a quarter of its
+// FMAs it would take 0.30 ms, with two instead of three blocks per CU the same 0.32 ms.)
 __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
 {
     extern __shared__ __align__(16) float2 lds[];
