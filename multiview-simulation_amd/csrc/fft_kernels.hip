@@ -450,6 +450,11 @@ void k_fft_lines(LinesArgs p)
     }
 }
 
+// 16 bytes at 8-byte alignment (two adjacent complex elements starting at an odd index): global memory takes a dwordx4 there
+struct __attribute__((packed, aligned(8))) Pair16 {
+    float a, b, c, d;
+};
+
 // ---------------------------------------------------------------------------------- x passes
 // A: rows of the (virtually) padded real volume -> half spectrum along x.  M = Px/2.
 // Each wave owns LW rows end to end (load, transform, post-process, store): no block barrier after the
@@ -563,8 +568,8 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* _
             hi[h] = cconj(csub(sm, t));                                 // element M-k (k = 0: element M)
         }
         *reinterpret_cast<float4*>(drow + 2 * q) = make_float4(lo[0].x, lo[0].y, lo[1].x, lo[1].y);
-        drow[M - 2 * q] = hi[0];
-        drow[M - 2 * q - 1] = hi[1];
+        // the mirrored pair is adjacent too (elements M-2q-1, M-2q): one 16-byte store at 8-byte alignment
+        *reinterpret_cast<Pair16*>(drow + M - 2 * q - 1) = Pair16{hi[1].x, hi[1].y, hi[0].x, hi[0].y};
     }
     // per row: the middle elements not covered by the pairs (k = M/2 when M % 4 == 0) and the zero padding up
     // to hxp; flattened over rows as well
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
             const float2* __restrict__ sp = srcc + off;
             xa[it] = *reinterpret_cast<const float4*>(sp + 2 * q);   // X[2q], X[2q+1]
             xb0[it] = sp[M - 2 * q];                                   // X[M-2q]
-            xb1[it] = sp[M - 2 * q - 1];                               // X[M-2q-1]
+            xb1[it] = sp[M - 2 * q - 1];                               // X[M-2q-1] (the compiler merges the pair into one 16-byte load)
         }
     }
 #pragma unroll
