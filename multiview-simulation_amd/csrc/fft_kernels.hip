@@ -332,6 +332,7 @@ __device__ __forceinline__ int map_src(const DimMap& m, int j)
 
 struct SrcMap {
     DimMap x, y, z;
+    int    enum_y;          // pass A: rows enumerated per plane (0: y.P); rows [enum_y, y.P) of a plane are never visited
 };
 
 // ---------------------------------------------------------------------------------- y / z pass kernel
@@ -479,17 +480,19 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* _
     const int nxs = map.x.n;
     const bool fast_x = (nxs & 3) == 0 && map.x.mode == 0;     // 16-B aligned interior loads
     // row offsets of the wave's LW rows (wave-uniform)
-    long long offs[LW];
+    long long offs[LW], drows[LW];                    // source offset (-1: zero row) and destination row of the wave's rows
 #pragma unroll
     for (int j = 0; j < LW; ++j) {
         const long long row = row0 + j;
         offs[j] = -1;
+        drows[j] = row;
         if (row < rows) {
-            const unsigned py = (unsigned)map.y.P;
+            const unsigned py = (unsigned)(map.enum_y ? map.enum_y : map.y.P);
             const unsigned urow = (unsigned)row;      // rows = Py*Pz < 2^31
             const int z = (int)(urow / py), y = (int)(urow - (unsigned)z * py);
             const int sy = map_src(map.y, y), sz = map_src(map.z, z);
             if (sy >= 0 && sz >= 0) offs[j] = (long long)nxs * (sy + (long long)map.y.n * sz);
+            drows[j] = (long long)z * map.y.P + y;
         }
     }
     // rows in the zero gap of the padded volume are never read by pass B/C (they skip the gap): if none of the
@@ -553,7 +556,10 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* _
         const int j = e / HQ, q = e - j * HQ;
         const long long row = row0 + j;
         if (row >= rows) continue;
-        float2* __restrict__ drow = dst + row * hxp;
+        long long drw = drows[0];
+#pragma unroll
+        for (int jj = 1; jj < LW; ++jj) drw = (j == jj) ? drows[jj] : drw;
+        float2* __restrict__ drow = dst + drw * hxp;
         const float2* __restrict__ zrow = wbuf + j * LP;
         float2 lo[2], hi[2];
 #pragma unroll
@@ -579,7 +585,10 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_r2c(const float* _
         const int j = e / ntail, u = e - j * ntail;
         const long long row = row0 + j;
         if (row >= rows) continue;
-        float2* __restrict__ drow = dst + row * hxp;
+        long long drw = drows[0];
+#pragma unroll
+        for (int jj = 1; jj < LW; ++jj) drw = (j == jj) ? drows[jj] : drw;
+        float2* __restrict__ drow = dst + drw * hxp;
         const float2* __restrict__ zrow = wbuf + j * LP;
         if (u < nmid) {
             const int k = 2 * HQ + u;
@@ -1500,7 +1509,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     int psf_rc = MVSIM_OK;
     ev_begin(ctx, ST_PSF);
     do {
-        SrcMap m;
+        SrcMap m{};
         m.x = DimMap{kx, px, kx - kx / 2, kx / 2, 1, kx / 2};   // embed along x with wrap-around
         m.y = DimMap{ky, ky, ky, 0, 1, 0};                       // compact: identity
         m.z = DimMap{kz, kz, kz, 0, 1, 0};
@@ -1533,7 +1542,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     // ---- image: A, B, C (with product), D, E
     ev_begin(ctx, ST_CONVOLVE);
     {
-        SrcMap m;
+        SrcMap m{};
         const int n[3] = {(int)dim[0], (int)dim[1], (int)dim[2]};
         const int Pd[3] = {px, py, pz};
         DimMap* dm[3] = {&m.x, &m.y, &m.z};
@@ -1547,9 +1556,9 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         // rows of a plane only and pass B reads the halo positions from their mirror images (same bytes, from L2)
         SrcMap ma = m;
         const bool ymirror = zdirect && m.y.n > 1 && m.y.a - m.y.n < m.y.n && m.y.b < m.y.n;   // one reflection reaches every halo row
-        if (ymirror) ma.y = DimMap{m.y.n, m.y.P, m.y.n, 0, 0, 0};
+        if (ymirror) { ma.y = DimMap{m.y.n, m.y.P, m.y.n, 0, 0, 0}; ma.enum_y = m.y.n; }   // and visits no other row
         ev_begin(ctx, ST_PASS_A);
-        MVSIM_TRY(launch_r2c(ctx, M, img, ma, F, tw_m, tw_px, hxp, zdirect ? (long long)py * nzs : rows_all));
+        MVSIM_TRY(launch_r2c(ctx, M, img, ma, F, tw_m, tw_px, hxp, zdirect ? (long long)(ymirror ? m.y.n : py) * nzs : rows_all));
         ev_end(ctx, ST_PASS_A);
         // zero gap of the padded volume: y in [Ny + cy, Py - lefty), z in [Nz + cz, Pz - leftz).  Pass A does not
         // transform (or write) rows there, pass B skips the gap planes and does not load gap rows, pass C does
