@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from .conftest import rel_to_max
+from .conftest import ROOT, rel_to_max
 
 pytestmark = pytest.mark.gpu
 
@@ -1215,3 +1215,23 @@ def test_tail_overlap_keeps_stream_order_semantics(mvs, synth):
         for d in (d_gt, acq, mine):
             c.dev_free(d)
     assert hip.hipStreamDestroy(stream) == 0
+
+
+def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
+    """bench.py --rehearse-multi: the control flow of N > 1 on the one GPU -- a second ground-truth buffer, torch-owned view
+    and broadcast streams, the C ABI's own RCCL communicator (one rank) and one mvsim_comm_broadcast_volume per step issued a
+    dataset ahead, in both broadcast forms and with the tail overlap on a caller's stream.  The line it prints is a rehearsal,
+    not a result; what is checked is that the path runs and leaves the ground truth and the acquisitions intact (the
+    script's own assertion) and that the line says which collective ran."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    for extra in (["--broadcast", "scatter_allgather"], ["--broadcast", "ring", "--tail-overlap", "1"]):
+        r = subprocess.run([sys.executable, bench, "--rehearse-multi", "--size", "256", "--psf", "15", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        assert "rehearsal" in d and d["value"] > 0 and "mvsim_comm_broadcast_volume" in d["config"]["collective"]
+        assert extra[1] in d["config"]["collective"]
