@@ -1261,3 +1261,28 @@ def test_random_geometries_against_oracle(mvs, orc, seed):
         only = c.simulate_view(gt.astype(np.float32), psf.copy(), p)
         assert only["acq"].shape == got["acq"].shape
         assert np.mean(only["acq"] != got["acq"]) < 2e-3
+
+
+def test_graph_capture_with_the_side_stream_options(mvs, synth):
+    """hipGraph replay of a view whose capture forks to the context's side stream (psf_overlap: PSF spectrum beside passes
+    A and B, joined before the z pass) -- and with tail_overlap asked for as well, which graph mode switches off: the same
+    voxels as the plain serial order, eager (first call), captured (second) and replayed (third, fourth)."""
+    n = 256
+    gt = synth.sphere_phantom(n)
+    psf = synth.gaussian_psf(15, sigma=(1.5, 1.7, 3.0))
+    outs = {}
+    for name, opts in (("plain", {}), ("graph+psf", {"graph": 1, "psf_overlap": 1}),
+                       ("graph+psf+tail", {"graph": 1, "psf_overlap": 1, "tail_overlap": 1}), ("psf+tail", {"psf_overlap": 1, "tail_overlap": 1})):
+        with mvs.Context(0) as c:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            d_gt = _dev_volume(c, gt)
+            d_acq = c.dev_alloc(gt.nbytes)
+            p = c.view_params(degrees=35, inc=1, snr=25.0, seed=SEED, stream=1, conv_method=1)
+            for _ in range(4):
+                c.simulate_view_dev(d_gt, (n, n, n), psf.copy(), p, d_acq)
+            outs[name] = c.download(d_acq, (n, n, n))
+            c.dev_free(d_gt)
+            c.dev_free(d_acq)
+    for k, v in outs.items():
+        assert np.array_equal(v, outs["plain"]), k
