@@ -386,7 +386,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     view_graphs_release(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->psf_dev.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release();
+    ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release();
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
@@ -436,7 +436,7 @@ int mvsim_release_caches(mvsim_ctx* ctx)
     view_graphs_release(ctx);                             // captured launches point into the workspaces released below
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->sphere_list.release();
+    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->sphere_list.release();
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     return MVSIM_OK;
 }

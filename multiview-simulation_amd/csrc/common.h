@@ -5,12 +5,14 @@
 #include <rocfft/rocfft.h>
 #include <roctracer/roctx.h>
 
+#include <array>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <map>
 #include <string>
 #include <unordered_set>
+#include <utility>
 #include <vector>
 
 #include "../../include/mvsim.h"
@@ -139,6 +141,7 @@ struct mvsim_ctx {
     mvsim::DevBuf vol_a, vol_b, vol_c;      // N-sized float staging for host entry points / fused path
     mvsim::DevBuf out_buf;                  // extract output staging
     mvsim::DevBuf psf_dev;                  // K^3 floats
+    mvsim::DevBuf stencil_psf;              // direct stencil: PSF reversed along x, rows zero-padded to 4 taps
     mvsim::PinnedRing pinned;
     mvsim::DevBuf fft_real;                 // P^3 floats
     mvsim::DevBuf fft_spec_img, fft_spec_psf;

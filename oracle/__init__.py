@@ -91,6 +91,7 @@ def lib():
         L.orc_adjust_image.argtypes = [_f32p, C.c_int64, C.c_float, C.c_float]
         L.orc_adjust_image.restype = C.c_double
         L.orc_convolve_direct.argtypes = [_f32p, _i64p, _f32p, _i64p, _f32p]
+        L.orc_convolve_direct_at.argtypes = [_f32p, _i64p, _f32p, _i64p, _i64p, C.c_int64, _f64p]
         L.orc_extract_nz.argtypes = [C.c_int64, C.c_int]
         L.orc_extract_nz.restype = C.c_int64
         L.orc_extract_slices_ref.argtypes = [_f32p, _i64p, C.c_int, C.c_float, C.POINTER(JRandomState), _f32p]
@@ -249,6 +250,18 @@ def convolve_direct(vol, psf: np.ndarray) -> np.ndarray:
     rc = lib().orc_convolve_direct(_p(v), _dim(v), _p(psf), _dim(psf), _p(out))
     if rc:
         raise MemoryError("convolve_direct")
+    return out
+
+
+def convolve_direct_at(vol, psf_normalised: np.ndarray, idx) -> np.ndarray:
+    """The exact (double) convolution sum at the listed flat voxel indices only; ``psf_normalised`` is used as given."""
+    v = _vol(vol)
+    assert psf_normalised.dtype == np.float32 and psf_normalised.flags.c_contiguous and psf_normalised.ndim == 3
+    ii = np.ascontiguousarray(idx, dtype=np.int64)
+    assert ii.min() >= 0 and ii.max() < v.size
+    out = np.empty(ii.size, dtype=np.float64)
+    lib().orc_convolve_direct_at(_p(v), _dim(v), _p(psf_normalised), _dim(psf_normalised),
+                                 ii.ctypes.data_as(_i64p), ii.size, out.ctypes.data_as(_f64p))
     return out
 
 

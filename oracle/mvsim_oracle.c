@@ -489,6 +489,33 @@ int orc_convolve_direct(const float* img, const int64_t dim[3], float* psf, cons
     return 0;
 }
 
+/* The same sum (SMVD:253-264 / FFTConvolution semantics: mirror-single image boundary, centre K/2, no flip) at n LISTED
+ * voxels only, psf taken AS GIVEN (already normalised by the caller): what lets a 63^3 PSF on a large volume be checked in
+ * seconds.  idx[i] = x + Nx*(y + Ny*z).  Taps are summed in the order of orc_convolve_direct (c, b, a). */
+int orc_convolve_direct_at(const float* img, const int64_t dim[3], const float* psf, const int64_t kdim[3],
+                           const int64_t* idx, int64_t n, double* out)
+{
+    const int64_t nx = dim[0], ny = dim[1], nz = dim[2];
+    const int64_t kx = kdim[0], ky = kdim[1], kz = kdim[2];
+    const int64_t cx = kx / 2, cy = ky / 2, cz = kz / 2;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t x = idx[i] % nx, y = (idx[i] / nx) % ny, z = idx[i] / (nx * ny);
+        double acc = 0.0;
+        for (int64_t c = 0; c < kz; ++c) {
+            const int64_t sz = mirror_single(z - (c - cz), nz);
+            for (int64_t b = 0; b < ky; ++b) {
+                const int64_t sy = mirror_single(y - (b - cy), ny);
+                const float* row = img + nx * (sy + ny * sz);
+                const float* krow = psf + kx * (b + ky * c);
+                for (int64_t a = 0; a < kx; ++a) acc += (double)krow[a] * (double)row[mirror_single(x - (a - cx), nx)];
+            }
+        }
+        out[i] = acc;
+    }
+    return 0;
+}
+
 /* SMVD:197 */
 int64_t orc_extract_nz(int64_t nz, int inc) { return (nz - 1) / inc + 1; }
 

@@ -74,6 +74,9 @@ double orc_adjust_image(float* img, int64_t n, float min_value, float target_ave
  *      boundary, kernel centre K/2, no flip (FFTConvolution semantics).
  *      Direct double-precision summation; normalises psf IN PLACE (SMVD:255). ---- */
 int orc_convolve_direct(const float* img, const int64_t dim[3], float* psf, const int64_t kdim[3], float* out);
+/* the same sum at n listed voxels (idx = x + Nx*(y + Ny*z)); psf as given (not normalised here); fp64 results */
+int orc_convolve_direct_at(const float* img, const int64_t dim[3], const float* psf, const int64_t kdim[3],
+                           const int64_t* idx, int64_t n, double* out);
 
 /* ---- SMVD:181-251 extractSlices / poissonProcess ----
  * mode 0: SNR<0 -> pure strided copy (noise flag ignored)

@@ -104,6 +104,51 @@ def test_convolve_phantom_gaussian_64(ctx, orc, synth):
     assert rel_to_max(got2, want) <= CONV_TOL
 
 
+@pytest.mark.parametrize("shape,kshape", [((40, 70, 50), (29, 17, 33)),      # PSF chunked in y AND z, 9 groups of 4 x taps
+                                          ((21, 30, 45), (64, 2, 11)),      # the deepest PSF the kernel takes; volume thinner than the PSF
+                                          ((18, 18, 70), (7, 64, 64))])     # 64 taps along x and y (KXP = 64: the largest instance)
+def test_stencil_chunked_psf_matches_oracle(ctx, orc, shape, kshape):
+    """The direct stencil cuts the PSF into (y, z) chunks that fit half a CU's LDS (stencil.hip: stencil_geometry); every
+    chunk boundary, the mirror halo on all faces and volumes smaller than the PSF against the exact direct sum."""
+    rng = np.random.default_rng(31)
+    v = rng.random(shape, dtype=np.float32)
+    psf = rng.random(kshape, dtype=np.float32) + 0.01
+    got = ctx.convolve(v, psf.copy(), method=2)
+    want = orc.convolve_direct(v, psf.copy())
+    assert rel_to_max(got, want) <= CONV_TOL
+
+
+def test_stencil_rejects_more_than_64_taps(ctx):
+    with pytest.raises(ValueError):
+        ctx.convolve(np.ones((8, 8, 8), np.float32), np.ones((3, 3, 65), np.float32), method=2)
+
+
+@pytest.mark.parametrize("psf_kind", ["measured_like_51", "hourglass_63"])
+def test_stencil_takes_the_psfs_the_path_uses(ctx, orc, synth, psf_kind):
+    """SimulateMultiViewDataset.java:579 loads 51^3 PSF stacks and BASELINE configs[4] names the direct stencil for a
+    measured, non-separable 63^3 PSF: method=2 on a 256 x 256 x 64 sub-volume of a sphere phantom against (a) the exact
+    fp64 direct sum of the oracle at sampled voxels -- two corner blocks, where all three mirror boundaries act, plus
+    random voxels -- and (b) the FFT path on the whole sub-volume.  Tolerance 1e-5, range-normalised."""
+    v = np.ascontiguousarray(synth.sphere_phantom(256)[96:160])
+    psf = synth.measured_like_psf(51) if psf_kind == "measured_like_51" else synth.hourglass_psf(63)
+    p2 = psf.copy()
+    got2 = ctx.convolve(v, p2, method=2)
+    got1 = ctx.convolve(v, psf.copy(), method=1)
+    scale = float(np.abs(got1).max())
+    assert scale > 0 and rel_to_max(got2, got1) <= CONV_TOL
+    nz, ny, nx = v.shape
+    zz, yy, xx = np.meshgrid(np.arange(3), np.arange(6), np.arange(40), indexing="ij")
+    corner = (xx + nx * (yy + ny * zz)).ravel()
+    far = ((nx - 1 - xx) + nx * ((ny - 1 - yy) + ny * (nz - 1 - zz))).ravel()
+    rnd = np.random.default_rng(7).integers(0, v.size, 1500)
+    bright = np.flatnonzero(got1.ravel() > 0.25 * scale)[::997][:500]
+    idx = np.unique(np.concatenate([corner, far, rnd, bright]))
+    want = orc.convolve_direct_at(v, p2, idx)            # p2 was normalised in place by the call above (Q5)
+    assert float(np.abs(want).max()) > 0.1 * scale
+    assert float(np.abs(got2.ravel()[idx] - want).max()) <= CONV_TOL * scale
+    assert float(np.abs(got1.ravel()[idx] - want).max()) <= CONV_TOL * scale
+
+
 # ------------------------------------------------------------------------------------------------ adjust / norm
 def test_adjust_and_norm_match_oracle(ctx, orc):
     rng = np.random.default_rng(5)
