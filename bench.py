@@ -14,10 +14,24 @@ views whatever N is (N = 8: one view per GPU).  The broadcast is issued one data
 ground-truth buffers on its own HIP stream, so it overlaps the views of the current dataset (`--serial-broadcast` puts it
 in front of them instead).  `--scaling weak` keeps 8 views PER GPU instead (dataset of 8 N views).
 
+Launching: `python bench.py --gpus N ...` with N > 1 and no WORLD_SIZE in the environment starts its N ranks ITSELF (one
+child process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, before this process has
+imported torch or touched a GPU; a failing child ends the run with a non-zero status).  Under torchrun /
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the environment already names the ranks and this
+process is one of them.  `--gpus` that disagrees with WORLD_SIZE is an error.
+
+`value` is measured with the library's defaults (round 3: extract + Poisson of view v beside rotate+attenuate of view v+1,
+PSF spectrum beside passes A/B -- bit-identical to the serial order); the `roofline` object comes from a SERIAL leg of the
+same K steps (both overlaps off: one kernel at a time, so HIP-event stage times are the kernels' own durations and agree
+with a rocprofv3 --kernel-trace of `bench.py --serial`).
+
 Rank 0 prints ONE JSON line (schema in the task contract) including
-  roofline     -- HBM roofline of the dominant stage: algorithmic bytes / HIP-event time, plus the PMC-measured traffic
-                  of the same stage (profiles/r02_traffic.json, valid only for the kernel sources it was measured on)
-  cpu_baseline -- the CPU oracle (restatement of the reference's ImgLib2 path) on a bounded sample
+  roofline     -- dominant stage: algorithmic bytes / HIP-event time against the 8 TB/s HBM peak, `fused_bytes` /
+                  `frac_fused` on the bytes the fused path must move, plus the PMC-measured traffic of the same stage
+                  (profiles/r03_traffic.json, valid only for the kernel sources it was measured on); with
+                  --conv-method 2 the direct stencil against the 157.3 Tflop/s fp32 vector peak (bound "fp32")
+  cpu_baseline -- the CPU oracle (C restatement of the reference's ImgLib2 path, not the JVM) on a bounded sample, two modes:
+                  as_reference (the reference's threading) and all_cores
   end_to_end   -- N = 1: the same views with page-locked HOST buffers in and out (PCIe-inclusive; never `value`)
   size_1024    -- N = 1: one 1024^3 view, same stage timings and roofline keys
 """
@@ -28,6 +42,8 @@ import ctypes as C
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,7 +54,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (same guide); the direct stencil's bound
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def parse_args():
@@ -63,13 +80,17 @@ def parse_args():
                          "broadcast streams, the C ABI's RCCL communicator with one rank, one mvsim_comm_broadcast_volume per step "
                          "issued one dataset ahead (a rehearsal of the control flow; the line it prints is not a result)")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the two_streams sub-record (N = 1 only)")
-    ap.add_argument("--tail-overlap", type=int, default=0, choices=(0, 1),
-                    help="options tail_overlap and psf_overlap of the view contexts for the MAIN line: extract + Poisson of view v "
-                         "beside rotate+attenuate of view v+1, PSF spectrum beside passes A/B (default 0 = the library's default: "
-                         "strictly serial kernels, so that per-kernel durations add up to the stage times; N = 1 reports the "
-                         "overlapped throughput in the `overlap` sub-record either way)")
+    ap.add_argument("--serial", action="store_true",
+                    help="switch the library's default overlaps (tail_overlap, psf_overlap) OFF for the main line: one kernel at a "
+                         "time, what a rocprofv3 --kernel-trace profile should be taken with (per-kernel durations then add up to "
+                         "the stage times); without it `value` uses the defaults and `roofline` comes from an extra serial leg")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="launcher / rendezvous check only: every rank joins the process group, all-reduces a 1 and rank 0 prints "
+                         "{n_gpus, ranks_seen}; no GPU, no libmvsim (what the CPU test of the self-launcher runs with --backend gloo)")
     ap.add_argument("--no-size-1024", action="store_true", help="skip the 1024^3 sub-record")
     ap.add_argument("--cpu-slab", type=int, default=64, help="z extent of the CPU-baseline sample slab")
+    ap.add_argument("--cpu-poisson-planes", type=int, default=64,
+                    help="planes of the slab the reference-exact (inter-arrival) Poisson sampler is timed on; the rest is scaled")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts/HIP streams per GPU; with 2 the views alternate between them so that the VALU-bound "
                          "Poisson kernel of one view overlaps the HBM-bound passes of the next (per-kernel durations then "
@@ -85,38 +106,133 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(gt: np.ndarray, psf_raw: np.ndarray, degrees: int, inc: int, snr: float, slab: int) -> dict:
-    """Time the CPU oracle on a bounded sample of the same workload: a centred z-slab of the volume
-    through all five stages with the reference's own threading (everything single-threaded except the
-    FFT convolution, SimulateMultiViewDataset.java:257,527) and the reference-exact inter-arrival
-    Poisson sampler on java.util.Random, the latter timed on 2 slices and scaled to the slab."""
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here.  Called before torch is imported and before
+    anything touches a GPU (the parent only waits); children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.  Rank 0's JSON
+    line reaches this process's stdout because the children inherit it.  Any child that fails ends the others (by PID)
+    and the parent exits with that child's status."""
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVSIM_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: rank {r} exited with status {code}; stopping the other ranks\n")
+                for q in alive:
+                    procs[q].terminate()
+        if alive:
+            time.sleep(0.05)
+    return rc
+
+
+def rccl_report(mvs, torch) -> dict:
+    """Which RCCL each side of this process is bound to: PyTorch ships its own librccl.so and loads it first; libmvsim.so
+    names librccl.so.1 and gets whatever copy the loader already holds under that name."""
+    mapped = []
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "librccl" in line:
+                    path = line.split()[-1]
+                    if path not in mapped:
+                        mapped.append(path)
+    except OSError:
+        pass
+    rep = {"mapped": mapped}
+    try:
+        rep["libmvsim"] = mvs.Context.comm_library_info()
+    except Exception as e:
+        rep["libmvsim"] = {"failed": repr(e)}
+    try:
+        v = torch.cuda.nccl.version()
+        rep["torch"] = {"version": ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)}
+    except Exception as e:
+        rep["torch"] = {"failed": repr(e)}
+    return rep
+
+
+def cpu_baseline(gt: np.ndarray, psf_raw: np.ndarray, degrees: int, inc: int, snr: float, slab: int, poisson_planes: int) -> dict:
+    """Time the CPU oracle -- a C restatement of the reference's ImgLib2 path, NOT the JVM (no JDK in the image) -- on a
+    bounded sample of the same workload: a centred z-slab of the volume through all five stages, in two modes.
+      as_reference: the reference's own threading -- everything a single-threaded cursor loop except the FFT convolution
+                    (SimulateMultiViewDataset.java:257,527) -- and the reference-exact inter-arrival Poisson sampler on
+                    java.util.Random (uncommons/PoissonGenerator.java:95-109), timed on `poisson_planes` planes of the slab
+      all_cores:    OpenMP over planes / columns in rotate, attenuate, adjust; the counter-based sampler (the GPU's own
+                    specification) over all cores; the same scipy float32 FFT convolution
+    `value` is mode as_reference (what a user of the reference gets on this host)."""
     import oracle
     nz = gt.shape[0]
     slab = min(slab, nz)
     z0 = (nz - slab) // 2
     sub = np.ascontiguousarray(gt[z0:z0 + slab])
-    t = {}
-    t0 = time.perf_counter(); rot = oracle.rotate_around_axis(sub, 0, degrees); t["rotate"] = time.perf_counter() - t0
-    t0 = time.perf_counter(); att = oracle.attenuate3d(rot, float(np.float32(0.01))); t["attenuate"] = time.perf_counter() - t0
-    psf = psf_raw.copy()
-    t0 = time.perf_counter(); con = oracle.convolve_fft(att, psf, workers=-1); t["convolve_fft"] = time.perf_counter() - t0
-    t0 = time.perf_counter(); oracle.adjust_image(con, 1e-4, 1.0); t["adjust"] = time.perf_counter() - t0
-    nsl = min(2, con.shape[0])
-    t0 = time.perf_counter()
-    oracle.extract_slices_ref(con[:nsl], 1, snr, oracle.JRandom(464232194))
-    n_extract = (slab - 1) // inc + 1
-    t["extract_poisson"] = (time.perf_counter() - t0) * (n_extract / nsl)
-    total = sum(t.values())
     vox = sub.size
-    return {
-        "value": vox / total / 1e6, "unit": "Mvoxel/s", "cores": os.cpu_count(), "kind": "port",
-        # the reference's own threading: only FFTConvolution gets the executor service (SMVD:257,527), every other
-        # stage -- the Poisson loop that dominates included -- is a single-threaded cursor loop
-        "threads": {"convolve_fft": os.cpu_count(), "rotate": 1, "attenuate": 1, "adjust": 1, "extract_poisson": 1},
-        "sample": (f"{sub.shape[2]}x{sub.shape[1]}x{slab} z-slab of the same view, {psf_raw.shape[0]}^3 PSF; "
-                   f"single-threaded C restatement except scipy float32 FFT convolution on all cores; "
-                   f"reference-exact Poisson timed on {nsl} slices and scaled to {n_extract}"),
+    n_extract = (slab - 1) // inc + 1
+    cores = os.cpu_count()
+    delta = float(np.float32(0.01))
+
+    def stages(parallel: bool):
+        oracle.set_parallel(parallel)
+        try:
+            t = {}
+            t0 = time.perf_counter(); rot = oracle.rotate_around_axis(sub, 0, degrees); t["rotate"] = time.perf_counter() - t0
+            t0 = time.perf_counter(); att = oracle.attenuate3d(rot, delta); t["attenuate"] = time.perf_counter() - t0
+            psf = psf_raw.copy()
+            t0 = time.perf_counter(); con = oracle.convolve_fft(att, psf, workers=-1); t["convolve_fft"] = time.perf_counter() - t0
+            t0 = time.perf_counter(); oracle.adjust_image(con, 1e-4, 1.0); t["adjust"] = time.perf_counter() - t0
+            return t, con
+        finally:
+            oracle.set_parallel(False)
+
+    modes = {}
+    t, con = stages(False)
+    nsl = max(1, min(poisson_planes, n_extract))
+    t0 = time.perf_counter()
+    oracle.extract_slices_ref(con[: (nsl - 1) * inc + 1], inc, snr, oracle.JRandom(464232194))
+    measured = time.perf_counter() - t0
+    t["extract_poisson"] = measured * (n_extract / nsl)
+    total = sum(t.values())
+    modes["as_reference"] = {
+        "value": vox / total / 1e6, "unit": "Mvoxel/s",
+        "threads": {"convolve_fft": cores, "rotate": 1, "attenuate": 1, "adjust": 1, "extract_poisson": 1},
+        "sampler": "reference-exact inter-arrival sampler on java.util.Random",
         "seconds": {k: round(v, 3) for k, v in t.items()},
+        "poisson_planes_timed": nsl, "poisson_planes_total": n_extract,
+        "extrapolated_fraction_of_seconds": round((t["extract_poisson"] - measured) / total, 4),
+    }
+    t2, con2 = stages(True)
+    t0 = time.perf_counter()
+    oracle.extract_slices_counter(con2, inc, snr, 464232194, 0)
+    t2["extract_poisson"] = time.perf_counter() - t0
+    total2 = sum(t2.values())
+    omp = oracle.max_threads()
+    modes["all_cores"] = {
+        "value": vox / total2 / 1e6, "unit": "Mvoxel/s",
+        "threads": {"convolve_fft": cores, "rotate": omp, "attenuate": omp, "adjust": omp, "extract_poisson": omp},
+        "sampler": "counter-based sampler (Philox + inversion / PTRS: the GPU path's own specification)",
+        "seconds": {k: round(v, 3) for k, v in t2.items()},
+        "extrapolated_fraction_of_seconds": 0.0,
+    }
+    return {
+        "value": modes["as_reference"]["value"], "unit": "Mvoxel/s", "cores": cores, "kind": "port",
+        "what": "C restatement of the reference's ImgLib2 path (oracle/), not the JVM; value = mode as_reference",
+        "sample": (f"{sub.shape[2]}x{sub.shape[1]}x{slab} z-slab of the same view, {psf_raw.shape[0]}^3 PSF, all five stages; "
+                   f"scipy float32 FFT convolution on all cores in both modes; reference-exact Poisson timed on {nsl} of "
+                   f"{n_extract} planes"),
+        "modes": modes,
     }
 
 
@@ -137,14 +253,20 @@ def load_traffic(n: int, psf: int, inc: int, streams: int, conv_method: int, ker
 
 
 def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: int, conv_method: int, traffic, traffic_note,
-                    view_wall_ms: float | None = None, tail_overlap: bool = False):
-    """Roofline object from per-stage HIP-event times (ms): algorithmic bytes of SURVEY.md 8d per reference stage."""
+                    view_wall_ms: float | None = None, overlapped: bool = False):
+    """Roofline object from per-stage HIP-event times (ms).  Two byte models, never blended:
+      algorithmic_bytes / frac       -- SURVEY.md 8(d): every REFERENCE stage reads its input once and writes its output once
+                                        (rotate 8N + attenuate 8N; convolve 8N + 4K^3; extract + Poisson 8N'; view 24N + 8N')
+      fused_bytes / frac_fused       -- what the fused path must move: rotate+attenuate is ONE kernel whose `rot` never
+                                        exists in HBM (8N), so a view is 16N + 8N' (+ 4K^3); this fraction cannot exceed 1
+    With conv_method 2 the convolve stage is the direct stencil: 2 K^3 N flop against the fp32 vector peak."""
     k3 = psf_edge ** 3
     alg = {
-        "rotate_attenuate": 16 * nvox,               # rotate 8N + attenuate 8N (one fused kernel)
-        "convolve": 8 * nvox + 4 * k3,               # + PSF spectrum
+        "rotate_attenuate": 16 * nvox,               # rotate 8N + attenuate 8N (two reference stages)
+        "convolve": 8 * nvox + 4 * k3,               # + PSF
         "extract_poisson": 8 * nprime,
     }
+    fused = {"rotate_attenuate": 8 * nvox, "convolve": 8 * nvox + 4 * k3, "extract_poisson": 8 * nprime}
     ms = {
         "rotate_attenuate": stage["rotate_ms"] + stage["attenuate_ms"],
         "convolve": stage["psf_ms"] + stage["convolve_ms"] + stage["adjust_ms"],
@@ -154,20 +276,22 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
     stages = {}
     for k in alg:
         gbps = alg[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0
-        stages[k] = {"algorithmic_bytes": alg[k], "ms": round(ms[k], 4), "GBps": gbps, "frac": gbps / HBM_PEAK_GBS}
+        fg = fused[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0
+        stages[k] = {"algorithmic_bytes": alg[k], "ms": round(ms[k], 4), "GBps": gbps, "frac": gbps / HBM_PEAK_GBS,
+                     "fused_bytes": fused[k], "frac_fused": fg / HBM_PEAK_GBS}
         if k in per_view and ms[k] > 0:
             stages[k]["traffic"] = per_view[k]
             stages[k]["hbm_measured"] = per_view[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
     dom = max(ms, key=ms.get)
-    b_view = 24 * nvox + 8 * nprime
+    b_view, b_view_fused = 24 * nvox + 8 * nprime, 16 * nvox + 8 * nprime + 4 * k3
     b_cn = 8 * nvox + 8 * nprime
     cn_ms = ms["convolve"] + ms["extract_poisson"]
     names = {
         "convolve": "convolve stage: PSF (x,y) spectrum (k_fft_x_r2c, k_fft_lines<FWD,sparse>), k_fft_x_r2c, k_fft_lines<FWD>, "
                     "k_zconv (direct z convolution), k_fft_lines<INV>, k_fft_x_c2r (+ adjust/Poisson epilogue when fused), "
                     "k_reduce_partials",
-        "extract_poisson": "extract stage: k_extract4_noise + k_poisson_resolve",
-        "rotate_attenuate": "k_rotate_attenuate_axis0",
+        "extract_poisson": "extract stage: k_extract4_noise2 + k_poisson_resolve",
+        "rotate_attenuate": "k_rotate_attenuate_axis0_lds",
     }
     passes = None
     geo = (C.c_int64 * 5)()
@@ -182,24 +306,41 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
         passes = {k: {"bytes": b, "ms": round(t, 4), "GBps": b / (t * 1e-3) / 1e9, "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
                   for k, (b, t) in pb.items() if t > 0}
     view_ms = view_wall_ms if view_wall_ms else stage["total_ms"]
-    rec = {
-        "bound": "hbm", "kernel": names[dom],
-        "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stages[dom]["frac"],
-        # HBM bytes of the dominant stage per view from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE,
-        # separate passes of this same command (profiles/r02_traffic.json); null when that record does not describe
-        # this build / workload
-        "traffic": stages[dom].get("traffic"),
-        "hbm_measured": stages[dom].get("hbm_measured"),
-        "algorithmic_bytes": alg[dom], "launch_ms": ms[dom],
+    if conv_method == 2:
+        flop = 2.0 * k3 * nvox
+        tf = flop / (ms["convolve"] * 1e-3) / 1e12 if ms["convolve"] > 0 else 0.0
+        sg = (C.c_int64 * 5)()
+        chunk = None
+        if mvs._lib.load().mvsim_stencil_geometry((C.c_int64 * 3)(psf_edge, psf_edge, psf_edge), sg) == 0:
+            chunk = {"psf_chunk_taps": [int(sg[0]), int(sg[1]), int(sg[2])], "lds_bytes_per_block": int(sg[3]), "blocks_per_cu": int(sg[4])}
+        head = {"bound": "fp32", "kernel": "k_stencil_pair (LDS-tiled direct 3-D convolution, packed fp32 FMAs)",
+                "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
+                "flop": flop, "flop_model": "2 * K^3 * N per view (useful taps only; the zero taps that pad a PSF row chunk are not counted)",
+                "launch_ms": ms["convolve"], "stencil_geometry": chunk}
+    else:
+        head = {"bound": "hbm", "kernel": names[dom],
+                "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stages[dom]["frac"],
+                "fused_bytes": fused[dom], "frac_fused": stages[dom]["frac_fused"],
+                # HBM bytes of the dominant stage per view from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE,
+                # separate passes of `bench.py --serial` (profiles/r03_traffic.json); null when that record does not describe
+                # this build / workload
+                "traffic": stages[dom].get("traffic"),
+                "hbm_measured": stages[dom].get("hbm_measured"),
+                "algorithmic_bytes": alg[dom], "launch_ms": ms[dom]}
+    rec = dict(head)
+    rec.update({
         "stages": stages,
-        # wall clock per view when the caller has it (with tail_overlap the stage events of consecutive views overlap, so
+        # wall clock per view when the caller has it (with the overlaps on, the stage events of consecutive views overlap, so
         # their sum, total_ms, is no longer the time a view takes)
-        "whole_view": {"bytes": b_view, "ms": view_ms,
-                       "frac": b_view / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "whole_view": {"bytes": b_view, "ms": view_ms, "frac": b_view / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "fused_bytes": b_view_fused, "frac_fused": b_view_fused / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "convolve_noise": {"bytes": b_cn, "ms": cn_ms, "frac": b_cn / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         "passes": passes,
-    }
+        "timed": ("overlapped views (library defaults): the stage times of rotate+attenuate and extract+Poisson include each other's "
+                  "share of the chip" if overlapped else
+                  "serial leg: tail_overlap = psf_overlap = 0, one kernel at a time on one stream (HIP events on that stream)"),
+    })
     if traffic is None:
         rec["traffic_note"] = traffic_note
     else:
@@ -208,10 +349,6 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
         tv = sum(per_view.values())
         rec["whole_view"]["traffic"] = tv
         rec["whole_view"]["hbm_measured"] = tv / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-    if tail_overlap:
-        rec["overlap_note"] = ("option tail_overlap: extract + Poisson of view v runs beside rotate+attenuate of view v+1, so the "
-                               "HIP-event times of THOSE two stages include each other's share of the chip (serial: bench.py "
-                               "--tail-overlap 0); the convolve stage between them -- the dominant one -- runs alone")
     return rec
 
 
@@ -258,47 +395,81 @@ def end_to_end_record(mvs, dev_index: int, gt_host: np.ndarray, psfs_raw: list, 
     return out
 
 
-def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.ndarray, inc: int, snr: float,
-                     tail_overlap: int = 1) -> dict:
-    """north_star's second size: one 1024^3 view (31^3 PSF, inc as the main run), device-resident, stage times by HIP
-    events.  The ground truth is the 512^3 phantom up-sampled 2x on the device (spheres of twice the radius: the
-    character of the phantom at that size, SimulateMultiViewDataset.java:436-522 scales the radii with the canvas)."""
+def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.ndarray, inc: int, snr: float) -> dict:
+    """north_star's second size: one 1024^3 view (31^3 PSF, inc as the main run), device-resident.  `value` with the library
+    defaults (three back-to-back views), stage times by HIP events from a serial leg.  The ground truth is the 512^3
+    phantom up-sampled 2x on the device (spheres of twice the radius: the character of the phantom at that size,
+    SimulateMultiViewDataset.java:436-522 scales the radii with the canvas)."""
     n = 1024
     g = gt_dev_512.view(512, 512, 512)
     g = g.repeat_interleave(2, dim=0).repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous().view(-1)
     nzo = (n - 1) // inc + 1
     acq = torch.empty(n * n * nzo, dtype=torch.float32, device=dev)
     with mvs.Context(dev_index) as c:
-        c.set_option("tail_overlap", tail_overlap)
         p = c.view_params(degrees=60, inc=inc, snr=snr, seed=464232194, stream=0, conv_method=1)
         c.simulate_view_dev(g.data_ptr(), (n, n, n), psf_raw.copy(), p, acq.data_ptr())
         c.synchronize()
-        c.enable_timing(True)
         reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            c.simulate_view_dev(g.data_ptr(), (n, n, n), psf_raw.copy(), p, acq.data_ptr())
-        c.synchronize()
-        wall = (time.perf_counter() - t0) / reps
+
+        def run():
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                c.simulate_view_dev(g.data_ptr(), (n, n, n), psf_raw.copy(), p, acq.data_ptr())
+            c.synchronize()
+            return (time.perf_counter() - t0) / reps
+        wall = run()
+        c.set_option("tail_overlap", 0)
+        c.set_option("psf_overlap", 0)
+        c.enable_timing(True)
+        wall_serial = run()
         stage = c.timings()
         c.enable_timing(False)
         rl = roofline_record(mvs, stage, n ** 3, n * n * nzo, n, psf_raw.shape[0], 1, None, "not profiled at this size",
-                             view_wall_ms=wall * 1e3, tail_overlap=bool(tail_overlap))
+                             view_wall_ms=wall_serial * 1e3)
     mean_count = float(acq[: n * n].double().mean().item())
     del acq, g
     torch.cuda.empty_cache()
     return {"workload": f"1024^3 float volume, 1 view, {psf_raw.shape[0]}^3 PSF, inc={inc}, SNR {snr:g}, device-resident",
             "views": reps, "ms_per_view": wall * 1e3, "value": n ** 3 / wall / 1e6, "unit": "Mvoxel/s",
+            "serial": {"ms_per_view": wall_serial * 1e3, "value": n ** 3 / wall_serial / 1e6},
             "first_plane_mean_count": mean_count, "roofline": rl}
+
+
+def dry_run_launch(args, world: int, rank: int) -> None:
+    """Launcher / rendezvous check: no GPU, no libmvsim (tests/test_host_logic.py runs it with --backend gloo)."""
+    import torch
+    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend if args.backend != "nccl" or torch.cuda.is_available() else "gloo",
+                                rank=rank, world_size=world)
+        t = torch.ones(1)
+        if dist.get_backend() == "nccl":
+            t = t.cuda(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run_launch": True, "n_gpus": world, "ranks_seen": seen, "backend": args.backend,
+                          "self_launched": os.environ.get("MVSIM_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one.  Nothing in this process has imported torch or touched a GPU yet.
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (self-launching) "
+                         f"or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    if args.dry_run_launch:
+        return dry_run_launch(args, world, rank)
 
     import torch
     import torch.distributed as dist
@@ -333,6 +504,16 @@ def main():
     angles = [15 + (360 * v) // total_views for v in range(total_views)]      # 8 views: 45-degree steps (configs[2])
     nzo = (n - 1) // args.inc + 1
 
+    # every rank really is there: one all-reduce of a 1 through torch.distributed, and (below) one through the C ABI's own
+    # communicator
+    ranks_seen = {"torch": 1}
+    if world > 1:
+        t = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        ranks_seen["torch"] = int(t.item())
+        if ranks_seen["torch"] != world:
+            raise SystemExit(f"rank {rank}: all-reduce of 1 over the process group gave {ranks_seen['torch']}, expected {world}")
+
     # synthetic inputs (rank 0 owns the ground truth; other ranks receive it by broadcast, once per step = dataset).
     # N > 1 keeps two ground-truth buffers so that the broadcast of the next dataset runs (RCCL, own stream) while
     # the views of the current one are being computed.
@@ -351,12 +532,15 @@ def main():
     # one context (own HIP stream + workspaces) per concurrent view pipeline
     ctxs = [mvs.Context(dev_index) for _ in range(max(1, args.streams))]
     ctx = ctxs[0]
-    for c in ctxs:
-        # on a caller's stream (N > 1 below) the overlap needs the explicit opt-in: nothing here reads a view's output from
-        # another stream before the final device-wide synchronisation, and the events that gate the next broadcast only
-        # protect the ground truth, which the tail does not read
-        c.set_option("tail_overlap", ("any" if multi else 1) if args.tail_overlap else 0)
-        c.set_option("psf_overlap", 1 if args.tail_overlap else 0)
+
+    def set_overlap(on: bool):
+        for c in ctxs:
+            # on a caller's stream (N > 1 below) the tail overlap needs the explicit opt-in ("any"): nothing here reads a view's
+            # output from another stream before the final device-wide synchronisation, and the events that gate the next
+            # broadcast only protect the ground truth, which the tail does not read
+            c.set_option("tail_overlap", ("any" if multi else 1) if on else 0)
+            c.set_option("psf_overlap", 1 if on else 0)
+    set_overlap(not args.serial)
     view_streams = []
     bc_ctx = None
     if multi:
@@ -375,6 +559,13 @@ def main():
             bc_ctx.set_stream(bc_stream.cuda_stream)
             bc_ctx.set_option("broadcast", args.broadcast)
             bc_ctx.comm_init(world, rank, box[0])
+            one = torch.ones(16, dtype=torch.float32, device=dev)
+            with torch.cuda.stream(bc_stream):
+                bc_ctx.comm_allreduce_sum(one.data_ptr(), 16)
+            bc_stream.synchronize()
+            ranks_seen["mvsim_comm"] = int(one[0].item())
+            if ranks_seen["mvsim_comm"] != world:
+                raise SystemExit(f"rank {rank}: all-reduce of 1 over the C ABI's communicator gave {ranks_seen['mvsim_comm']}, expected {world}")
     views_done = [[], []]      # per ground-truth buffer: events after the last views that read it
     bcast_done = [None, None]  # per ground-truth buffer: event after the broadcast that filled it
     step_no = [0]
@@ -436,10 +627,11 @@ def main():
             if not torch.equal(lo, hi) or float(hi[1]) == 0.0:
                 raise SystemExit(f"rank {rank}: ground-truth buffer {b_i} differs between ranks after the broadcast")
         sync()
-    # per-stage HIP events are recorded inside the timed region, on the stream each view runs on (one event set
-    # per view; read once after the final sync): the stage durations include whatever overlap the streams produce
-    for c in ctxs:
-        c.enable_timing(True)
+    # ---- the timed region: exactly K steps between two barrier + synchronise pairs; MAX over ranks below
+    timed_with_events = args.serial or multi      # serial main line: its stage events ARE the roofline's source
+    if timed_with_events:
+        for c in ctxs:
+            c.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -450,15 +642,40 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    stage = None
-    if rank == 0 and my_views:
+    def read_stage():
         acc = {}
         for c in ctxs:
             for k, v in c.timings().items():
                 acc[k] = acc.get(k, 0.0) + v / len(ctxs)
-        stage = acc
-    for c in ctxs:
-        c.enable_timing(False)
+        return acc
+    stage = None
+    stage_overlapped = not args.serial
+    if timed_with_events:
+        if rank == 0 and my_views:
+            stage = read_stage()
+        for c in ctxs:
+            c.enable_timing(False)
+
+    serial_leg = None
+    if rank == 0 and not multi and not args.serial and my_views:
+        # the roofline's source: the same K steps with both overlaps off -- one kernel at a time on the context's stream, HIP
+        # events around every stage (on that stream), so that stage times are the kernels' own durations
+        set_overlap(False)
+        step(); sync()
+        for c in ctxs:
+            c.enable_timing(True)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt = time.perf_counter() - t1
+        stage = read_stage()
+        stage_overlapped = False
+        for c in ctxs:
+            c.enable_timing(False)
+        serial_leg = {"ms_per_step": dt / args.steps * 1e3, "value": total_views * args.steps / dt * nvox / 1e6, "unit": "Mvoxel/s",
+                      "note": "options tail_overlap = psf_overlap = 0 (kernels strictly one at a time): the leg `roofline` is read from"}
+        set_overlap(True)
 
     if rank == 0 and args.rehearse_multi:
         # the rehearsal's own check: both ground-truth buffers still hold the phantom, the views produced counts
@@ -467,6 +684,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         views_s = total_views * args.steps / elapsed
         mvox_s = views_s * nvox / 1e6
+        conv_name = ("fft (hand-written LDS FFT passes in x and y, direct Kz-tap convolution in z; rocFFT only for unsupported sizes)"
+                     if args.conv_method == 1 else "direct LDS-tiled stencil (fp32-FMA-bound)" if args.conv_method == 2 else "auto")
         out = {
             "metric": "simulated Mvoxel/s (views x input voxels / s), 512^3 volume x 8 views",
             "value": mvox_s, "unit": "Mvoxel/s", "views_per_s": views_s,
@@ -475,28 +694,36 @@ def main():
             **({"rehearsal": "N > 1 data path on one GPU (--rehearse-multi): a control-flow check, not a result"} if args.rehearse_multi else {}),
             "dtype": "f32 (f64 attenuation/reductions/Poisson)", "data": "synthetic",
             "config": {"workload": f"{n}^3 float volume x {total_views} views per dataset (one dataset per step), {args.psf}^3 PSF, "
-                                   f"rotate+attenuate+FFT-convolve+adjust+extract(inc={args.inc})+Poisson(SNR {args.snr:g}), "
+                                   f"rotate+attenuate+convolve+adjust+extract(inc={args.inc})+Poisson(SNR {args.snr:g}), "
                                    f"device-resident; BASELINE configs[1] per view, configs[2] sharding (view v on GPU v % N)",
                        "volume": [n, n, n], "psf": [args.psf] * 3, "views_total": total_views,
                        "views_this_gpu": len(my_views), "inc": args.inc, "snr": args.snr,
-                       "conv_method": "fft (hand-written LDS FFT passes in x and y, direct Kz-tap convolution in z; rocFFT only for unsupported sizes)" if args.conv_method == 1 else "direct stencil",
-                       "streams_per_gpu": len(ctxs), "tail_overlap": args.tail_overlap,
+                       "conv_method": conv_name,
+                       "streams_per_gpu": len(ctxs),
+                       "overlap": ("off (--serial)" if args.serial else
+                                   "library defaults: tail_overlap (extract + Poisson of view v beside rotate+attenuate of view v+1) + "
+                                   "psf_overlap (PSF spectrum beside passes A/B); bit-identical to the serial order"),
+                       "launcher": ("self-launched by bench.py (one child process per rank)" if os.environ.get("MVSIM_BENCH_SELF_LAUNCHED") == "1"
+                                    else "external launcher (torchrun)" if world > 1 else "single process"),
+                       "ranks_seen": ranks_seen,
+                       "rccl": rccl_report(mvs, torch),
                        "collective": ("none" if not multi else
                                       (f"mvsim_comm_broadcast_volume ({args.broadcast}, RCCL over xGMI)" if bc_ctx is not None
                                        else f"torch.distributed.broadcast ({args.backend})")
                                       + ", one per step, " + ("serial" if args.serial_broadcast else "issued one dataset ahead"))},
         }
+        if serial_leg:
+            out["serial"] = serial_leg
         if stage:
             kernel_sha = build.source_sha()
             traffic, note = load_traffic(n, args.psf, args.inc, len(ctxs), args.conv_method, kernel_sha)
-            wall_view = elapsed / args.steps / max(1, len(my_views)) * 1e3 if len(ctxs) == 1 else None
+            wall_ms = (serial_leg["ms_per_step"] if serial_leg else ms_per_step)
+            wall_view = wall_ms / max(1, len(my_views)) if len(ctxs) == 1 else None
             out["roofline"] = roofline_record(mvs, stage, nvox, n * n * nzo, n, args.psf, args.conv_method, traffic, note,
-                                              view_wall_ms=wall_view, tail_overlap=bool(args.tail_overlap))
+                                              view_wall_ms=wall_view, overlapped=stage_overlapped)
             out["kernel_sha"] = kernel_sha
-    if rank == 0 and not multi and len(ctxs) == 1 and not args.no_two_streams:
-        # The same K steps with stages of consecutive views overlapped -- the drain/fill gaps between the 12 dependent
-        # kernels of a view, and its latency-bound first stage, are filled by another view's work.  Reported beside
-        # `value`, which stays strictly serial so that the per-kernel HIP-event durations of `roofline` are undisturbed.
+    if rank == 0 and not multi and len(ctxs) == 1 and not args.no_two_streams and args.conv_method == 1:
+        # two contexts on the GPU: views alternate between them (reported beside `value`)
         def timed_steps():
             for _ in range(max(1, args.warmup)):
                 step()
@@ -508,13 +735,8 @@ def main():
             dt = time.perf_counter() - t0
             return {"ms_per_step": dt / args.steps * 1e3, "value": total_views * args.steps / dt * nvox / 1e6, "unit": "Mvoxel/s"}
         try:
-            ctxs[0].set_option("tail_overlap", 1)
-            ctxs[0].set_option("psf_overlap", 1)
-            out["overlap"] = dict(timed_steps(), note="one context, options tail_overlap + psf_overlap: extract + Poisson of view v on "
-                                  "a stream of its own beside rotate+attenuate of view v+1, PSF spectrum beside passes A/B")
-            ctxs[0].set_option("tail_overlap", 0)
-            ctxs[0].set_option("psf_overlap", 0)
             ctxs.append(mvs.Context(dev_index))
+            set_overlap(not args.serial)
             out["two_streams"] = dict(timed_steps(), streams_per_gpu=2,
                                       note="views alternate between two contexts of the same GPU; same workload and timed-region rules as `value`")
         except Exception as e:
@@ -525,21 +747,21 @@ def main():
         bc_ctx.close()
 
     if rank == 0:
-        if not multi and not args.no_end_to_end:
+        if not multi and not args.no_end_to_end and args.conv_method == 1:
             try:
                 out["end_to_end"] = end_to_end_record(mvs, dev_index, gt_host, [psf_raw], angles, args.inc, args.snr)
             except Exception as e:  # reported extras never cost the GPU line
                 out["end_to_end"] = {"failed": repr(e)}
-        if not multi and not args.no_size_1024 and n == 512:
+        if not multi and not args.no_size_1024 and n == 512 and args.conv_method == 1:
             try:
                 acq.clear()
                 torch.cuda.empty_cache()
-                out["size_1024"] = size_1024_record(mvs, torch, dev, dev_index, gt_bufs[0], psf_raw, args.inc, args.snr, args.tail_overlap)
+                out["size_1024"] = size_1024_record(mvs, torch, dev, dev_index, gt_bufs[0], psf_raw, args.inc, args.snr)
             except Exception as e:
                 out["size_1024"] = {"failed": repr(e)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(gt_host, psf_raw, angles[0], args.inc, args.snr, args.cpu_slab)
+                out["cpu_baseline"] = cpu_baseline(gt_host, psf_raw, angles[0], args.inc, args.snr, args.cpu_slab, args.cpu_poisson_planes)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "Mvoxel/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}

@@ -65,9 +65,11 @@ int  mvsim_join(mvsim_ctx* ctx);
  * "fft_backend" = custom|rocfft (MVSIM_FFT_BACKEND), "fft_pad" = "px,py,pz"|auto (MVSIM_FFT_PAD), "fused_rotate" = auto|1|0|2
  * (MVSIM_NO_FUSED_ROTATE; auto = fused from 131072 columns up, separate kernels for small views; 2 = the variant that
  * recomputes the row geometry in every lane), "poisson_queue" = 1|0 (MVSIM_POISSON_NOQUEUE), "early_sum" = 1|0 (MVSIM_NO_EARLY_SUM),
- * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "psf_overlap" = 0|1 (the PSF's spectrum on a side
- * stream of the context, concurrent with the image passes A and B), "tail_overlap" = 0|1|any (extract + Poisson of a device
- * view concurrent with the next view's rotate+attenuate; 1 = only on the context's own stream, see mvsim_join), "fuse_tail" = 0|1 (adjust +
+ * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "psf_overlap" = 1|0 (the PSF's spectrum on a side
+ * stream of the context, concurrent with the image passes A and B), "tail_overlap" = 1|0|any (extract + Poisson of a device
+ * view concurrent with the next view's rotate+attenuate; 1 = only on the context's own stream, see mvsim_join; both
+ * overlaps are on by default -- results are bit-identical to the serial order -- and are switched off for profiles whose
+ * per-kernel durations must add up to the stage times), "fuse_tail" = 0|1 (adjust +
  * extract + Poisson phase 1 in the epilogue of the convolution's last pass), "attenuate" = serial|scan (mvsim_attenuate3d
  * as a wavefront-level prefix scan along the illumination axis: parallel in y, not bit-identical to the serial walk).
  * MVSIM_OPTIONS="name=value;name=value" sets any of them process-wide.  Unknown names or values: MVSIM_EINVAL. */
@@ -109,7 +111,8 @@ int mvsim_attenuate3d(mvsim_ctx* ctx, const float* in, const int64_t dim[3], dou
 int mvsim_norm_image(mvsim_ctx* ctx, float* img, int64_t n);
 /* SMVD:253-264 convolve(img, psf, service): normalises psf IN PLACE (sum -> 1), then exact
  * linear convolution with mirror-single image boundary, kernel centre kdim/2, no flip.
- * method: 0 = auto, 1 = FFT, 2 = direct LDS-tiled stencil. */
+ * method: 0 = auto (the stencil up to 4 x 4 x 4 taps, where it is measured faster; the FFT passes beyond), 1 = FFT,
+ * 2 = direct LDS-tiled stencil (any PSF up to 64 taps per axis; 2 Kx Ky Kz flop per voxel). */
 int mvsim_convolve(mvsim_ctx* ctx, const float* img, const int64_t dim[3],
                    float* psf, const int64_t kdim[3], int method, float* out);
 /* Tools:143-159 adjustImage: in place; *correction = (target - min) / mean. */
@@ -255,6 +258,10 @@ typedef struct mvsim_timings {
  * pitch), 1 if the z pass is the direct convolution}.  A pass moves 8 * Hxp * Py * planes bytes each way (the x passes
  * 4 N on their real side).  MVSIM_EINVAL when the sizes fall outside the pass table (rocFFT path). */
 int mvsim_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t geometry[5]);
+/* Geometry of the direct LDS-tiled stencil (method 2) for this PSF: {taps of one x chunk, y taps, z taps of the PSF chunk a
+ * tile serves, LDS bytes per block, blocks per CU}.  Any PSF of 1..64 taps per axis is accepted (SimulateMultiViewDataset.java:579
+ * loads 51^3 stacks); beyond that MVSIM_EINVAL (use the FFT method). */
+int mvsim_stencil_geometry(const int64_t kdim[3], int64_t geometry[5]);
 int mvsim_enable_timing(mvsim_ctx* ctx, int enable);
 int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t);
 
@@ -263,6 +270,10 @@ int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t);
 /* rank 0 creates the id, the host passes the 128 bytes to every rank by any means. */
 int mvsim_comm_unique_id(unsigned char id[MVSIM_UNIQUE_ID_BYTES]);
 int mvsim_comm_init(mvsim_ctx* ctx, int nranks, int rank, const unsigned char id[MVSIM_UNIQUE_ID_BYTES]);
+/* The RCCL this library is bound to in the running process: file path of the shared object that provides ncclGetVersion
+ * (a process that loaded PyTorch first holds torch/lib/librccl.so under the same soname) and its version code
+ * (major * 10000 + minor * 100 + patch).  Either output may be NULL. */
+int mvsim_comm_library_info(char* path, size_t path_capacity, int* version);
 /* Broadcast the ground-truth volume (device pointer, count floats) from root; enqueued on
  * the context stream.  The only collective on the path (views are independent, SMVD:567).
  * Default form: scatter (root sends chunk r to rank r, nranks-1 concurrent ncclSend: one per xGMI link) followed by
@@ -289,6 +300,7 @@ int        mvsim_group_create(int ndev, const int* devices, mvsim_group** group)
 int        mvsim_group_destroy(mvsim_group* group);
 int        mvsim_group_size(const mvsim_group* group);
 mvsim_ctx* mvsim_group_ctx(mvsim_group* group, int index);
+/* gt_host is free for reuse when the call returns (the upload has completed; the collectives behind it may still run). */
 int        mvsim_group_broadcast_volume(mvsim_group* group, const float* gt_host, const int64_t dim[3]);
 int        mvsim_group_simulate_views(mvsim_group* group, float* const* psf_host, const int64_t kdim[3],
                                       const mvsim_view_params* params, int n_views, float* const* acq_host);

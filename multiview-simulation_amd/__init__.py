@@ -502,6 +502,16 @@ class Context:
         _lib.check(_lib.load().mvsim_comm_unique_id(buf))
         return bytes(buf)
 
+    @staticmethod
+    def comm_library_info() -> dict:
+        """Path and version of the RCCL shared object libmvsim.so is bound to in this process."""
+        L = _lib.load()
+        buf = C.create_string_buffer(1024)
+        ver = C.c_int(0)
+        _lib.check(L.mvsim_comm_library_info(buf, len(buf), C.byref(ver)))
+        v = int(ver.value)
+        return {"path": buf.value.decode(), "version_code": v, "version": f"{v // 10000}.{(v // 100) % 100}.{v % 100}"}
+
     def comm_init(self, nranks: int, rank: int, uid: bytes) -> None:
         if len(uid) != _lib.UNIQUE_ID_BYTES:
             raise ValueError("unique id must be 128 bytes")

@@ -113,10 +113,12 @@ SIGNATURES = {
     "mvsim_simulate_view_zslabs": (C.c_int, [_vp, C.POINTER(_vp), _i64p, C.c_int, _i64p, _vp, _i64p, C.POINTER(ViewParams),
                                              C.POINTER(_vp), _i64p, C.c_int, C.POINTER(C.c_double)]),
     "mvsim_fft_geometry": (C.c_int, [_i64p, _i64p, _i64p]),
+    "mvsim_stencil_geometry": (C.c_int, [_i64p, _i64p]),
     "mvsim_enable_timing": (C.c_int, [_vp, C.c_int]),
     "mvsim_get_timings": (C.c_int, [_vp, C.POINTER(Timings)]),
     "mvsim_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "mvsim_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
+    "mvsim_comm_library_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "mvsim_comm_broadcast_volume": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
     "mvsim_comm_allreduce_sum": (C.c_int, [_vp, _vp, C.c_int64]),
     "mvsim_comm_allreduce_sum_f64": (C.c_int, [_vp, C.POINTER(C.c_double)]),

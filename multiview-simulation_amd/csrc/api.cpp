@@ -120,12 +120,10 @@ int ensure_lds_attr(mvsim_ctx* ctx, const void* kernel, size_t bytes)
 
 // Bumped whenever a workspace moves or goes away: captured view graphs hold raw workspace addresses and must not be
 // replayed across such a change (view_graph_launch compares the epoch it captured under).
-static std::atomic<unsigned long long> g_alloc_epoch{1};
-
 int DevBuf::reserve(size_t need)
 {
     if (need <= bytes) return MVSIM_OK;
-    g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
+    if (epoch) *epoch += 1;
     if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
     hipError_t e = hipMalloc(&p, need);
     if (e != hipSuccess) {
@@ -139,7 +137,7 @@ int DevBuf::reserve(size_t need)
 
 void DevBuf::release()
 {
-    if (p) g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
+    if (p && epoch) *epoch += 1;
     if (p) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
@@ -247,6 +245,7 @@ int join_tail(mvsim_ctx* ctx)
 static int set_device(mvsim_ctx* ctx, bool keep_tail = false)
 {
     MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
+    ev_rebalance(ctx);
     MVSIM_HIP(hipSetDevice(ctx->device));
     if (!keep_tail) MVSIM_TRY(join_tail(ctx));
     return MVSIM_OK;
@@ -298,8 +297,9 @@ static int psf_prepare(mvsim_ctx* ctx, float* psf_host, const int64_t kdim[3], c
 static int pick_method(int method, const int64_t kdim[3])
 {
     if (method == 1 || method == 2) return method;
-    // direct stencil costs 2*K^3 flop/voxel; break-even with the FFT path is around K ~ 7
-    return (kdim[0] * kdim[1] * kdim[2] <= 7 * 7 * 7) ? 2 : 1;
+    // direct stencil costs 2*K^3 flop/voxel; measured at 512^3 (tools/stencil_bench.py, profiles/r03_stencil_bench.txt): 3^3
+    // 0.67x the FFT passes' time, 5^3 1.06x, 7^3 1.76x -- the FFT path takes over between 4 and 5 taps per axis
+    return (kdim[0] * kdim[1] * kdim[2] <= 4 * 4 * 4) ? 2 : 1;
 }
 
 static int convolve_dev_impl(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const int64_t kdim[3],
@@ -477,7 +477,12 @@ int mvsim_host_alloc(mvsim_ctx* ctx, size_t bytes, void** hptr)
 
 int mvsim_host_free(mvsim_ctx* ctx, void* hptr)
 {
-    if (ctx) MVSIM_TRY(set_device(ctx));               // ctx may be NULL: blocks can outlive their context
+    if (ctx) {                                         // ctx may be NULL: blocks can outlive their context
+        MVSIM_TRY(set_device(ctx));
+        // a block that comes back from the allocator at the same address is a different ground truth
+        for (int s = 0; s < mvsim_ctx::ASYNC_SLOTS; ++s)
+            if (hptr && ctx->async_gt_src[s] == hptr) ctx->async_gt_src[s] = nullptr;
+    }
     if (hptr) MVSIM_HIP(hipHostFree(hptr));
     return MVSIM_OK;
 }
@@ -819,8 +824,10 @@ static std::string view_graph_key(mvsim_ctx* ctx, const float* gt, const int64_t
     add(&o->rot, sizeof(o->rot)); add(&o->att, sizeof(o->att)); add(&o->con, sizeof(o->con)); add(&o->acq, sizeof(o->acq));
     add(&ctx->stream, sizeof(ctx->stream));
     const Options& q = ctx->opt;
-    const int oo[8] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, q.psf_overlap ? 1 : 0, 0};
+    const int oo[8] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, q.psf_overlap ? 1 : 0,
+                       q.attenuate_scan ? 1 : 0};
     add(oo, sizeof(oo));
+    add(q.fft_pad, sizeof(q.fft_pad));
     return k;
 }
 
@@ -839,7 +846,7 @@ static int view_graph_launch(mvsim_ctx* ctx, const float* gt, const int64_t dim[
 {
     const std::string key = view_graph_key(ctx, gt, dim, kdim, p, o);
     ctx->graph_tick += 1;
-    const unsigned long long epoch = g_alloc_epoch.load(std::memory_order_relaxed);
+    const unsigned long long epoch = ctx->alloc_epoch;
     if (ctx->graph_epoch != epoch) {
         // some workspace was (re)allocated since the graphs were captured: their baked-in addresses may be stale
         for (auto& g : ctx->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -863,7 +870,7 @@ static int view_graph_launch(mvsim_ctx* ctx, const float* gt, const int64_t dim[
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc != MVSIM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (g_alloc_epoch.load(std::memory_order_relaxed) != epoch) {
+    if (ctx->alloc_epoch != epoch) {
         // an allocation slipped into the capture (a workspace grew): do not keep this graph; run the view eagerly
         if (graph) (void)hipGraphDestroy(graph);
         return view_enqueue(ctx, gt, dim, kdim, p, o);
@@ -1289,7 +1296,13 @@ int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt, uint64_t gt_gener
     }
     const bool wants_twins = o->rot || o->att || o->con;
     mvsim_view_outputs dev = {nullptr, nullptr, nullptr, nullptr};
-    MVSIM_TRY(ctx->async_gt[s].reserve(vbytes));
+    {
+        // the staging buffer may move when a later view is larger: what it held is gone then, whatever the caller's pointer
+        // and generation say; a view of another size never matches the cached upload either
+        const void* before = ctx->async_gt[s].p;
+        MVSIM_TRY(ctx->async_gt[s].reserve(vbytes));
+        if (ctx->async_gt[s].p != before || ctx->async_gt_bytes[s] != vbytes) ctx->async_gt_src[s] = nullptr;
+    }
     MVSIM_TRY(ctx->async_acq[s].reserve(obytes));
     if (o->rot) { MVSIM_TRY(ctx->host_rot.reserve(vbytes)); dev.rot = ctx->host_rot.as<float>(); }
     if (o->att) { MVSIM_TRY(ctx->host_att.reserve(vbytes)); dev.att = ctx->host_att.as<float>(); }
@@ -1304,6 +1317,7 @@ int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt, uint64_t gt_gener
         MVSIM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_h2d[s], 0));
         ctx->async_gt_src[s] = gt;
         ctx->async_gt_gen[s] = gt_generation;
+        ctx->async_gt_bytes[s] = vbytes;
     }
     // compute: the acquisition buffer of the set is free (waited for above); the single-buffered intermediates are free
     // once the neighbour's downloads are through
@@ -1385,6 +1399,16 @@ int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, con
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MVSIM_OK) { set_error("stream synchronise failed"); rc = MVSIM_EHIP; }
     return rc;
+}
+
+int mvsim_stencil_geometry(const int64_t kdim[3], int64_t geometry[5])
+{
+    if (!kdim || !geometry) { set_error("invalid argument: null pointer"); return MVSIM_EINVAL; }
+    if (!stencil_chunk_geometry(kdim, geometry)) {
+        set_error("direct stencil: PSF outside 1..64 taps per axis");
+        return MVSIM_EINVAL;
+    }
+    return MVSIM_OK;
 }
 
 int mvsim_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t geometry[5])

@@ -5,6 +5,8 @@
 
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
 #include <cstring>
 #include <new>
 #include <vector>
@@ -31,6 +33,25 @@ int mvsim_comm_unique_id(unsigned char id[MVSIM_UNIQUE_ID_BYTES])
     MVSIM_NCCL(ncclGetUniqueId(&uid));
     std::memset(id, 0, MVSIM_UNIQUE_ID_BYTES);
     std::memcpy(id, &uid, sizeof(uid));
+    return MVSIM_OK;
+}
+
+// Which RCCL this library is bound to.  libmvsim.so names librccl.so.1 as a dependency; in a process that has already
+// loaded another copy under that name (PyTorch ships its own in torch/lib) the dynamic loader binds to THAT copy, so the
+// path and version are reported instead of assumed (bench.py prints them beside torch's own).
+int mvsim_comm_library_info(char* path, size_t path_capacity, int* version)
+{
+    if (version) {
+        int v = 0;
+        MVSIM_NCCL(ncclGetVersion(&v));
+        *version = v;
+    }
+    if (path && path_capacity > 0) {
+        path[0] = 0;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void*>(&ncclGetVersion), &info) && info.dli_fname)
+            std::snprintf(path, path_capacity, "%s", info.dli_fname);
+    }
     return MVSIM_OK;
 }
 
@@ -230,6 +251,19 @@ int mvsim_group_broadcast_volume(mvsim_group* g, const float* gt_host, const int
     }
     MVSIM_HIP(hipSetDevice(g->ctx[0]->device));
     MVSIM_HIP(hipMemcpyAsync(g->gt[0].p, gt_host, bytes, hipMemcpyHostToDevice, g->ctx[0]->stream));
+    // gt_host belongs to the caller again when this function returns (header: "keeps no reference to the pointers
+    // afterwards"): the upload is waited for below, after the collectives behind it have been enqueued
+    hipEvent_t uploaded = nullptr;
+    MVSIM_HIP(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming));
+    if (hipEventRecord(uploaded, g->ctx[0]->stream) != hipSuccess) {
+        (void)hipEventDestroy(uploaded);
+        mvsim::set_error("hipEventRecord failed");
+        return MVSIM_EHIP;
+    }
+    struct EventGuard {
+        hipEvent_t e;
+        ~EventGuard() { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
+    } guard{uploaded};
     for (int phase = 0; phase < 3; ++phase) {
         int rc = MVSIM_OK;
         MVSIM_NCCL(ncclGroupStart());

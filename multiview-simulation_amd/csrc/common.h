@@ -59,6 +59,10 @@ void set_error(const char* fmt, ...);
 struct DevBuf {
     void*  p     = nullptr;
     size_t bytes = 0;
+    // allocation epoch of the owning context (null for buffers that belong to no context): bumped whenever this buffer
+    // moves or goes away, so that the context's captured view graphs -- which hold raw workspace addresses -- are dropped.
+    // Per context, not per process: another thread's context growing a workspace must not cost this one its graphs.
+    unsigned long long* epoch = nullptr;
     int    reserve(size_t need);
     void   release();
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -105,10 +109,11 @@ struct Options {
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
                                        // resolver, production), 0: one kernel
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
-    bool    psf_overlap = false;       // PSF spectrum on the context's side stream, concurrent with passes A and B (views of
-                                       // >= 2^24 voxels; +1 % views/s at 512^3).  Opt-in like tail_overlap: overlapped kernels
-                                       // share the chip, so their own durations in a profile no longer add up to the stage time
-    int     tail_overlap = 0;          // extract + Poisson of a view concurrent with the next view's rotate+attenuate (device
+    bool    psf_overlap = true;        // PSF spectrum on the context's side stream, concurrent with passes A and B (views of
+                                       // >= 2^24 voxels; +1 % views/s at 512^3).  On by default since round 3 (bit-identical, tested);
+                                       // overlapped kernels share the chip, so their own durations in a profile no longer add up to
+                                       // the stage time: profiles and bench.py's roofline leg switch both overlaps off
+    int     tail_overlap = 1;          // extract + Poisson of a view concurrent with the next view's rotate+attenuate (device
                                        // views of >= 2^24 voxels; measured +0..6 % views/s at 512^3 depending on the box -- the two
                                        // stages then share the chip, so their own HIP-event times grow while the convolution
                                        // between them is undisturbed): 0 off, 1 on the context's own stream only (nothing outside
@@ -132,6 +137,11 @@ enum Stage { ST_ROTATE = 0, ST_ATTENUATE, ST_PSF, ST_CONVOLVE, ST_ADJUST, ST_EXT
 }  // namespace mvsim
 
 struct mvsim_ctx {
+    mvsim_ctx();
+    mvsim_ctx(const mvsim_ctx&) = delete;
+    mvsim_ctx& operator=(const mvsim_ctx&) = delete;
+    unsigned long long alloc_epoch = 1;     // see DevBuf::epoch
+    int         roctx_depth = 0;            // stage ranges open on this context (rebalanced by every entry point after an error return)
     int         device     = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream     = nullptr;
@@ -194,6 +204,7 @@ struct mvsim_ctx {
     double*    async_corr = nullptr;          // pinned: one double per slot
     const void* async_gt_src[ASYNC_SLOTS] = {};   // host ground truth a slot holds (identity + generation: re-upload skipped)
     unsigned long long async_gt_gen[ASYNC_SLOTS] = {};
+    size_t     async_gt_bytes[ASYNC_SLOTS] = {};  // bytes of that upload (a view of another size never reuses it)
     long long  async_next = 0;
     bool       async_ready = false;
     bool       async_twins_busy = false;      // the single-buffered rot/att/con twins are being downloaded
@@ -213,6 +224,14 @@ struct mvsim_ctx {
     void* comm = nullptr;
     int   nranks = 1, rank = 0;
 };
+
+inline mvsim_ctx::mvsim_ctx()
+{
+    for (mvsim::DevBuf* b : {&vol_a, &vol_b, &vol_c, &out_buf, &psf_dev, &stencil_psf, &fft_real, &fft_spec_img, &fft_spec_psf, &fft_work,
+                             &pqueue, &sphere_list, &host_gt, &host_rot, &host_att, &host_con, &partials, &partials_e, &cfft_f, &cfft_g,
+                             &cfft_g1, &cfft_g2, &partials_z, &async_gt[0], &async_gt[1], &async_acq[0], &async_acq[1]})
+        b->epoch = &alloc_epoch;
+}
 
 namespace mvsim {
 
@@ -257,6 +276,7 @@ int launch_crop_scale_sum(hipStream_t s, const float* real, const int64_t P[3], 
                           const int64_t dim[3], float scale, double* partial, double* scal);
 int launch_stencil(mvsim_ctx* ctx, const float* img, const int64_t dim[3], const float* psf,
                    const int64_t kdim[3], float* out);
+bool stencil_chunk_geometry(const int64_t kdim[3], int64_t out[5]);
 // raise a kernel's dynamic-LDS limit once per context (hipFuncSetAttribute is not free on a launch path)
 int ensure_lds_attr(mvsim_ctx* ctx, const void* kernel, size_t bytes);
 
@@ -323,15 +343,22 @@ inline const char* stage_name(int st)
 inline void ev_begin(mvsim_ctx* ctx, int st)
 {
     (void)roctxRangePushA(stage_name(st));
+    ctx->roctx_depth += 1;
     if (ctx->timing) (void)hipEventRecord(ctx->evr[ctx->ev_cur][st][0], ctx->stream);
 }
 inline void ev_end(mvsim_ctx* ctx, int st)
 {
-    (void)roctxRangePop();
+    if (ctx->roctx_depth > 0) { (void)roctxRangePop(); ctx->roctx_depth -= 1; }
     if (ctx->timing) {
         (void)hipEventRecord(ctx->evr[ctx->ev_cur][st][1], ctx->stream);
         ctx->ev_used[ctx->ev_cur][st] = true;
     }
+}
+// An error return between ev_begin and ev_end (MVSIM_TRY / MVSIM_HIP) leaves ranges open: every entry point closes what
+// the previous call on this context left behind (set_device), and so does mvsim_destroy.
+inline void ev_rebalance(mvsim_ctx* ctx)
+{
+    while (ctx->roctx_depth > 0) { (void)roctxRangePop(); ctx->roctx_depth -= 1; }
 }
 // start a new slot (called once per timed call)
 inline void ev_next(mvsim_ctx* ctx)

@@ -91,6 +91,8 @@ def lib():
         L.orc_adjust_image.argtypes = [_f32p, C.c_int64, C.c_float, C.c_float]
         L.orc_adjust_image.restype = C.c_double
         L.orc_convolve_direct.argtypes = [_f32p, _i64p, _f32p, _i64p, _f32p]
+        L.orc_set_parallel.argtypes = [C.c_int]
+        L.orc_max_threads.restype = C.c_int
         L.orc_convolve_direct_at.argtypes = [_f32p, _i64p, _f32p, _i64p, _i64p, C.c_int64, _f64p]
         L.orc_extract_nz.argtypes = [C.c_int64, C.c_int]
         L.orc_extract_nz.restype = C.c_int64
@@ -251,6 +253,16 @@ def convolve_direct(vol, psf: np.ndarray) -> np.ndarray:
     if rc:
         raise MemoryError("convolve_direct")
     return out
+
+
+def set_parallel(on: bool) -> None:
+    """bench.py's cpu_baseline mode "all_cores": OpenMP in rotate / attenuate / adjust_image (default off = the reference's
+    single-threaded cursor loops; the parity tests never switch it on)."""
+    lib().orc_set_parallel(1 if on else 0)
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
 
 
 def convolve_direct_at(vol, psf_normalised: np.ndarray, idx) -> np.ndarray:

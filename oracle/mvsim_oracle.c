@@ -8,6 +8,9 @@
 #include "mvsim_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -366,6 +369,21 @@ static float nlinear3(const float* in, const int64_t dim[3], tap_fn tap, double 
     return acc;
 }
 
+/* Threading switch for the CPU-baseline leg of bench.py (mode "all_cores"): 0 (default) = every stage a single-threaded cursor
+ * loop, as the reference runs them (only FFTConvolution gets the executor service, SMVD:257,527); 1 = OpenMP over planes /
+ * columns.  rotate and attenuate are bit-identical either way (independent voxels / columns); adjustImage's sum then
+ * cascades per 64 Ki chunk and over the chunk sums (not the serial RealSum order), so the parity tests keep the default. */
+static int g_parallel = 0;
+void orc_set_parallel(int on) { g_parallel = on ? 1 : 0; }
+int  orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* SMVD:104-135 */
 int orc_rotate_around_axis(const float* in, const int64_t dim[3], int axis, int degrees, float* out)
 {
@@ -373,6 +391,7 @@ int orc_rotate_around_axis(const float* in, const int64_t dim[3], int axis, int 
     double m[12], a[12];
     orc_axis_rotation(dim, axis, degrees, m);
     orc_affine_invert(m, a);
+#pragma omp parallel for schedule(static) if (g_parallel)
     for (int64_t z = 0; z < dim[2]; ++z)
         for (int64_t y = 0; y < dim[1]; ++y)
             for (int64_t x = 0; x < dim[0]; ++x) {
@@ -391,6 +410,7 @@ int orc_attenuate3d(const float* in, const int64_t dim[3], double delta, float* 
     const int64_t nx = dim[0], ny = dim[1], nz = dim[2];
     if (nx > ny) return -1;                       /* reference walks out of the interval */
     memset(out, 0, (size_t)(nx * ny * nz) * sizeof(float));
+#pragma omp parallel for schedule(static) if (g_parallel)
     for (int64_t z = 0; z < nz; ++z)
         for (int64_t x = 0; x < nx; ++x) {
             double n = 1.0;
@@ -442,11 +462,29 @@ void orc_norm_image(float* img, int64_t n)                   /* Tools:112-118 */
     for (int64_t i = 0; i < n; ++i) img[i] = (float)((double)img[i] / sum);
 }
 
+static double sum_image_chunked(const float* img, int64_t n)  /* g_parallel only: RealSum per chunk, RealSum of the chunk sums */
+{
+    const int64_t chunk = 65536, nc = (n + chunk - 1) / chunk;
+    double* part = (double*)malloc((size_t)nc * sizeof(double));
+    if (!part) return orc_sum_image(img, n);
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nc; ++c) {
+        const int64_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        part[c] = orc_sum_image(img + lo, hi - lo);
+    }
+    realsum s; memset(&s, 0, sizeof(s));
+    for (int64_t c = 0; c < nc; ++c) realsum_add(&s, part[c]);
+    free(part);
+    return realsum_get(&s);
+}
+
 double orc_adjust_image(float* img, int64_t n, float min_value, float target_average) /* Tools:143-159 */
 {
-    const double avg = orc_sum_image(img, n) / (double)n;
+    const double avg = (g_parallel ? sum_image_chunked(img, n) : orc_sum_image(img, n)) / (double)n;
     const double correction = (double)(target_average - min_value) / avg;  /* float subtraction, Q6 */
+#pragma omp parallel for schedule(static) if (g_parallel)
     for (int64_t i = 0; i < n; ++i) img[i] = (float)((double)img[i] * correction);
+#pragma omp parallel for schedule(static) if (g_parallel)
     for (int64_t i = 0; i < n; ++i) img[i] = img[i] + min_value;
     return correction;
 }

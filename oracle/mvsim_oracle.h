@@ -67,6 +67,10 @@ int orc_attenuate3d(const float* in, const int64_t dim[3], double delta, float* 
 double orc_sum_image(const float* img, int64_t n);
 void   orc_norm_image(float* img, int64_t n);
 
+/* bench.py's cpu_baseline mode "all_cores": OpenMP over planes / columns in rotate, attenuate, adjustImage (default 0: serial) */
+void orc_set_parallel(int on);
+int  orc_max_threads(void);
+
 /* ---- Tools:143-159 adjustImage; returns the correction factor ---- */
 double orc_adjust_image(float* img, int64_t n, float min_value, float target_average);
 

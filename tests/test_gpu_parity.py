@@ -711,7 +711,7 @@ def options(ctx):
             ctx.set_option(k, v)
     yield set_
     for k, v in (("fft_zpass", "auto"), ("fft_backend", "custom"), ("fft_pad", "auto"), ("fused_rotate", 1),
-                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial"), ("psf_overlap", 0), ("tail_overlap", 0)):
+                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial"), ("psf_overlap", 1), ("tail_overlap", 1)):
         ctx.set_option(k, v)
 
 
@@ -1200,7 +1200,7 @@ def test_hipgraph_replay_of_views(mvs, synth):
 
 
 def test_tail_overlap_keeps_stream_order_semantics(mvs, synth):
-    """Option tail_overlap (opt-in; device views of >= 2^24 voxels on the context's own stream): the extract +
+    """Option tail_overlap (the default from round 3 on; device views of >= 2^24 voxels on the context's own stream): the extract +
     Poisson tail of view v runs on a stream of its own beside the rotate+attenuate of view v+1.  Same voxels as the
     serial order for back-to-back views into distinct and into shared outputs, for a view whose INPUT is the previous
     view's output (the pending tail must be joined first), around a stage operator, a download and a caller's stream."""
@@ -1272,7 +1272,7 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
     import subprocess
     import sys
     bench = os.path.join(ROOT, "bench.py")
-    for extra in (["--broadcast", "scatter_allgather"], ["--broadcast", "ring", "--tail-overlap", "1"]):
+    for extra in (["--broadcast", "scatter_allgather"], ["--broadcast", "ring", "--serial"]):
         r = subprocess.run([sys.executable, bench, "--rehearse-multi", "--size", "256", "--psf", "15", "--steps", "2", "--warmup", "1",
                             "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -1280,6 +1280,29 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
         d = json.loads(line)
         assert "rehearsal" in d and d["value"] > 0 and "mvsim_comm_broadcast_volume" in d["config"]["collective"]
         assert extra[1] in d["config"]["collective"]
+        assert d["config"]["rccl"]["libmvsim"]["version_code"] > 0 and d["config"]["rccl"]["libmvsim"]["path"]
+        assert ("off" in d["config"]["overlap"]) == ("--serial" in extra)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself (children with RANK /
+    WORLD_SIZE / MASTER_* set, before anything touches the GPU in the parent) and rank 0's line says n_gpus 2 with both
+    ranks seen by an all-reduce.  Two ranks share the one GPU of this box, so the process group is gloo and the ground truth
+    travels through torch.distributed.broadcast (RCCL cannot place two ranks on one device); on an 8-GPU node the same
+    command line with the default backend runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--size", "256", "--psf", "15", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["ranks_seen"]["torch"] == 2
+    assert d["config"]["launcher"].startswith("self-launched") and d["config"]["views_this_gpu"] == 4
+    assert "torch.distributed.broadcast (gloo)" in d["config"]["collective"]
+    assert d["roofline"]["stages"]["convolve"]["ms"] > 0
 
 
 @pytest.mark.parametrize("seed", range(12))

@@ -211,6 +211,33 @@ def test_make_square(mvs):
     assert np.array_equal(mvs.Tools.makeSquare(cube), cube)
 
 
+def _bench_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                              "MVSIM_BENCH_SELF_LAUNCHED")}
+
+
+def test_bench_self_launcher_starts_its_ranks():
+    """`python bench.py --gpus 2 --backend gloo` without torchrun: the parent starts two children (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT) and forwards rank 0's line; --dry-run-launch stops after the rendezvous
+    and an all-reduce of 1 (no GPU here).  A child that fails makes the parent fail; --gpus that contradicts WORLD_SIZE is
+    an error, also for WORLD_SIZE=1 (round 2 ran one rank and printed n_gpus 1 there)."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--dry-run-launch"], capture_output=True, text=True,
+                       timeout=300, env=_bench_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d == {"dry_run_launch": True, "n_gpus": 2, "ranks_seen": 2, "backend": "gloo", "self_launched": True}
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "no_such_backend", "--dry-run-launch"], capture_output=True,
+                         text=True, timeout=300, env=_bench_env())
+    assert bad.returncode != 0 and "exited with status" in bad.stderr
+    mism = subprocess.run([sys.executable, bench, "--gpus", "8", "--dry-run-launch"], capture_output=True, text=True, timeout=120,
+                          env=dict(_bench_env(), WORLD_SIZE="1", RANK="0"))
+    assert mism.returncode != 0 and "WORLD_SIZE=1" in mism.stderr
+
+
 def test_slab_range_partitions_the_planes(mvs):
     """mvsim_slab_range (host only): contiguous, balanced, covering partition of [0, Nz)."""
     L = importlib.import_module("multiview-simulation_amd._lib").load()
