@@ -70,7 +70,9 @@ int  mvsim_join(mvsim_ctx* ctx);
  * view concurrent with the next view's rotate+attenuate; 1 = only on the context's own stream, see mvsim_join; both
  * overlaps are on by default -- results are bit-identical to the serial order -- and are switched off for profiles whose
  * per-kernel durations must add up to the stage times), "fuse_tail" = 0|1 (adjust +
- * extract + Poisson phase 1 in the epilogue of the convolution's last pass), "attenuate" = serial|scan (mvsim_attenuate3d
+ * extract + Poisson phase 1 in the epilogue of the convolution's last pass), "fused_fftx" = auto|1|0 (per-view pipeline: rotate + attenuate + the x transform of
+ * the FFT convolution as one kernel, so that the attenuated volume crosses HBM only when requested; auto = from 131072
+ * columns up), "attenuate" = serial|scan (mvsim_attenuate3d
  * as a wavefront-level prefix scan along the illumination axis: parallel in y, not bit-identical to the serial walk).
  * MVSIM_OPTIONS="name=value;name=value" sets any of them process-wide.  Unknown names or values: MVSIM_EINVAL. */
 int  mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value);

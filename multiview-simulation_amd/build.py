@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvsim.so")
-SOURCES = ["api.cpp", "comm.cpp", "kernels.hip", "fftconv.hip", "fft_kernels.hip", "stencil.hip", "phantom.hip"]
-HEADERS = ["common.h", "poisson_dev.h", "../../include/mvsim.h"]
+SOURCES = ["api.cpp", "comm.cpp", "kernels.hip", "fftconv.hip", "fft_kernels.hip", "rotate_fft.hip", "stencil.hip", "phantom.hip"]
+HEADERS = ["common.h", "poisson_dev.h", "fft_dev.h", "../../include/mvsim.h"]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 

@@ -104,6 +104,9 @@ struct Options {
                                        // cannot use 16-byte rows (Nx % 4 != 0), else 0 -- one lane walks
                                        // one (x, z) column, so a 128^3 view is 256 waves of serial latency (measured 30 us
                                        // against 20 us for the two kernels; break-even at 256^3)
+    int     fused_fftx = 2;            // rotate + attenuate + the convolution's x transform as ONE kernel in the per-view pipeline
+                                       // (rotate_fft.hip; `att` crosses HBM only when requested): 0 off, 1 whenever the geometry
+                                       // allows, 2 auto (production): from 131072 columns up, like fused_rotate
     bool    attenuate_scan = false;    // attenuate3d (stage operator) as a wavefront prefix scan along y: re-associates the
                                        // fp64 products (float outputs differ from the serial walk by one ulp on < 1e-6 of the voxels)
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
@@ -299,6 +302,9 @@ struct ConvTail {
     uint32_t stream = 0;
     // out: true when the convolution did all of that (sum, factor in the context's scalar slots; acquisition complete)
     bool     fused = false;
+    // in: pass A has run already -- the context's spectrum buffer holds the x transform of the image rows (fused rotate +
+    // attenuate + x transform, rotate_fft.hip); `img` is not read
+    bool     x_done = false;
     // in: voxels of the view (> 0: compute adjustImage's factor from min_value / target_average together with the sum);
     // out: corr_done = the factor is in the context's scalar slot, no separate k_adjust_corr needed
     long long corr_n = 0;
@@ -308,6 +314,8 @@ struct ConvTail {
 size_t fused_tail_queue_bytes(const int64_t dim[3], const int64_t kdim[3], int inc, bool con_wanted, const Options& opt);
 int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
                            double mul, uint64_t seed, uint32_t stream);
+int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, float* att_or_null, const int64_t dim[3],
+                          const int64_t kdim[3], const Affine& inv, double delta, bool* done);
 int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,
                  const int64_t kdim[3], float* out_dev, ConvTail* tail);
 void fft_release(mvsim_ctx* ctx);

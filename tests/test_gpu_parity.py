@@ -928,9 +928,88 @@ def test_config1_512_cubed_fused_view_with_rotation(mvs):
 
 
 def test_config3_1024_cubed_anisotropic_psf_inc4(mvs):
-    """BASELINE configs[3]: 1024^3 volume, anisotropic PSF, 4x axial down-sampling -- one view fits one GPU, so the
-    view runs untiled (z-slab tiling is a capacity measure this size does not need)."""
-    _large_view_properties(mvs, (1024, 1024, 1024), (41, 15, 15), 4, (1.5, 1.6, 7.0))
+    """BASELINE configs[3] as SURVEY 8(d) states it: 1024^3 volume, 31 x 31 x 63 Gaussian PSF with sigma = (2, 2.2, 12), 4x
+    axial down-sampling -- one view fits one GPU, so the view runs untiled here (the slab-tiled form of the same PSF depth:
+    test_view_slab_tiling_at_size_with_the_config3_psf)."""
+    _large_view_properties(mvs, (1024, 1024, 1024), (63, 31, 31), 4, (2.0, 2.2, 12.0))
+
+
+def test_view_slab_tiling_at_size_with_the_config3_psf(mvs, synth):
+    """configs[3]'s z-slab tiling at size: a 512 x 512 x 256 view with the 63-deep anisotropic PSF (31 x 31 x 63, sigma
+    2 / 2.2 / 12), inc 4, cut into 4 slabs of 64 planes (one context per slab, as one GPU per rank would have it).  Every slab
+    recomputes a 31-plane halo of rotation and attenuation, the mirror boundary acts at the global faces only, the one
+    exchanged double is the adjustImage sum: the stitched noise-free acquisition equals the untiled view's to 1e-6, the
+    Poisson counts (global counters) differ only where that 1e-6 moves a voxel across an integer step."""
+    nx, ny, nz, inc, nslabs = 512, 512, 256, 4, 4
+    gt = np.ascontiguousarray(synth.sphere_phantom(512)[128:384])
+    psf = synth.gaussian_psf(31, 31, 63, sigma=(2.0, 2.2, 12.0))
+    dims = (nx, ny, nz)
+    nzo = (nz - 1) // inc + 1
+    with mvs.Context(0) as whole:
+        p = whole.view_params(degrees=50, delta=0.01, inc=inc, snr=25.0, seed=SEED, stream=5, conv_method=1)
+        pn = whole.view_params(degrees=50, delta=0.01, inc=inc, snr=-1.0, conv_method=1)
+        ref = whole.simulate_view(gt, psf.copy(), p, want=("acq",))["acq"]
+        ref_noise_free = whole.simulate_view(gt, psf.copy(), pn, want=("acq",))["acq"]
+    ctxs = [mvs.Context(0) for _ in range(nslabs)]
+    try:
+        ranges = [ctxs[0].slab_range(nz, nslabs, r) for r in range(nslabs)]
+        assert [b - a for a, b in ranges] == [64] * 4
+        d_gt = [_dev_volume(c, gt) for c in ctxs]
+        sums = [c.view_slab_convolve_dev(d, dims, psf.copy(), p, z0, z1) for c, d, (z0, z1) in zip(ctxs, d_gt, ranges)]
+        total = float(np.sum(np.array(sums, dtype=np.float64)))
+        for pp, want in ((pn, ref_noise_free), (p, ref)):
+            parts = []
+            for c, (z0, z1) in zip(ctxs, ranges):
+                d_acq = c.dev_alloc(((z1 - z0) // inc + 2) * ny * nx * 4)
+                try:
+                    k = c.view_slab_finish_dev(dims, pp, z0, z1, total, d_acq)
+                    parts.append(c.download(d_acq, (k, ny, nx)))
+                finally:
+                    c.dev_free(d_acq)
+            got = np.concatenate(parts, axis=0)
+            assert got.shape == (nzo, ny, nx)
+            if pp is pn:
+                assert rel_to_max(got, want) <= 1e-6
+            else:
+                assert np.array_equal(got, np.round(got)) and (got != want).mean() < 0.005
+                assert abs(got.mean() / want.mean() - 1) < 1e-3
+        for c, d in zip(ctxs, d_gt):
+            c.dev_free(d)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_host_streaming_entry_points_at_512_cubed(ctx, synth):
+    """configs[4] names host-pinned streaming: the z-slab host-buffer entry point (mvsim_simulate_view_zslabs: ground truth
+    in, acquisition out as lists of page-locked z slabs -- the convention for volumes beyond one Java array) and the
+    pipelined entry point (mvsim_simulate_view_async / mvsim_wait) at 512^3, against the synchronous single-buffer call."""
+    n = 512
+    gt = synth.sphere_phantom(n)
+    psf = synth.gaussian_psf(31, sigma=(2.0, 2.2, 6.0))
+    p = ctx.view_params(degrees=60, inc=3, snr=25.0, seed=SEED, stream=2, conv_method=1)
+    ref = ctx.simulate_view(gt, psf.copy(), p)
+    cuts = [0, 100, 101, 300, 512]
+    slabs = []
+    for a, b in zip(cuts, cuts[1:]):
+        h = ctx.pinned_empty((b - a, n, n))
+        h[...] = gt[a:b]
+        slabs.append(h)
+    acq, corr = ctx.simulate_view_zslabs(slabs, psf.copy(), p, [60, 1, 110])
+    assert abs(corr - ref["corr"]) <= 1e-12 * corr
+    assert np.array_equal(np.concatenate(acq, axis=0), ref["acq"])
+    del acq, slabs
+    g = ctx.pinned_empty(gt.shape)
+    g[...] = gt
+    params = [ctx.view_params(degrees=15 + 45 * v, inc=3, snr=25.0, seed=SEED, stream=v, conv_method=1) for v in range(3)]
+    outs = [{"acq": ctx.pinned_empty(ref["acq"].shape)} for _ in range(3)]
+    tickets = [ctx.simulate_view_async(g, psf.copy(), params[v], outs[v]) for v in range(2)]
+    ctx.wait(tickets[0])
+    tickets.append(ctx.simulate_view_async(g, psf.copy(), params[2], outs[2]))
+    for t in tickets[1:]:
+        ctx.wait(t)
+    for v in range(3):
+        assert np.array_equal(outs[v]["acq"], ctx.simulate_view(gt, psf.copy(), params[v])["acq"]), v
 
 
 def test_config4_2048x2048x512_psf63(mvs):
@@ -1282,6 +1361,33 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
         assert extra[1] in d["config"]["collective"]
         assert d["config"]["rccl"]["libmvsim"]["version_code"] > 0 and d["config"]["rccl"]["libmvsim"]["path"]
         assert ("off" in d["config"]["overlap"]) == ("--serial" in extra)
+
+
+@pytest.mark.parametrize("shape,kshape,degrees,inc", [((40, 64, 64), (9, 5, 7), 33, 1),       # one wave per row batch
+                                                      ((50, 160, 128), (11, 7, 5), -52, 3),   # Ny > Nx: rows the attenuation never visits
+                                                      ((48, 200, 192), (31, 9, 15), 60, 2),   # three waves: rows wrap round the waves
+                                                      ((64, 256, 256), (15, 15, 15), 15, 1),
+                                                      ((33, 100, 100), (5, 5, 5), 90, 1)])    # Nx not a multiple of 64 (inactive lanes)
+def test_fused_rotate_attenuate_x_transform_is_bit_identical(mvs, synth, shape, kshape, degrees, inc):
+    """rotate + attenuate + pass A of the convolution as one kernel (rotate_fft.hip, option fused_fftx): the attenuated volume
+    no longer crosses HBM, and nothing else changes -- the spectrum it leaves is pass A's bit for bit, so rot, att, the
+    adjusted convolved volume and the counts are IDENTICAL to the separate kernels', with and without the intermediates
+    requested (the kernel's store-nothing instance)."""
+    rng = np.random.default_rng(77)
+    gt = synth.sphere_phantom(shape[2], shape[1], shape[0]) + (rng.random(shape, dtype=np.float32) < 0.02).astype(np.float32)
+    psf = rng.random(kshape, dtype=np.float32) + 0.05
+    res = {}
+    for mode in (0, 1):
+        with mvs.Context(0) as c:
+            c.set_option("fused_fftx", mode)
+            p = c.view_params(degrees=degrees, inc=inc, snr=25.0, seed=SEED, stream=3, conv_method=1)
+            full = c.simulate_view(gt, psf.copy(), p, want=("rot", "att", "con", "acq"))
+            only = c.simulate_view(gt, psf.copy(), p, want=("acq",))
+            res[mode] = (full, only)
+    for k in ("rot", "att", "con", "acq"):
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    assert np.array_equal(res[0][1]["acq"], res[1][1]["acq"])
+    assert float(res[1][0]["acq"].max()) > 0
 
 
 def test_bench_launches_its_own_ranks():

@@ -10,6 +10,7 @@ synth = importlib.import_module("multiview-simulation_amd.synthetic")
 nx, ny, nz, kx, ky, kz, inc = (int(a) for a in sys.argv[1:8])
 rng = np.random.default_rng(1)
 ctx = mvs.Context(0)
+ctx.set_option("tail_overlap", 0); ctx.set_option("psf_overlap", 0)   # one kernel at a time: stage times are the kernels' own
 # cheap compactly supported volume built on the host plane by plane
 w = lambda n: np.clip(1 - ((np.arange(n, dtype=np.float32) - (n - 1) / 2) / (0.3 * n)) ** 2, 0, None) ** 2
 gt = (w(nz)[:, None, None] * w(ny)[None, :, None]).astype(np.float32) * w(nx)[None, None, :]
