@@ -247,6 +247,21 @@ int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, con
                                const mvsim_view_params* params, float* const* acq_slabs, const int64_t* acq_slab_nz,
                                int n_acq_slabs, double* correction);
 
+/* The per-stage operators with HOST buffers given as z slabs: an ArrayImg may hold 2^31-1 voxels (SimulateMultiViewDataset.java:109,
+ * :198, :235, :321 create their results with ArrayImgFactory) but one direct ByteBuffer only 2^31-1 BYTES, so the Java facade hands
+ * volumes beyond 2^29 voxels over as several page-locked blocks.  in_slabs[i] holds in_slab_nz[i] planes (sum = dim[2]); out_slabs[j]
+ * receives out_slab_nz[j] planes (sum = dim[2], or mvsim_extract_nz(dim[2], inc) for extractSlices).  Same arithmetic as the
+ * single-buffer entry points (SMVD:104-135, :318-364, :253-264, :181-231). */
+int mvsim_rotate_around_axis_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const int64_t* in_slab_nz, int n_in, const int64_t dim[3],
+                                    int axis, int degrees, float* const* out_slabs, const int64_t* out_slab_nz, int n_out);
+int mvsim_attenuate3d_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const int64_t* in_slab_nz, int n_in, const int64_t dim[3],
+                             double delta, float* const* out_slabs, const int64_t* out_slab_nz, int n_out);
+int mvsim_convolve_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const int64_t* in_slab_nz, int n_in, const int64_t dim[3],
+                          float* psf, const int64_t kdim[3], int method, float* const* out_slabs, const int64_t* out_slab_nz, int n_out);
+int mvsim_extract_slices_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const int64_t* in_slab_nz, int n_in, const int64_t dim[3],
+                                int inc, float snr, uint64_t seed, uint32_t stream, float* const* out_slabs, const int64_t* out_slab_nz,
+                                int n_out);
+
 /* ---- per-stage device timings of the last simulate_view / stage call (milliseconds) ------ */
 typedef struct mvsim_timings {
     /* psf_ms is 0 when the PSF spectrum ran on the context's side stream (option psf_overlap, views of >= 2^24 voxels):

@@ -1,8 +1,10 @@
 // JNI shim: net.preibisch.simulation.gpu.MvsimNative  ->  C ABI of libmvsim.so (include/mvsim.h).
 //
-// SOURCE ONLY in this repository (the build image has no JDK / jni.h): this file has never been compiled or run.
+// SOURCE ONLY in this repository (the build image has no JDK / jni.h): this file has never been run, and compiled only with
+// -fsyntax-only against the hand-written jni.h subset of tests/jni_stub (tests/test_host_logic.py) -- a syntax and type check
+// of this file against include/mvsim.h, nothing more.
 // Build on a host with a JDK:
-//   g++ -shared -fPIC -std=c++17 -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
+//   g++ -shared -fPIC -std=c++17 -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include
 //       mvsim_jni.cpp -L../../multiview-simulation_amd -lmvsim -Wl,-rpath,'$ORIGIN' -o libmvsim_jni.so
 //
 // Every buffer is a direct java.nio.FloatBuffer: GetDirectBufferAddress gives the host pointer and
@@ -208,6 +210,97 @@ JNIEXPORT void JNICALL JNI_FN(axisRotation)(JNIEnv* env, jclass, jlongArray dim,
     env->SetDoubleArrayRegion(m12, 0, 12, m);
 }
 
+// ---- per-stage operators with z-slab lists (mvsim_*_zslabs) ----------------------------------------------------------
+namespace {
+// the host pointers and plane counts of a FloatBuffer[] / long[] pair; every buffer is checked against plane * nz[i] floats
+// and the planes against `planes` before the C ABI sees anything.  ok == false: an exception is pending.
+struct SlabArgs {
+    std::vector<float*>  ptr;
+    std::vector<int64_t> nz;
+    bool ok = false;
+    SlabArgs(JNIEnv* env, jobjectArray bufs, jlongArray counts, int64_t plane, int64_t planes, const char* what)
+    {
+        if (!bufs || !counts) { throw_new(env, "java/lang/IllegalArgumentException", what); return; }
+        const jsize n = env->GetArrayLength(bufs);
+        if (n < 1 || env->GetArrayLength(counts) != n) { throw_new(env, "java/lang/IllegalArgumentException", what); return; }
+        std::vector<jlong> c(static_cast<size_t>(n));
+        env->GetLongArrayRegion(counts, 0, n, c.data());
+        if (env->ExceptionCheck()) return;
+        int64_t total = 0;
+        for (jsize i = 0; i < n; ++i) {
+            if (c[i] < 1) { throw_new(env, "java/lang/IllegalArgumentException", what); return; }
+            jobject b = env->GetObjectArrayElement(bufs, i);
+            if (env->ExceptionCheck()) return;
+            float* p = fptr(env, b, plane * c[i], what);
+            if (!p) return;
+            ptr.push_back(p);
+            nz.push_back(c[i]);
+            total += c[i];
+        }
+        if (total != planes) { throw_new(env, "java/lang/IllegalArgumentException", what); return; }
+        ok = true;
+    }
+};
+}  // namespace
+
+JNIEXPORT void JNICALL JNI_FN(rotateAroundAxisSlabs)(JNIEnv* env, jclass, jlong h, jobjectArray in, jlongArray in_nz, jlongArray dim,
+                                                     jint axis, jint degrees, jobjectArray out, jlongArray out_nz)
+{
+    Dim d(env, dim);
+    if (!d.ok) return;
+    SlabArgs si(env, in, in_nz, d.d[0] * d.d[1], d.d[2], "rotateAroundAxis: input slabs do not match the dimensions");
+    if (!si.ok) return;
+    SlabArgs so(env, out, out_nz, d.d[0] * d.d[1], d.d[2], "rotateAroundAxis: output slabs do not match the dimensions");
+    if (!so.ok) return;
+    throw_for(env, mvsim_rotate_around_axis_zslabs(ctx_of(h), si.ptr.data(), si.nz.data(), (int)si.ptr.size(), d.d, axis, degrees,
+                                                   so.ptr.data(), so.nz.data(), (int)so.ptr.size()));
+}
+
+JNIEXPORT void JNICALL JNI_FN(attenuate3dSlabs)(JNIEnv* env, jclass, jlong h, jobjectArray in, jlongArray in_nz, jlongArray dim,
+                                                jdouble delta, jobjectArray out, jlongArray out_nz)
+{
+    Dim d(env, dim);
+    if (!d.ok) return;
+    SlabArgs si(env, in, in_nz, d.d[0] * d.d[1], d.d[2], "attenuate3d: input slabs do not match the dimensions");
+    if (!si.ok) return;
+    SlabArgs so(env, out, out_nz, d.d[0] * d.d[1], d.d[2], "attenuate3d: output slabs do not match the dimensions");
+    if (!so.ok) return;
+    throw_for(env, mvsim_attenuate3d_zslabs(ctx_of(h), si.ptr.data(), si.nz.data(), (int)si.ptr.size(), d.d, delta, so.ptr.data(),
+                                            so.nz.data(), (int)so.ptr.size()));
+}
+
+JNIEXPORT void JNICALL JNI_FN(convolveSlabs)(JNIEnv* env, jclass, jlong h, jobjectArray in, jlongArray in_nz, jlongArray dim, jobject psf,
+                                             jlongArray kdim, jint method, jobjectArray out, jlongArray out_nz)
+{
+    Dim d(env, dim);
+    if (!d.ok) return;
+    Dim k(env, kdim);
+    if (!k.ok) return;
+    float* pp = fptr(env, psf, k.n(), "convolve: PSF buffer smaller than its dimensions");
+    if (!pp) return;
+    SlabArgs si(env, in, in_nz, d.d[0] * d.d[1], d.d[2], "convolve: input slabs do not match the dimensions");
+    if (!si.ok) return;
+    SlabArgs so(env, out, out_nz, d.d[0] * d.d[1], d.d[2], "convolve: output slabs do not match the dimensions");
+    if (!so.ok) return;
+    throw_for(env, mvsim_convolve_zslabs(ctx_of(h), si.ptr.data(), si.nz.data(), (int)si.ptr.size(), d.d, pp, k.d, method, so.ptr.data(),
+                                         so.nz.data(), (int)so.ptr.size()));
+}
+
+JNIEXPORT void JNICALL JNI_FN(extractSlicesSlabs)(JNIEnv* env, jclass, jlong h, jobjectArray in, jlongArray in_nz, jlongArray dim, jint inc,
+                                                  jfloat snr, jlong seed, jint stream, jobjectArray out, jlongArray out_nz)
+{
+    Dim d(env, dim);
+    if (!d.ok) return;
+    if (inc < 1) { throw_new(env, "java/lang/IllegalArgumentException", "extractSlices: inc must be >= 1"); return; }
+    SlabArgs si(env, in, in_nz, d.d[0] * d.d[1], d.d[2], "extractSlices: input slabs do not match the dimensions");
+    if (!si.ok) return;
+    SlabArgs so(env, out, out_nz, d.d[0] * d.d[1], mvsim_extract_nz(d.d[2], inc), "extractSlices: output slabs do not hold (Nz-1)/inc+1 planes");
+    if (!so.ok) return;
+    throw_for(env, mvsim_extract_slices_zslabs(ctx_of(h), si.ptr.data(), si.nz.data(), (int)si.ptr.size(), d.d, inc, snr,
+                                               static_cast<uint64_t>(seed), static_cast<uint32_t>(stream), so.ptr.data(), so.nz.data(),
+                                               (int)so.ptr.size()));
+}
+
 JNIEXPORT jobject JNICALL JNI_FN(allocPinned)(JNIEnv* env, jclass, jlong h, jlong bytes)
 {
     void* p = nullptr;
@@ -364,12 +457,16 @@ JNIEXPORT void JNICALL JNI_FN(groupBroadcastVolume)(JNIEnv* env, jclass, jlong g
     throw_for(env, mvsim_group_broadcast_volume(group_of(g), p, d.d));
 }
 
-JNIEXPORT void JNICALL JNI_FN(groupSimulateViews)(JNIEnv* env, jclass, jlong g, jobjectArray psfs, jlongArray kdim, jintArray degrees,
-                                                  jdouble delta, jfloat min_value, jfloat target, jint inc, jfloat snr, jlongArray seeds,
-                                                  jobjectArray acqs)
+JNIEXPORT void JNICALL JNI_FN(groupSimulateViews)(JNIEnv* env, jclass, jlong g, jobjectArray psfs, jlongArray kdim, jlongArray dim,
+                                                  jintArray degrees, jdouble delta, jfloat min_value, jfloat target, jint inc, jfloat snr,
+                                                  jlongArray seeds, jobjectArray acqs)
 {
     Dim k(env, kdim);
     if (!k.ok) return;
+    Dim d(env, dim);                                       // the dimensions of the broadcast ground truth (GpuGroup keeps them)
+    if (!d.ok) return;
+    if (inc < 1) { throw_new(env, "java/lang/IllegalArgumentException", "groupSimulateViews: inc must be >= 1"); return; }
+    const int64_t acq_floats = d.d[0] * d.d[1] * mvsim_extract_nz(d.d[2], inc);
     if (!psfs || !degrees || !seeds || !acqs) { throw_new(env, "java/lang/IllegalArgumentException", "groupSimulateViews: null argument"); return; }
     const jsize n = env->GetArrayLength(degrees);
     if (env->GetArrayLength(psfs) != n || env->GetArrayLength(seeds) != n || env->GetArrayLength(acqs) != n) {
@@ -392,8 +489,8 @@ JNIEXPORT void JNICALL JNI_FN(groupSimulateViews)(JNIEnv* env, jclass, jlong g, 
         pp[v] = fptr(env, b, k.n(), "groupSimulateViews: PSF buffer smaller than its dimensions");
         jobject a = env->GetObjectArrayElement(acqs, v);
         if (env->ExceptionCheck()) return;
-        // the library knows the volume's dimensions; the capacity of the acquisition buffers is checked against them there
-        pa[v] = fptr(env, a, 1, "groupSimulateViews: acquisition buffer missing");
+        // the C ABI takes no capacity: an undersized direct buffer would take an out-of-bounds copy, so it is refused here
+        pa[v] = fptr(env, a, acq_floats, "groupSimulateViews: acquisition buffer smaller than nx * ny * ((nz - 1) / inc + 1) floats");
         if (!pp[v] || !pa[v]) return;
         fill_params(&par[v], 0, deg[v], delta, min_value, target, inc, snr, sd[v], v);
     }

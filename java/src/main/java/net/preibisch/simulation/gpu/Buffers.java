@@ -4,7 +4,10 @@ import java.nio.ByteBuffer;
 import java.nio.ByteOrder;
 import java.nio.FloatBuffer;
 import java.util.ArrayDeque;
+import java.util.ArrayList;
 import java.util.HashMap;
+import java.util.List;
+import java.util.concurrent.atomic.AtomicLong;
 
 import net.imglib2.Cursor;
 import net.imglib2.Interval;
@@ -31,11 +34,23 @@ final class Buffers
 {
 	private Buffers() {}
 
+	/**
+	 * Every time a block is (re)filled with image data it gets a new generation.  mvsim_simulate_view_async skips the upload of
+	 * a ground truth whose host pointer AND generation it has seen already; blocks are pooled by size, so a second dataset of
+	 * the same size lands at the SAME host address -- only the generation tells the library that the contents changed.
+	 */
+	private static final AtomicLong GENERATION = new AtomicLong( 1 );
+
+	/** floats per z-slab block of a large volume: one direct ByteBuffer holds at most 2^31 - 1 bytes */
+	static final long MAX_BLOCK_FLOATS = 1L << 28;
+
 	static final class Block implements AutoCloseable
 	{
 		final ByteBuffer bytes;
 		final FloatBuffer floats;
 		final boolean pinned;
+		/** identity of the contents (see {@link #GENERATION}); 0 for a block that holds no image data yet */
+		long generation = 0;
 		private boolean open = true;
 
 		Block( final ByteBuffer bytes, final boolean pinned )
@@ -70,7 +85,7 @@ final class Buffers
 	static Block direct( final long n )
 	{
 		if ( n > Integer.MAX_VALUE / 4 )
-			throw new IllegalArgumentException( "image has more than 2^29 voxels: pass z-slabs (simulateViewSlabs, INTEGRATION.md)" );
+			throw new IllegalArgumentException( "one staging block holds at most 2^29 - 1 floats: larger volumes travel as z slabs (Buffers.Slabs)" );
 		final long bytes = 4 * Math.max( n, 1 );
 		final Pool pool = POOL.get();
 		final ArrayDeque< ByteBuffer > q = pool.free.get( bytes );
@@ -140,6 +155,7 @@ final class Buffers
 					b.put( c.next().get() );
 			}
 			b.rewind();
+			blk.generation = GENERATION.getAndIncrement();
 			return blk;
 		}
 		catch ( final RuntimeException e )
@@ -147,6 +163,121 @@ final class Buffers
 			blk.close();
 			throw e;
 		}
+	}
+
+	/**
+	 * A volume as a list of z-slab blocks (whole planes each, at most {@link #MAX_BLOCK_FLOATS} floats per block): the form in
+	 * which the per-stage operators hand images to the native side.  A 512^3 image is ONE slab; a 1024^3 ArrayImg (2^30
+	 * voxels: fine for ImgLib2, SimulateMultiViewDataset.java:109, but four times what one direct buffer holds) becomes four.
+	 */
+	static final class Slabs implements AutoCloseable
+	{
+		final List< Block > blocks = new ArrayList<>();
+		final long[] nz;            // planes per slab
+		final long[] dim;           // { nx, ny, planes in total }
+
+		Slabs( final long nx, final long ny, final long planes )
+		{
+			dim = new long[] { nx, ny, planes };
+			final long plane = nx * ny;
+			if ( plane > MAX_BLOCK_FLOATS )
+				throw new IllegalArgumentException( "a single plane of " + plane + " voxels exceeds one staging block" );
+			final long per = Math.max( 1, MAX_BLOCK_FLOATS / plane );
+			final int count = ( int ) ( ( planes + per - 1 ) / per );
+			nz = new long[ count ];
+			try
+			{
+				for ( int i = 0; i < count; ++i )
+				{
+					nz[ i ] = Math.min( per, planes - i * per );
+					blocks.add( direct( plane * nz[ i ] ) );
+				}
+			}
+			catch ( final RuntimeException e )
+			{
+				close();
+				throw e;
+			}
+		}
+
+		FloatBuffer[] buffers()
+		{
+			final FloatBuffer[] f = new FloatBuffer[ blocks.size() ];
+			for ( int i = 0; i < f.length; ++i )
+				f[ i ] = blocks.get( i ).floats;
+			return f;
+		}
+
+		@Override
+		public void close()
+		{
+			for ( final Block b : blocks )
+				b.close();
+			blocks.clear();
+		}
+	}
+
+	/** Any RAI view -> z-slab blocks in flat iteration order (x fastest). */
+	static Slabs toSlabs( final RandomAccessibleInterval< FloatType > rai )
+	{
+		final long[] d = dims( rai );
+		final Slabs s = new Slabs( d[ 0 ], d[ 1 ], d[ 2 ] );
+		try
+		{
+			final long plane = d[ 0 ] * d[ 1 ];
+			if ( rai instanceof ArrayImg && ( ( ArrayImg< ?, ? > ) rai ).update( null ) instanceof FloatArray )
+			{
+				final float[] a = ( ( FloatArray ) ( ( ArrayImg< ?, ? > ) rai ).update( null ) ).getCurrentStorageArray();
+				long off = 0;
+				for ( int i = 0; i < s.nz.length; ++i )
+				{
+					final long n = plane * s.nz[ i ];
+					final FloatBuffer b = s.blocks.get( i ).floats;
+					b.put( a, ( int ) off, ( int ) n );           // off + n <= a.length < 2^31
+					b.rewind();
+					off += n;
+				}
+			}
+			else
+			{
+				final Cursor< FloatType > c = Views.flatIterable( rai ).cursor();
+				for ( int i = 0; i < s.nz.length; ++i )
+				{
+					final FloatBuffer b = s.blocks.get( i ).floats;
+					for ( long k = plane * s.nz[ i ]; k > 0; --k )
+						b.put( c.next().get() );
+					b.rewind();
+				}
+			}
+			final long g = GENERATION.getAndIncrement();
+			for ( final Block b : s.blocks )
+				b.generation = g;
+			return s;
+		}
+		catch ( final RuntimeException e )
+		{
+			s.close();
+			throw e;
+		}
+	}
+
+	/** a fresh ArrayImg holding the slabs' planes (up to 2^31 - 1 voxels: the limit of ArrayImg itself) */
+	static Img< FloatType > toImg( final Slabs s )
+	{
+		final long n = size( s.dim );
+		if ( n > Integer.MAX_VALUE )
+			throw new IllegalArgumentException( "an ArrayImg holds at most 2^31 - 1 voxels (the reference has the same limit)" );
+		final float[] a = new float[ ( int ) n ];
+		final long plane = s.dim[ 0 ] * s.dim[ 1 ];
+		long off = 0;
+		for ( int i = 0; i < s.nz.length; ++i )
+		{
+			final FloatBuffer b = s.blocks.get( i ).floats;
+			b.rewind();
+			b.get( a, ( int ) off, ( int ) ( plane * s.nz[ i ] ) );
+			off += plane * s.nz[ i ];
+		}
+		return ArrayImgs.floats( a, s.dim );
 	}
 
 	/** a fresh ArrayImg holding the block's first size(d) floats (the block stays owned by the caller) */

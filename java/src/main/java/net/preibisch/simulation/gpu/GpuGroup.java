@@ -51,7 +51,7 @@ public final class GpuGroup implements AutoCloseable
 				af[ v ] = a[ v ].floats;
 				seeds[ v ] = rnd.nextLong();
 			}
-			MvsimNative.groupSimulateViews( handle, pf, Buffers.dims( psfs.get( 0 ) ), degrees, attenuation, SimulateMultiViewDatasetGPU.minValue,
+			MvsimNative.groupSimulateViews( handle, pf, Buffers.dims( psfs.get( 0 ) ), dim, degrees, attenuation, SimulateMultiViewDatasetGPU.minValue,
 					SimulateMultiViewDatasetGPU.avgIntensity, lightsheetSpacing, poissonSNR, seeds, af );
 			final List< Img< FloatType > > res = new ArrayList<>();
 			for ( int v = 0; v < n; ++v )

@@ -32,6 +32,15 @@ final class MvsimNative
 	static native void computeWeightImage( long ctx, long[] dim, FloatBuffer out );
 	static native void axisRotation( long[] dim, int axis, int degrees, double[] m12 );
 
+	// the per-stage operators with volumes as z-slab lists (mvsim_*_zslabs): in[i] holds inNz[i] planes, out[j] receives outNz[j];
+	// this is how images beyond one 2 GiB direct buffer (2^29 voxels) cross the boundary -- a 512^3 image is a list of one
+	static native void rotateAroundAxisSlabs( long ctx, FloatBuffer[] in, long[] inNz, long[] dim, int axis, int degrees, FloatBuffer[] out, long[] outNz );
+	static native void attenuate3dSlabs( long ctx, FloatBuffer[] in, long[] inNz, long[] dim, double delta, FloatBuffer[] out, long[] outNz );
+	static native void convolveSlabs( long ctx, FloatBuffer[] in, long[] inNz, long[] dim, FloatBuffer psf, long[] kdim, int method,
+			FloatBuffer[] out, long[] outNz );
+	static native void extractSlicesSlabs( long ctx, FloatBuffer[] in, long[] inNz, long[] dim, int inc, float snr, long seed, int stream,
+			FloatBuffer[] out, long[] outNz );
+
 	/** mvsim_host_alloc wrapped by NewDirectByteBuffer: a page-locked block (null if the allocation fails); freePinned releases it. */
 	static native java.nio.ByteBuffer allocPinned( long ctx, long bytes );
 	static native void freePinned( java.nio.ByteBuffer block );
@@ -64,6 +73,7 @@ final class MvsimNative
 	static native long groupCreate( int ndev );
 	static native void groupDestroy( long group );
 	static native void groupBroadcastVolume( long group, FloatBuffer gt, long[] dim );
-	static native void groupSimulateViews( long group, FloatBuffer[] psfs, long[] kdim, int[] degrees, double delta, float minValue,
+	/** dim = the dimensions given to groupBroadcastVolume: the shim checks every acquisition buffer against them */
+	static native void groupSimulateViews( long group, FloatBuffer[] psfs, long[] kdim, long[] dim, int[] degrees, double delta, float minValue,
 			float targetAverage, int inc, float snr, long[] seeds, FloatBuffer[] acqs );
 }

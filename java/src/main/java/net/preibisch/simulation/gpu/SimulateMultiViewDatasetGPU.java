@@ -24,7 +24,8 @@ import net.imglib2.view.Views;
  * pass new Random(seed) stay reproducible (distributional, not stream, parity: DESIGN.md).  drawSpheres, whose
  * stream the reference shares with everything else, consumes the caller's generator exactly as the reference does.
  *
- * SOURCE ONLY in this repository (no JDK in the build image): never compiled or run here.
+ * SOURCE ONLY in this repository (no JDK in the build image): never compiled or run here (the JNI shim gets a syntax-only
+ * compile against a hand-written jni.h subset, tests/jni_stub -- a compile check, it pins nothing).
  */
 public class SimulateMultiViewDatasetGPU
 {
@@ -41,23 +42,27 @@ public class SimulateMultiViewDatasetGPU
 		return model;
 	}
 
+	// The four per-stage operators take ANY image an ArrayImg can hold (up to 2^31 - 1 voxels, the reference's own limit,
+	// SimulateMultiViewDataset.java:109): volumes cross the boundary as z-slab lists of page-locked blocks (Buffers.Slabs), one
+	// block for everything up to 2^28 voxels, several beyond -- a 1024^3 image is four.
+
 	public static Img< FloatType > rotateAroundAxis( final RandomAccessibleInterval< FloatType > in, final int axis, final int degrees )
 	{
 		final long[] d = Buffers.dims( in );
-		try ( Buffers.Block src = Buffers.toBlock( Views.zeroMin( in ) ); Buffers.Block out = Buffers.direct( Buffers.size( d ) ) )
+		try ( Buffers.Slabs src = Buffers.toSlabs( Views.zeroMin( in ) ); Buffers.Slabs out = new Buffers.Slabs( d[ 0 ], d[ 1 ], d[ 2 ] ) )
 		{
-			MvsimNative.rotateAroundAxis( GpuContextPool.get(), src.floats, d, axis, degrees, out.floats );
-			return Buffers.toImg( out, d );
+			MvsimNative.rotateAroundAxisSlabs( GpuContextPool.get(), src.buffers(), src.nz, d, axis, degrees, out.buffers(), out.nz );
+			return Buffers.toImg( out );
 		}
 	}
 
 	public static Img< FloatType > attenuate3d( final RandomAccessibleInterval< FloatType > in, final double delta )
 	{
 		final long[] d = Buffers.dims( in );
-		try ( Buffers.Block src = Buffers.toBlock( Views.zeroMin( in ) ); Buffers.Block out = Buffers.direct( Buffers.size( d ) ) )
+		try ( Buffers.Slabs src = Buffers.toSlabs( Views.zeroMin( in ) ); Buffers.Slabs out = new Buffers.Slabs( d[ 0 ], d[ 1 ], d[ 2 ] ) )
 		{
-			MvsimNative.attenuate3d( GpuContextPool.get(), src.floats, d, delta, out.floats );
-			return Buffers.toImg( out, d );
+			MvsimNative.attenuate3dSlabs( GpuContextPool.get(), src.buffers(), src.nz, d, delta, out.buffers(), out.nz );
+			return Buffers.toImg( out );
 		}
 	}
 
@@ -65,11 +70,11 @@ public class SimulateMultiViewDatasetGPU
 	public static Img< FloatType > convolve( final Img< FloatType > img, final Img< FloatType > psf, final ExecutorService service )
 	{
 		final long[] d = Buffers.dims( img ), k = Buffers.dims( psf );
-		try ( Buffers.Block p = Buffers.toBlock( psf ); Buffers.Block src = Buffers.toBlock( img ); Buffers.Block out = Buffers.direct( Buffers.size( d ) ) )
+		try ( Buffers.Block p = Buffers.toBlock( psf ); Buffers.Slabs src = Buffers.toSlabs( img ); Buffers.Slabs out = new Buffers.Slabs( d[ 0 ], d[ 1 ], d[ 2 ] ) )
 		{
-			MvsimNative.convolve( GpuContextPool.get(), src.floats, d, p.floats, k, 0, out.floats );
+			MvsimNative.convolveSlabs( GpuContextPool.get(), src.buffers(), src.nz, d, p.floats, k, 0, out.buffers(), out.nz );
 			Buffers.copyBack( p, psf );   // Tools.normImage( psf ) side effect of the reference (:255)
-			return Buffers.toImg( out, d );
+			return Buffers.toImg( out );
 		}
 	}
 
@@ -83,10 +88,10 @@ public class SimulateMultiViewDatasetGPU
 		final long[] d = Buffers.dims( in );
 		final long[] o = new long[] { d[ 0 ], d[ 1 ], ( d[ 2 ] - 1 ) / inc + 1 };
 		final long seed = poissonSNR >= 0.0 ? rnd.nextLong() : 0L;
-		try ( Buffers.Block src = Buffers.toBlock( Views.zeroMin( in ) ); Buffers.Block out = Buffers.direct( Buffers.size( o ) ) )
+		try ( Buffers.Slabs src = Buffers.toSlabs( Views.zeroMin( in ) ); Buffers.Slabs out = new Buffers.Slabs( o[ 0 ], o[ 1 ], o[ 2 ] ) )
 		{
-			MvsimNative.extractSlices( GpuContextPool.get(), src.floats, d, inc, poissonSNR, seed, 0, out.floats );
-			return Buffers.toImg( out, o );
+			MvsimNative.extractSlicesSlabs( GpuContextPool.get(), src.buffers(), src.nz, d, inc, poissonSNR, seed, 0, out.buffers(), out.nz );
+			return Buffers.toImg( out );
 		}
 	}
 
@@ -120,6 +125,9 @@ public class SimulateMultiViewDatasetGPU
 			return Buffers.toImg( out, d );
 		}
 	}
+
+	/** simulate() of the reference (:366): the shared static generator */
+	public static Img< FloatType > simulate() { return simulate( false, rnd ); }
 
 	/** simulate (:366-392): sphere cloud at 2x resolution, then 2x down-sampling; any java.util.Random. */
 	public static Img< FloatType > simulate( final boolean halfPixelOffset, final Random rnd )
@@ -302,7 +310,7 @@ public class SimulateMultiViewDatasetGPU
 				}
 				psf[ s ] = Buffers.toBlock( psfs.get( v ) );
 				acq[ s ] = Buffers.direct( Buffers.size( o ) );
-				ticket[ s ] = MvsimNative.simulateViewAsync( ctx, gt.floats, 0L, d, psf[ s ].floats, Buffers.dims( psfs.get( v ) ), 0, degrees[ v ],
+				ticket[ s ] = MvsimNative.simulateViewAsync( ctx, gt.floats, gt.generation, d, psf[ s ].floats, Buffers.dims( psfs.get( v ) ), 0, degrees[ v ],
 						attenuation, minValue, avgIntensity, lightsheetSpacing, poissonSNR, rnd.nextLong(), v, acq[ s ].floats );
 			}
 			// the last two views, in order
@@ -325,5 +333,80 @@ public class SimulateMultiViewDatasetGPU
 				if ( psf[ s ] != null ) psf[ s ].close();
 			}
 		}
+	}
+
+	/**
+	 * The driver of the reference, SimulateMultiViewDataset.main (:524-665), on the GPU operators: same hard-coded parameters
+	 * (:531-548: SNR 25, light-sheet spacing 3, attenuation 0.01f, seven angles at 52 degree steps, OSEM 3, angle offset 15),
+	 * same stages per angle, same output files next to the PSF stacks (:526, :561-562, :598-604, :645, :663).  File I/O and the
+	 * window toolkit stay the reference's own (net.preibisch.simulation.Tools.open / save, ij.ImageJ).
+	 */
+	public static void main( final String[] args )
+	{
+		final String dir = "src/main/resources/";
+		final java.util.concurrent.ExecutorService service = java.util.concurrent.Executors.newFixedThreadPool( Runtime.getRuntime().availableProcessors() );
+
+		new ij.ImageJ();
+
+		final float poissonSNR = 25f;
+		final int lightsheetSpacing = 3;
+		final float attenuation = 0.01f;
+		final int angleIncrement = 52;       // seven angles
+		final float osem = 3.0f;
+		final int angleOffset = 15;          // so that everything is rotated at least once
+
+		System.out.println( new java.util.Date( System.currentTimeMillis() ) + ": rendering basis for ground truth" );
+		final Img< FloatType > rendered = simulate( false, rnd );
+
+		System.out.println( new java.util.Date( System.currentTimeMillis() ) + ": computing ground truth" );
+		final Img< FloatType > obj = rotateAroundAxis( rendered, 0, angleOffset );
+
+		net.preibisch.simulation.Tools.save( rendered, dir + "rendered.tif" );
+		net.preibisch.simulation.Tools.save( obj, dir + "groundtruth.tif" );
+
+		final ArrayList< Img< FloatType > > weights = new ArrayList< Img< FloatType > >();
+
+		for ( int angle = 0; angle < 360; angle += angleIncrement )
+		{
+			System.out.println( new java.util.Date( System.currentTimeMillis() ) + ": view at angle " + angle );
+			final Img< FloatType > psf = net.preibisch.simulation.Tools.open( dir + "Angle" + angle + ".tif", true );
+			// rotate, attenuate, convolve, adjustImage, extractSlices (:570-585) as ONE native call, every intermediate kept
+			final Img< FloatType >[] v = simulateView( rendered, psf, angle + angleOffset, attenuation, lightsheetSpacing, poissonSNR, rnd, angle / angleIncrement );
+			final Img< FloatType > rot = v[ 0 ], att = v[ 1 ], con = v[ 2 ], acq = v[ 3 ];
+			final Img< FloatType > w = computeWeightImage( rot, attenuation );
+			final Img< FloatType > iso = makeIsotropic( acq, lightsheetSpacing );
+			final Img< FloatType > view = rotateAroundAxis( iso, 0, -angle );
+			final Img< FloatType > viewWeights = rotateAroundAxis( w, 0, -angle );
+			final Img< FloatType > viewPSF = rotateAroundAxis( psf, 0, -angle );
+
+			net.preibisch.simulation.Tools.save( rot, dir + "rot_view_" + angle + ".tif" );
+			net.preibisch.simulation.Tools.save( att, dir + "att_view_" + angle + ".tif" );
+			net.preibisch.simulation.Tools.save( con, dir + "con_view_" + angle + ".tif" );
+			net.preibisch.simulation.Tools.save( acq, dir + "acq_view_" + angle + ".tif" );
+			net.preibisch.simulation.Tools.save( iso, dir + "iso_view_" + angle + ".tif" );
+			net.preibisch.simulation.Tools.save( view, dir + "aligned_view_" + angle + ".tif" );
+			net.preibisch.simulation.Tools.save( viewPSF, dir + "aligned_view_psf_" + angle + ".tif" );
+
+			weights.add( viewWeights );
+		}
+
+		// norm sum weights to osem (:615-640)
+		normalizeWeights( weights, osem );
+
+		for ( int i = 0; i < weights.size(); ++i )
+			net.preibisch.simulation.Tools.save( weights.get( i ), dir + "aligned_view_weights" + ( i * angleIncrement ) + ".tif" );
+
+		// sum of the normalised weights (:647-663)
+		final Img< FloatType > sumWeights = weights.get( 0 ).factory().create( weights.get( 0 ), weights.get( 0 ).firstElement() );
+		for ( final Img< FloatType > w : weights )
+		{
+			final net.imglib2.Cursor< FloatType > s = sumWeights.cursor();
+			final net.imglib2.Cursor< FloatType > c = w.cursor();
+			while ( s.hasNext() )
+				s.next().add( c.next() );
+		}
+		net.preibisch.simulation.Tools.save( sumWeights, dir + "sum_weights.tif" );
+		service.shutdown();
+		System.out.println( "done" );
 	}
 }

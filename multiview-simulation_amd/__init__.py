@@ -424,6 +424,34 @@ class Context:
                                                       C.byref(params), aa, an, len(acq), C.byref(corr)))
         return acq, corr.value
 
+    def stage_zslabs(self, op: str, in_slabs: list, out_slab_nz: list, **kw) -> list:
+        """The per-stage operators on host buffers given as z slabs (``mvsim_*_zslabs``): op in {"rotate", "attenuate",
+        "convolve", "extract"}; keyword arguments as the single-buffer methods take them.  Returns the output slabs."""
+        gs = [np.ascontiguousarray(g, dtype=np.float32) for g in in_slabs]
+        ny, nx = gs[0].shape[1:]
+        nz = sum(g.shape[0] for g in gs)
+        outs = [np.empty((int(k), ny, nx), dtype=np.float32) for k in out_slab_nz]
+        ga = (C.c_void_p * len(gs))(*[g.ctypes.data for g in gs])
+        gn = (C.c_int64 * len(gs))(*[g.shape[0] for g in gs])
+        oa = (C.c_void_p * len(outs))(*[a.ctypes.data for a in outs])
+        on = (C.c_int64 * len(outs))(*[a.shape[0] for a in outs])
+        dim = (C.c_int64 * 3)(nx, ny, nz)
+        L = self._L
+        if op == "rotate":
+            rc = L.mvsim_rotate_around_axis_zslabs(self._h, ga, gn, len(gs), dim, kw["axis"], kw["degrees"], oa, on, len(outs))
+        elif op == "attenuate":
+            rc = L.mvsim_attenuate3d_zslabs(self._h, ga, gn, len(gs), dim, kw["delta"], oa, on, len(outs))
+        elif op == "convolve":
+            psf = kw["psf"]
+            _check_inplace(psf, "psf")
+            rc = L.mvsim_convolve_zslabs(self._h, ga, gn, len(gs), dim, _ptr(psf), _dim(psf), kw.get("method", 0), oa, on, len(outs))
+        elif op == "extract":
+            rc = L.mvsim_extract_slices_zslabs(self._h, ga, gn, len(gs), dim, kw["inc"], kw["snr"], kw["seed"], kw.get("stream", 0), oa, on, len(outs))
+        else:
+            raise ValueError(f"unknown stage {op!r}")
+        _lib.check(rc)
+        return outs
+
     def simulate_view_dev(self, gt_dptr: int, dim_xyz, psf: np.ndarray, params: ViewParams, acq_dptr: int,
                           rot_dptr: int = 0, att_dptr: int = 0, con_dptr: int = 0, want_corr: bool = False):
         """Device-resident buffers (raw HBM addresses); asynchronous unless ``want_corr``."""

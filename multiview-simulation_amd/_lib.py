@@ -113,6 +113,11 @@ SIGNATURES = {
     "mvsim_simulate_view_zslabs": (C.c_int, [_vp, C.POINTER(_vp), _i64p, C.c_int, _i64p, _vp, _i64p, C.POINTER(ViewParams),
                                              C.POINTER(_vp), _i64p, C.c_int, C.POINTER(C.c_double)]),
     "mvsim_fft_geometry": (C.c_int, [_i64p, _i64p, _i64p]),
+    "mvsim_rotate_around_axis_zslabs": (C.c_int, [_vp, C.POINTER(_vp), _i64p, C.c_int, _i64p, C.c_int, C.c_int, C.POINTER(_vp), _i64p, C.c_int]),
+    "mvsim_attenuate3d_zslabs": (C.c_int, [_vp, C.POINTER(_vp), _i64p, C.c_int, _i64p, C.c_double, C.POINTER(_vp), _i64p, C.c_int]),
+    "mvsim_convolve_zslabs": (C.c_int, [_vp, C.POINTER(_vp), _i64p, C.c_int, _i64p, _vp, _i64p, C.c_int, C.POINTER(_vp), _i64p, C.c_int]),
+    "mvsim_extract_slices_zslabs": (C.c_int, [_vp, C.POINTER(_vp), _i64p, C.c_int, _i64p, C.c_int, C.c_float, C.c_uint64, C.c_uint32,
+                                              C.POINTER(_vp), _i64p, C.c_int]),
     "mvsim_stencil_geometry": (C.c_int, [_i64p, _i64p]),
     "mvsim_enable_timing": (C.c_int, [_vp, C.c_int]),
     "mvsim_get_timings": (C.c_int, [_vp, C.POINTER(Timings)]),

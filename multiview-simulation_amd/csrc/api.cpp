@@ -1415,6 +1415,101 @@ int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, con
     return rc;
 }
 
+// ---- per-stage operators on host buffers given as z slabs (volumes beyond one 2 GiB direct buffer) --------------------
+namespace {
+struct SlabList {
+    const void* const* ptr;
+    const int64_t*     nz;
+    int                count;
+};
+int check_slabs(const SlabList& l, int64_t planes, const char* what)
+{
+    if (!l.ptr || !l.nz || l.count < 1) { set_error("invalid argument: %s slab list is empty", what); return MVSIM_EINVAL; }
+    int64_t z = 0;
+    for (int i = 0; i < l.count; ++i) {
+        if (!l.ptr[i] || l.nz[i] < 1) { set_error("invalid argument: %s slab %d is empty", what, i); return MVSIM_EINVAL; }
+        z += l.nz[i];
+    }
+    if (z != planes) { set_error("invalid argument: %s slabs hold %lld planes, expected %lld", what, (long long)z, (long long)planes); return MVSIM_EINVAL; }
+    return MVSIM_OK;
+}
+int upload_slabs(mvsim_ctx* ctx, const SlabList& l, int64_t plane, float* dev)
+{
+    int64_t z = 0;
+    for (int i = 0; i < l.count; ++i) {
+        MVSIM_HIP(hipMemcpyAsync(dev + plane * z, l.ptr[i], (size_t)(plane * l.nz[i]) * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        z += l.nz[i];
+    }
+    return MVSIM_OK;
+}
+int download_slabs(mvsim_ctx* ctx, const SlabList& l, int64_t plane, const float* dev)
+{
+    int rc = MVSIM_OK;
+    int64_t z = 0;
+    for (int i = 0; i < l.count && rc == MVSIM_OK; ++i) {
+        if (hipMemcpyAsync(const_cast<void*>(l.ptr[i]), dev + plane * z, (size_t)(plane * l.nz[i]) * sizeof(float), hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess) { set_error("download of slab %d failed", i); rc = MVSIM_EHIP; }
+        z += l.nz[i];
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MVSIM_OK) { set_error("stream synchronise failed"); rc = MVSIM_EHIP; }
+    return rc;
+}
+// stage the input slabs in vol_a, make room for `out_planes` planes in vol_b
+int slabs_in(mvsim_ctx* ctx, const float* const* in_slabs, const int64_t* in_nz, int n_in, const int64_t dim[3], float* const* out_slabs,
+             const int64_t* out_nz, int n_out, int64_t out_planes, SlabList* in, SlabList* out)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    *in = SlabList{reinterpret_cast<const void* const*>(in_slabs), in_nz, n_in};
+    *out = SlabList{reinterpret_cast<const void* const*>(out_slabs), out_nz, n_out};
+    MVSIM_TRY(check_slabs(*in, dim[2], "input"));
+    MVSIM_TRY(check_slabs(*out, out_planes, "output"));
+    const int64_t plane = dim[0] * dim[1];
+    MVSIM_TRY(ctx->vol_a.reserve((size_t)(plane * dim[2]) * sizeof(float)));
+    MVSIM_TRY(ctx->vol_b.reserve((size_t)(plane * out_planes) * sizeof(float)));
+    return upload_slabs(ctx, *in, plane, ctx->vol_a.as<float>());
+}
+}  // namespace
+
+int mvsim_rotate_around_axis_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const int64_t* in_slab_nz, int n_in, const int64_t dim[3],
+                                    int axis, int degrees, float* const* out_slabs, const int64_t* out_slab_nz, int n_out)
+{
+    SlabList in, out;
+    MVSIM_TRY(slabs_in(ctx, in_slabs, in_slab_nz, n_in, dim, out_slabs, out_slab_nz, n_out, dim ? dim[2] : 0, &in, &out));
+    MVSIM_TRY(mvsim_rotate_around_axis_dev(ctx, ctx->vol_a.as<float>(), dim, axis, degrees, ctx->vol_b.as<float>()));
+    return download_slabs(ctx, out, dim[0] * dim[1], ctx->vol_b.as<float>());
+}
+
+int mvsim_attenuate3d_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const int64_t* in_slab_nz, int n_in, const int64_t dim[3],
+                             double delta, float* const* out_slabs, const int64_t* out_slab_nz, int n_out)
+{
+    SlabList in, out;
+    MVSIM_TRY(slabs_in(ctx, in_slabs, in_slab_nz, n_in, dim, out_slabs, out_slab_nz, n_out, dim ? dim[2] : 0, &in, &out));
+    MVSIM_TRY(mvsim_attenuate3d_dev(ctx, ctx->vol_a.as<float>(), dim, delta, ctx->vol_b.as<float>()));
+    return download_slabs(ctx, out, dim[0] * dim[1], ctx->vol_b.as<float>());
+}
+
+int mvsim_convolve_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const int64_t* in_slab_nz, int n_in, const int64_t dim[3],
+                          float* psf, const int64_t kdim[3], int method, float* const* out_slabs, const int64_t* out_slab_nz, int n_out)
+{
+    SlabList in, out;
+    MVSIM_TRY(slabs_in(ctx, in_slabs, in_slab_nz, n_in, dim, out_slabs, out_slab_nz, n_out, dim ? dim[2] : 0, &in, &out));
+    MVSIM_TRY(mvsim_convolve_dev(ctx, ctx->vol_a.as<float>(), dim, psf, kdim, method, ctx->vol_b.as<float>()));
+    return download_slabs(ctx, out, dim[0] * dim[1], ctx->vol_b.as<float>());
+}
+
+int mvsim_extract_slices_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const int64_t* in_slab_nz, int n_in, const int64_t dim[3],
+                                int inc, float snr, uint64_t seed, uint32_t stream, float* const* out_slabs, const int64_t* out_slab_nz,
+                                int n_out)
+{
+    MVSIM_CHECK_ARG(inc >= 1, "inc must be >= 1");
+    SlabList in, out;
+    MVSIM_TRY(slabs_in(ctx, in_slabs, in_slab_nz, n_in, dim, out_slabs, out_slab_nz, n_out, dim ? mvsim_extract_nz(dim[2], inc) : 0, &in, &out));
+    MVSIM_TRY(mvsim_extract_slices_dev(ctx, ctx->vol_a.as<float>(), dim, inc, snr, seed, stream, ctx->vol_b.as<float>()));
+    MVSIM_TRY(join_tail(ctx));
+    return download_slabs(ctx, out, dim[0] * dim[1], ctx->vol_b.as<float>());
+}
+
 int mvsim_stencil_geometry(const int64_t kdim[3], int64_t geometry[5])
 {
     if (!kdim || !geometry) { set_error("invalid argument: null pointer"); return MVSIM_EINVAL; }

@@ -1151,6 +1151,25 @@ def test_async_pipelined_views_equal_synchronous_views(ctx, synth):
         ctx.wait(10_000)
 
 
+def test_async_ground_truth_cache_is_dropped_when_the_staging_buffer_changes(mvs, synth):
+    """the upload of a ground truth is skipped only while the staging set really holds it -- a view of another size
+    (the staging buffer moves or is laid out differently) and a host block that went back to the allocator both invalidate
+    the (pointer, generation) pair, whatever generation the caller keeps passing."""
+    with mvs.Context(0) as c:
+        small, big = synth.sphere_phantom(40), synth.sphere_phantom(56)
+        psf = synth.gaussian_psf(7, sigma=(1.1, 1.2, 1.6))
+        p = c.view_params(degrees=33, inc=2, snr=25.0, seed=SEED, stream=1)
+        hs, hb = c.pinned_empty(small.shape), c.pinned_empty(big.shape)
+        hs[...] = small
+        hb[...] = big
+        want_s = c.simulate_view(small, psf.copy(), p)["acq"]
+        want_b = c.simulate_view(big, psf.copy(), p)["acq"]
+        for src, want in ((hs, want_s), (hs, want_s), (hb, want_b), (hb, want_b), (hs, want_s), (hb, want_b), (hs, want_s)):
+            out = {"acq": c.pinned_empty(want.shape)}
+            c.wait(c.simulate_view_async(src, psf.copy(), p, out, gt_generation=0))
+            assert np.array_equal(out["acq"], want)
+
+
 def test_view_from_z_slab_host_buffers(ctx, synth):
     """mvsim_simulate_view_zslabs: ground truth and acquisition as lists of z slabs (the host convention for volumes
     beyond 2^31-1 voxels) -- same voxels as the single-buffer entry point."""
@@ -1163,6 +1182,29 @@ def test_view_from_z_slab_host_buffers(ctx, synth):
     assert np.array_equal(np.concatenate(acq, axis=0), ref["acq"])
     with pytest.raises(ValueError):
         ctx.simulate_view_zslabs([gt[:7], gt[7:30]], psf.copy(), p, [14])          # slabs do not add up to the volume
+
+
+def test_stage_operators_from_z_slab_host_buffers(ctx, synth):
+    """mvsim_{rotate_around_axis,attenuate3d,convolve,extract_slices}_zslabs: the per-stage operators the reference's call
+    sites use (SimulateMultiViewDataset.java:570-585), with volumes handed over as lists of z slabs -- what the Java facade
+    does beyond 2^29 voxels (one direct buffer holds 2 GiB, an ArrayImg four times that).  Same voxels as the single-buffer
+    operators, for ragged slab lists on both sides; slab lists that do not add up are rejected."""
+    gt = synth.sphere_phantom(48)
+    cut = lambda a, edges: [a[lo:hi] for lo, hi in zip(edges, edges[1:])]
+    rot = ctx.stage_zslabs("rotate", cut(gt, [0, 5, 6, 30, 48]), [20, 28], axis=0, degrees=33)
+    assert np.array_equal(np.concatenate(rot), ctx.rotate_around_axis(gt, 0, 33))
+    att = ctx.stage_zslabs("attenuate", cut(gt, [0, 47, 48]), [1, 47], delta=0.01)
+    assert np.array_equal(np.concatenate(att), ctx.attenuate3d(gt, 0.01))
+    psf = synth.gaussian_psf(7, sigma=(1.1, 1.2, 1.8))
+    p1, p2 = psf.copy(), psf.copy()
+    con = ctx.stage_zslabs("convolve", cut(gt, [0, 16, 32, 48]), [48], psf=p1, method=1)
+    assert np.array_equal(np.concatenate(con), ctx.convolve(gt, p2, method=1)) and np.array_equal(p1, p2)
+    ext = ctx.stage_zslabs("extract", cut(gt, [0, 24, 48]), [3, 13], inc=3, snr=25.0, seed=SEED, stream=2)
+    assert np.array_equal(np.concatenate(ext), ctx.extract_slices(gt, 3, 25.0, SEED, 2))
+    with pytest.raises(ValueError):
+        ctx.stage_zslabs("rotate", cut(gt, [0, 24, 47]), [48], axis=0, degrees=10)       # input one plane short
+    with pytest.raises(ValueError):
+        ctx.stage_zslabs("extract", cut(gt, [0, 48]), [17], inc=3, snr=-1.0, seed=0)     # (48 - 1) / 3 + 1 = 16 planes
 
 
 @pytest.mark.parametrize("shape,kshape", [((32, 32, 32), (9, 7, 7)), ((24, 40, 36), (5, 8, 6)), ((17, 23, 19), (7, 3, 5)),
