@@ -23,7 +23,9 @@ struct __attribute__((aligned(16))) RowGeoF {
     int       kind;             // 0 none, 1 all four taps inside, 2 partial: bits 8..11 = inside(00, 10, 11, 01)
     int       pad;
 };
-constexpr int GEO_CHUNK_F = 512;
+// rows per LDS geometry table: 512 (24 KB) for blocks of up to 8 waves, 128 for the 16-wave blocks of rows longer than 512
+// voxels, whose double-buffered 16-row transform rounds take 144 KB of the CU's 160
+constexpr int geo_chunk_f(int G) { return G == 1 ? 512 : 128; }
 constexpr int UF = 8;
 // rows of the NEXT batch requested before this batch's transforms (their latency would hide behind the FFTs).  Measured at
 // 512^3: 0 -> 0.43 ms, 2 -> 0.46 ms, 4 -> 0.46 ms (128 VGPRs, 4 spilled): the kernel is bound by vector issue (32.6 k VALU
@@ -32,13 +34,16 @@ constexpr int UF = 8;
 #define MVSIM_ROTFFT_PREFETCH 0
 #endif
 
-template <class PLAN, bool WRITE_OUT>
+// G: batches of U rows per transform round.  One wave transforms one row, so a block of up to 8 waves transforms after every
+// batch (G = 1); a 16-wave block (rows of 513 .. 1024 voxels) collects two batches first (G = 2), or half its waves would
+// sit out every transform.
+template <class PLAN, bool WRITE_OUT, int G>
 __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
 {
-    constexpr int M = PLAN::len, LP = M + 1, U = UF;
+    constexpr int M = PLAN::len, LP = M + 1, U = UF, GEO_CHUNK_F = geo_chunk_f(G);
     extern __shared__ __align__(16) float2 lds[];
-    float2* rowbuf = lds;                                         // [2][U][LP]
-    float2* tw = lds + 2 * U * LP;                                // [M]
+    float2* rowbuf = lds;                                         // [2][G * U][LP]
+    float2* tw = lds + 2 * G * U * LP;                            // [M]
     RowGeoF* geo = reinterpret_cast<RowGeoF*>(tw + M + (M & 1));  // 16-byte aligned: 2 U LP + M (+1) float2 is a multiple of 2
     int* bclass = reinterpret_cast<int*>(geo + GEO_CHUNK_F);
     const int nx = p.nx, ny = p.ny, nz = p.nz, steps = p.steps;
@@ -110,6 +115,19 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
 
     double n = 1.0;
     int buf = 0;
+    int fill = 0;                                                 // batches waiting in the current round buffer (block-uniform)
+    int ysub[G], nsub[G];                                         // first row (y) and row count of each of them
+    // one barrier per round: the rows are complete; every wave transforms its share; the other buffer takes the next round
+    // (a wave reaches the NEXT round's barrier only after its transforms of this one, so two buffers suffice)
+    auto flush_round = [&]() {
+        __syncthreads();
+        for (int j = wave; j < fill * U; j += nwaves) {
+            const int sub = j / U, u = j - sub * U;
+            if (u < nsub[sub]) transform_store(rowbuf + (((size_t)buf * G + sub) * U + u) * LP, ysub[sub] - u);
+        }
+        buf ^= 1;
+        fill = 0;
+    };
     float pv00[U], pv10[U], pv11[U], pv01[U];                     // source rows of a class-1 batch (see issue_loads)
     bool have_pref = false;                                       // block-uniform
     // straight-line loads of a batch whose rows all have their four taps inside the volume: scalar row bases from the
@@ -243,7 +261,10 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
                 }
             }
             // the batch's rows into LDS as the padded real rows pass A would read: position x, the two mirror images, the gap
-            float* __restrict__ rb = reinterpret_cast<float*>(rowbuf + (size_t)buf * U * LP);
+            float* __restrict__ rb = reinterpret_cast<float*>(rowbuf + ((size_t)buf * G + fill) * U * LP);
+            ysub[fill] = y0;
+            nsub[fill] = nrows;
+            fill += 1;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float* __restrict__ rr = rb + (size_t)u * 2 * LP;
@@ -255,10 +276,9 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
             // the next batch's rows are requested BEFORE this batch's transforms: their latency hides behind the FFTs
             have_pref = r0 + U < cnt && __builtin_amdgcn_readfirstlane(bclass[r0 / U + 1]) == 1;
             if (have_pref) issue_loads(r0 + U, std::integral_constant<int, 0>{}, std::integral_constant<int, UPRE>{});
-            __syncthreads();
-            for (int j = wave; j < nrows; j += nwaves) transform_store(rowbuf + ((size_t)buf * U + j) * LP, y0 - j);
-            buf ^= 1;
+            if (fill == G) flush_round();
         }
+        if (fill > 0) flush_round();                              // before the geometry table (and with it nothing the round needs) moves on
     }
     // rows the reference never visits (Ny > Nx): the attenuated image stays zero there; rot still has its values
     for (int yy = ny - 1 - steps; yy >= 0; --yy) {
@@ -296,16 +316,26 @@ static int launch_rot_fftx_t(mvsim_ctx* ctx, const RotFftArgs& a, bool write_out
 {
     constexpr int M = PLAN::len;
     const int waves = (a.nx + 63) / 64;
-    const size_t lds = (size_t)(2 * UF * (M + 1) + M + (M & 1)) * sizeof(float2) + (size_t)GEO_CHUNK_F * sizeof(RowGeoF) +
-                       (size_t)(GEO_CHUNK_F / UF) * sizeof(int);
+    const int G = waves > 8 ? 2 : 1;
+    const size_t lds = (size_t)(2 * G * UF * (M + 1) + M + (M & 1)) * sizeof(float2) + (size_t)geo_chunk_f(G) * sizeof(RowGeoF) +
+                       (size_t)(geo_chunk_f(G) / UF) * sizeof(int);
+    if (lds > 160 * 1024) { set_error("fused rotate + x transform: %zu bytes of LDS", lds); return MVSIM_EINVAL; }
     dim3 grid((unsigned)((a.nz + 7) / 8 * 8)), block((unsigned)(waves * 64));
-    if (write_out) {
-        MVSIM_TRY(ensure_lds_attr(ctx, reinterpret_cast<const void*>(k_rotate_attenuate_fftx<PLAN, true>), lds));
-        hipLaunchKernelGGL((k_rotate_attenuate_fftx<PLAN, true>), grid, block, lds, ctx->stream, a);
-    } else {
-        MVSIM_TRY(ensure_lds_attr(ctx, reinterpret_cast<const void*>(k_rotate_attenuate_fftx<PLAN, false>), lds));
-        hipLaunchKernelGGL((k_rotate_attenuate_fftx<PLAN, false>), grid, block, lds, ctx->stream, a);
+#define MVSIM_RF(W_, G_)                                                                                            \
+    do {                                                                                                            \
+        MVSIM_TRY(ensure_lds_attr(ctx, reinterpret_cast<const void*>(k_rotate_attenuate_fftx<PLAN, W_, G_>), lds)); \
+        hipLaunchKernelGGL((k_rotate_attenuate_fftx<PLAN, W_, G_>), grid, block, lds, ctx->stream, a);              \
+    } while (0)
+    if constexpr (M >= 280) {                                     // rows of more than 512 voxels: padded half length >= 280
+        if (G == 2) {
+            if (write_out) MVSIM_RF(true, 2); else MVSIM_RF(false, 2);
+            MVSIM_HIP(hipGetLastError());
+            return MVSIM_OK;
+        }
     }
+    if (G == 2) { set_error("fused rotate + x transform: no 16-wave instance for half length %d", M); return MVSIM_EINVAL; }
+    if (write_out) MVSIM_RF(true, 1); else MVSIM_RF(false, 1);
+#undef MVSIM_RF
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }

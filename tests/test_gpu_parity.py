@@ -1409,7 +1409,9 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
                                                       ((50, 160, 128), (11, 7, 5), -52, 3),   # Ny > Nx: rows the attenuation never visits
                                                       ((48, 200, 192), (31, 9, 15), 60, 2),   # three waves: rows wrap round the waves
                                                       ((64, 256, 256), (15, 15, 15), 15, 1),
-                                                      ((33, 100, 100), (5, 5, 5), 90, 1)])    # Nx not a multiple of 64 (inactive lanes)
+                                                      ((33, 100, 100), (5, 5, 5), 90, 1),     # Nx not a multiple of 64 (inactive lanes)
+                                                      ((20, 700, 640), (7, 9, 31), 25, 1),    # ten waves: two batches per transform round
+                                                      ((12, 1024, 1024), (5, 5, 15), -40, 2)])  # sixteen waves, 128-row geometry chunks
 def test_fused_rotate_attenuate_x_transform_is_bit_identical(mvs, synth, shape, kshape, degrees, inc):
     """rotate + attenuate + pass A of the convolution as one kernel (rotate_fft.hip, option fused_fftx): the attenuated volume
     no longer crosses HBM, and nothing else changes -- the spectrum it leaves is pass A's bit for bit, so rot, att, the

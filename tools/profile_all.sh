@@ -1,14 +1,15 @@
 #!/bin/bash
 # Collect the rocprofv3 artefacts of profiles/ for the current build (run on the GPU box through gpurun):
-#   bash tools/profile_all.sh r02_x
+#   bash tools/profile_all.sh r03_x
 # kernel trace + stats, then the PMC passes in runs of their own (no trace domains beside --pmc), as
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
-BENCH="bench.py --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams"
+# --serial: the library's default overlaps off, one kernel at a time, so that per-kernel durations add up to the stage times
+BENCH="bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams"
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/trace -o run -- python3 $BENCH > $O/trace.log 2>&1
 python3 tools/kstats.py $O/trace 20 $O/kernel_stats.csv > $O/kernel_stats.txt
