@@ -46,12 +46,21 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
     float2* tw = lds + 2 * G * U * LP;                            // [M]
     RowGeoF* geo = reinterpret_cast<RowGeoF*>(tw + M + (M & 1));  // 16-byte aligned: 2 U LP + M (+1) float2 is a multiple of 2
     int* bclass = reinterpret_cast<int*>(geo + GEO_CHUNK_F);
+    // [2][G][16 waves]: bit u set = the wave's 64 columns of row u of that batch hold a non-zero value (see flush_round)
+    unsigned int* wmask = reinterpret_cast<unsigned int*>(bclass + GEO_CHUNK_F / U);
     const int nx = p.nx, ny = p.ny, nz = p.nz, steps = p.steps;
     const int x = threadIdx.x;
     const int lane = x & 63, wave = __builtin_amdgcn_readfirstlane(x >> 6), nwaves = (int)blockDim.x >> 6;
     // plane order: every XCD gets a contiguous slab of planes (planes z and z + 1 read the same source rows)
+    // Plane order.  Consecutive block ids go to different XCDs (round-robin dispatch, for speed only) and planes z, z + 1 read
+    // the same source rows, so every XCD gets contiguous runs of planes -- TWO runs half a volume apart: the work of a plane
+    // follows its content (empty rows skip the fp64 blends and the transforms), all blocks are resident at once (two per
+    // CU), and a specimen in the middle of the volume would otherwise put all the dense planes on two XCDs
+    // (measured 0.40 -> 0.36 ms at 512^3 on the sphere phantom).
     const int slab = (gridDim.x + 7) / 8;
-    const int z = (int)(blockIdx.x % 8u) * slab + (int)(blockIdx.x / 8u);
+    const int hs = slab / 2, jb = (int)(blockIdx.x / 8u), kb = (int)(blockIdx.x % 8u);
+    const int z = (hs > 0 && slab == 2 * hs) ? ((jb < hs) ? kb * hs + jb : (int)gridDim.x / 2 + kb * hs + (jb - hs))
+                                             : kb * slab + jb;
     if (z >= nz) return;                                          // whole block: uniform
     const bool active = x < nx;
     const long long row = (long long)nx;
@@ -120,10 +129,24 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
     // one barrier per round: the rows are complete; every wave transforms its share; the other buffer takes the next round
     // (a wave reaches the NEXT round's barrier only after its transforms of this one, so two buffers suffice)
     auto flush_round = [&]() {
-        __syncthreads();
+        // LDS-only barrier: __syncthreads() is a workgroup-scope fence as well and drains vmcnt, i.e. it would wait for every
+        // global store of the previous round's spectra (and for the next batch's rows, were they requested ahead) before the
+        // waves may meet.  What the round hands over travels through LDS alone: the wave's own ds_writes are complete
+        // (lgkmcnt(0)), then the barrier; global loads and stores stay in flight across it.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int j = wave; j < fill * U; j += nwaves) {
             const int sub = j / U, u = j - sub * U;
-            if (u < nsub[sub]) transform_store(rowbuf + (((size_t)buf * G + sub) * U + u) * LP, ysub[sub] - u);
+            if (u < nsub[sub]) {
+                // a row without a single non-zero voxel (everything outside the specimen: well over half the rows of a sphere
+                // phantom) has the zero spectrum: no transform, sixteen-byte zero stores.  Exact, not an approximation.
+                unsigned int any = 0u;
+                for (int w = 0; w < nwaves; ++w) any |= wmask[(buf * G + sub) * 16 + w];
+#ifdef MVSIM_EXP_ROTFFT_NOFFT
+                any = 0u;
+#endif
+                if ((__builtin_amdgcn_readfirstlane(any) >> u) & 1u) transform_store(rowbuf + (((size_t)buf * G + sub) * U + u) * LP, ysub[sub] - u);
+                else zero_row(ysub[sub] - u);
+            }
         }
         buf ^= 1;
         fill = 0;
@@ -214,6 +237,22 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
                 issue_loads(r0, std::integral_constant<int, UPRE>{}, std::integral_constant<int, U>{});
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    // four zero taps in EVERY lane of the wave (empty space): rot = +0, the attenuation state does not move
+                    // (n - 0 delta n = n), att = +0 -- what the arithmetic below gives, without the fp64 blends.  Wave-uniform.
+#ifdef MVSIM_EXP_ROTFFT_NOBLEND
+                    const unsigned bits = 0u; val[u] = pv00[u] + pv10[u] + pv11[u] + pv01[u];
+#else
+                    const unsigned bits = __float_as_uint(pv00[u]) | __float_as_uint(pv10[u]) | __float_as_uint(pv11[u]) | __float_as_uint(pv01[u]);
+#endif
+                    if (__builtin_amdgcn_ballot_w64((bits << 1) != 0u) == 0ull) {
+                        val[u] = 0.f;
+                        if (WRITE_OUT && active) {
+                            const long long ob = (out_plane + (long long)(y0 - u) * row) * 4;
+                            if (p.rot_out) *reinterpret_cast<float*>(reinterpret_cast<char*>(p.rot_out) + ob + xoff) = 0.f;
+                            if (p.att_out) *reinterpret_cast<float*>(reinterpret_cast<char*>(p.att_out) + ob + xoff) = 0.f;
+                        }
+                        continue;
+                    }
                     const RowGeoF* g = &geo[r0 + u];
                     float r = (float)((double)pv00[u] * g->w00);
                     r += (float)((double)pv10[u] * g->w10);
@@ -261,6 +300,13 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
                 }
             }
             // the batch's rows into LDS as the padded real rows pass A would read: position x, the two mirror images, the gap
+            {
+                unsigned int rowmask = 0u;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (__builtin_amdgcn_ballot_w64(active && (__float_as_uint(val[u]) << 1) != 0u) != 0ull) rowmask |= 1u << u;
+                if (lane == 0) wmask[(buf * G + fill) * 16 + wave] = rowmask;
+            }
             float* __restrict__ rb = reinterpret_cast<float*>(rowbuf + ((size_t)buf * G + fill) * U * LP);
             ysub[fill] = y0;
             nsub[fill] = nrows;
@@ -318,7 +364,7 @@ static int launch_rot_fftx_t(mvsim_ctx* ctx, const RotFftArgs& a, bool write_out
     const int waves = (a.nx + 63) / 64;
     const int G = waves > 8 ? 2 : 1;
     const size_t lds = (size_t)(2 * G * UF * (M + 1) + M + (M & 1)) * sizeof(float2) + (size_t)geo_chunk_f(G) * sizeof(RowGeoF) +
-                       (size_t)(geo_chunk_f(G) / UF) * sizeof(int);
+                       (size_t)(geo_chunk_f(G) / UF) * sizeof(int) + (size_t)(2 * G * 16) * sizeof(unsigned int);
     if (lds > 160 * 1024) { set_error("fused rotate + x transform: %zu bytes of LDS", lds); return MVSIM_EINVAL; }
     dim3 grid((unsigned)((a.nz + 7) / 8 * 8)), block((unsigned)(waves * 64));
 #define MVSIM_RF(W_, G_)                                                                                            \
