@@ -282,8 +282,20 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
         if k in per_view and ms[k] > 0:
             stages[k]["traffic"] = per_view[k]
             stages[k]["hbm_measured"] = per_view[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    # the x transform of the convolution (pass A) runs INSIDE the rotate + attenuate kernel when the fused kernel is active
+    # (k_rotate_attenuate_fftx): the convolve stage then holds the PSF spectrum and passes B..E only -- said in so many words
+    # below, and the two stages are also reported as one (`rotate_attenuate_convolve`) so that nothing hides in the split
+    x_in_rotate = conv_method == 1 and stage.get("pass_a_ms", 0.0) == 0.0 and stage.get("pass_b_ms", 0.0) > 0.0
+    rc_ms = ms["rotate_attenuate"] + ms["convolve"]
+    rc_alg, rc_fused = alg["rotate_attenuate"] + alg["convolve"], (8 * nvox + 4 * k3 if x_in_rotate else fused["rotate_attenuate"] + fused["convolve"])
+    stages["rotate_attenuate_convolve"] = {
+        "algorithmic_bytes": rc_alg, "ms": round(rc_ms, 4), "GBps": rc_alg / (rc_ms * 1e-3) / 1e9 if rc_ms > 0 else 0.0,
+        "frac": rc_alg / (rc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rc_ms > 0 else 0.0,
+        "fused_bytes": rc_fused, "frac_fused": rc_fused / (rc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rc_ms > 0 else 0.0,
+        "note": "stages rotate_attenuate + convolve taken together (24 N + 4 K^3 algorithmic bytes; fused: ground truth in, convolved volume out)"}
     dom = max(ms, key=ms.get)
-    b_view, b_view_fused = 24 * nvox + 8 * nprime, 16 * nvox + 8 * nprime + 4 * k3
+    b_view = 24 * nvox + 8 * nprime
+    b_view_fused = (8 * nvox + 8 * nprime + 4 * k3) if x_in_rotate else (16 * nvox + 8 * nprime + 4 * k3)
     b_cn = 8 * nvox + 8 * nprime
     cn_ms = ms["convolve"] + ms["extract_poisson"]
     names = {
@@ -291,8 +303,12 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
                     "k_zconv (direct z convolution), k_fft_lines<INV>, k_fft_x_c2r (+ adjust/Poisson epilogue when fused), "
                     "k_reduce_partials",
         "extract_poisson": "extract stage: k_extract4_noise2 + k_poisson_resolve",
-        "rotate_attenuate": "k_rotate_attenuate_axis0_lds",
+        "rotate_attenuate": "k_rotate_attenuate_fftx (rotate + attenuate + x transform)" if x_in_rotate else "k_rotate_attenuate_axis0_lds",
     }
+    if x_in_rotate:
+        names["convolve"] = ("convolve stage WITHOUT its x transform (pass A runs inside k_rotate_attenuate_fftx, stage rotate_attenuate): PSF "
+                             "(x,y) spectrum (k_fft_x_r2c, k_fft_lines<FWD,sparse>), k_fft_lines<FWD>, k_zconv, k_fft_lines<INV>, k_fft_x_c2r, "
+                             "k_reduce_partials")
     passes = None
     geo = (C.c_int64 * 5)()
     if conv_method == 1 and mvs._lib.load().mvsim_fft_geometry((C.c_int64 * 3)(n, n, n), (C.c_int64 * 3)(psf_edge, psf_edge, psf_edge), geo) == 0:
@@ -326,7 +342,8 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
                 # this build / workload
                 "traffic": stages[dom].get("traffic"),
                 "hbm_measured": stages[dom].get("hbm_measured"),
-                "algorithmic_bytes": alg[dom], "launch_ms": ms[dom]}
+                "algorithmic_bytes": alg[dom], "launch_ms": ms[dom],
+                "x_transform_in_rotate_kernel": x_in_rotate}
     rec = dict(head)
     rec.update({
         "stages": stages,
@@ -334,7 +351,11 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
         # their sum, total_ms, is no longer the time a view takes)
         "whole_view": {"bytes": b_view, "ms": view_ms, "frac": b_view / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "fused_bytes": b_view_fused, "frac_fused": b_view_fused / (view_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        "convolve_noise": {"bytes": b_cn, "ms": cn_ms, "frac": b_cn / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "convolve_noise": {"bytes": b_cn, "ms": cn_ms, "frac": b_cn / (cn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           **({"note": "the convolution's x transform runs inside the rotate + attenuate kernel and is NOT in `ms`; "
+                                       "`frac_with_rotate_kernel` charges that whole kernel (rotation and attenuation included) to the sub-path",
+                               "frac_with_rotate_kernel": b_cn / ((cn_ms + ms["rotate_attenuate"]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                              if x_in_rotate else {})},
         "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         "passes": passes,
         "timed": ("overlapped views (library defaults): the stage times of rotate+attenuate and extract+Poisson include each other's "
