@@ -1171,7 +1171,6 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     float2* G2 = ctx->cfft_g2.as<float2>();
     hipStream_t s = ctx->stream;
     const long long rows_all = (long long)py * pz;
-    const long long rows_out = (long long)dim[1] * nzo;
     const long long plane = (long long)hxp * py;
     const DimMap ident_none = DimMap{0, 0, 0, 0, 1, 0};
 

@@ -1,9 +1,11 @@
-# stage times of the default bench line for experiment builds: bash tools/attribute_flags.sh "<cflags 1>" "<cflags 2>" ...
+# stage times of the serial bench leg for experiment builds: bash tools/attribute_flags.sh "<cflags 1>" "<cflags 2>" ...
+# e.g. the fused rotate + attenuate + x transform kernel:
+#   bash tools/attribute_flags.sh "-DMVSIM_EXP_ROTFFT_NOFFT" "-DMVSIM_EXP_ROTFFT_NOBLEND" "-DMVSIM_EXP_ROTFFT_NOFFT -DMVSIM_EXP_ROTFFT_NOBLEND" "-DMVSIM_ROTFFT_PREFETCH=4"
 set -e
 for f in "$@"; do
   MVSIM_EXTRA_CFLAGS="$f" python -c "import importlib; b = importlib.import_module('multiview-simulation_amd.build'); b.build(force=True)"
   for r in 1 2; do
-  python bench.py --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams 2>/dev/null | python -c "
+  python bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
