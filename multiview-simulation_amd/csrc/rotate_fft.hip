@@ -28,8 +28,8 @@ struct __attribute__((aligned(16))) RowGeoF {
 constexpr int geo_chunk_f(int G) { return G == 1 ? 512 : 128; }
 constexpr int UF = 8;
 // rows of the NEXT batch requested before this batch's transforms (their latency would hide behind the FFTs).  Measured at
-// 512^3: 0 -> 0.43 ms, 2 -> 0.46 ms, 4 -> 0.46 ms (128 VGPRs, 4 spilled): the kernel is bound by vector issue (32.6 k VALU
-// instructions per wave, fp64 blends and recurrence among them), not by load latency -- no prefetch in the product build.
+// 512^3: 0 -> 0.43 ms, 2 -> 0.46 ms, 4 -> 0.46 ms (128 VGPRs, 4 spilled), also with the LDS-only round barrier that lets loads
+// stay in flight across it (0.40 against 0.42 ms): the kernel is not waiting for these loads -- no prefetch in the product build.
 #ifndef MVSIM_ROTFFT_PREFETCH
 #define MVSIM_ROTFFT_PREFETCH 0
 #endif
@@ -51,7 +51,6 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
     const int nx = p.nx, ny = p.ny, nz = p.nz, steps = p.steps;
     const int x = threadIdx.x;
     const int lane = x & 63, wave = __builtin_amdgcn_readfirstlane(x >> 6), nwaves = (int)blockDim.x >> 6;
-    // plane order: every XCD gets a contiguous slab of planes (planes z and z + 1 read the same source rows)
     // Plane order.  Consecutive block ids go to different XCDs (round-robin dispatch, for speed only) and planes z, z + 1 read
     // the same source rows, so every XCD gets contiguous runs of planes -- TWO runs half a volume apart: the work of a plane
     // follows its content (empty rows skip the fp64 blends and the transforms), all blocks are resident at once (two per

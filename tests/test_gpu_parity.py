@@ -1434,6 +1434,41 @@ def test_fused_rotate_attenuate_x_transform_is_bit_identical(mvs, synth, shape, 
     assert float(res[1][0]["acq"].max()) > 0
 
 
+def test_bench_line_carries_the_contract_keys():
+    """bench.py's one JSON line (small volume, so that the test stays short): the contract keys, `value` on the library
+    defaults with a serial leg beside it, a roofline whose fused-byte fractions never exceed 1 and that says where the x
+    transform ran, a two-mode CPU baseline labelled as a port; and with --conv-method 2 the direct stencil against the fp32
+    vector peak."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--size", "256", "--psf", "15", "--steps", "2", "--warmup", "1", "--cpu-slab", "8",
+                        "--no-end-to-end", "--no-two-streams"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, MVSIM_OPTIONS="fused_fftx=1"))       # (auto takes the fused kernel from 131072 columns up)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "serial"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    rl = d["roofline"]
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and rl["peak"] == 8000.0 and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9
+    assert rl["x_transform_in_rotate_kernel"] is True and rl["stage_ms"]["pass_a_ms"] == 0.0
+    for st in rl["stages"].values():
+        assert 0 < st["frac_fused"] <= 1.0 and st["fused_bytes"] <= st["algorithmic_bytes"]
+    assert 0 < rl["whole_view"]["frac_fused"] <= 1.0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and set(cb["modes"]) == {"as_reference", "all_cores"} and cb["value"] == cb["modes"]["as_reference"]["value"]
+    assert cb["modes"]["as_reference"]["extrapolated_fraction_of_seconds"] == 0.0 and "not the JVM" in cb["what"]
+    r = subprocess.run([sys.executable, bench, "--conv-method", "2", "--size", "128", "--psf", "15", "--steps", "1", "--warmup", "1", "--serial",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rl = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["roofline"]
+    assert rl["bound"] == "fp32" and rl["unit"] == "TFLOP/s" and rl["peak"] == 157.3 and 0 < rl["frac"] < 1
+    assert rl["flop"] == 2.0 * 15 ** 3 * 128 ** 3 and rl["stencil_geometry"]["blocks_per_cu"] == 2
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself (children with RANK /
     WORLD_SIZE / MASTER_* set, before anything touches the GPU in the parent) and rank 0's line says n_gpus 2 with both
