@@ -32,6 +32,7 @@ Rank 0 prints ONE JSON line (schema in the task contract) including
                   --conv-method 2 the direct stencil against the 157.3 Tflop/s fp32 vector peak (bound "fp32")
   cpu_baseline -- the CPU oracle (C restatement of the reference's ImgLib2 path, not the JVM) on a bounded sample, two modes:
                   as_reference (the reference's threading) and all_cores
+  no_empty_space -- N = 1: the serial leg again on the phantom + 1e-6 (nothing for the exact zero-row fast paths to skip)
   end_to_end   -- N = 1: the same views with page-locked HOST buffers in and out (PCIe-inclusive; never `value`)
   size_1024    -- N = 1: one 1024^3 view, same stage timings and roofline keys
 """
@@ -88,6 +89,7 @@ def parse_args():
                     help="launcher / rendezvous check only: every rank joins the process group, all-reduces a 1 and rank 0 prints "
                          "{n_gpus, ranks_seen}; no GPU, no libmvsim (what the CPU test of the self-launcher runs with --backend gloo)")
     ap.add_argument("--no-size-1024", action="store_true", help="skip the 1024^3 sub-record")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the `no_empty_space` sub-record (N = 1 only)")
     ap.add_argument("--cpu-slab", type=int, default=64, help="z extent of the CPU-baseline sample slab")
     ap.add_argument("--cpu-poisson-planes", type=int, default=64,
                     help="planes of the slab the reference-exact (inter-arrival) Poisson sampler is timed on; the rest is scaled")
@@ -698,6 +700,34 @@ def main():
                       "note": "options tail_overlap = psf_overlap = 0 (kernels strictly one at a time): the leg `roofline` is read from"}
         set_overlap(True)
 
+    no_empty = None
+    if rank == 0 and not multi and my_views and args.conv_method == 1 and not args.no_dense_leg:
+        # The rotate + attenuate + x-transform kernel skips the fp64 blends and the transforms of rows that hold no non-zero voxel
+        # (exact; the phantom, like the reference's drawSpheres volume, is empty outside the specimen).  How much of `value` is
+        # owed to that: the same K serial steps on the SAME phantom plus 1e-6 everywhere -- no empty row left, the same intensity
+        # distribution (adjustImage adds 1e-4 to every voxel anyway), so the sampler sees the same regime mix.
+        keep = gt_bufs[0].clone()
+        gt_bufs[0].add_(1e-6)
+        set_overlap(False)
+        step(); sync()
+        for c in ctxs:
+            c.enable_timing(True)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt = time.perf_counter() - t1
+        st = read_stage()
+        for c in ctxs:
+            c.enable_timing(False)
+        no_empty = {"ms_per_step": dt / args.steps * 1e3, "value": total_views * args.steps / dt * nvox / 1e6, "unit": "Mvoxel/s",
+                    "rotate_attenuate_ms": round(st["rotate_ms"] + st["attenuate_ms"], 4), "extract_ms": round(st["extract_ms"], 4),
+                    "note": "serial leg on the phantom + 1e-6 in every voxel: no empty rows for the zero fast paths of "
+                            "k_rotate_attenuate_fftx (DESIGN.md 4.1) to skip; same intensity distribution"}
+        gt_bufs[0].copy_(keep)
+        del keep
+        set_overlap(not args.serial)
+
     if rank == 0 and args.rehearse_multi:
         # the rehearsal's own check: both ground-truth buffers still hold the phantom, the views produced counts
         assert all(torch.equal(b, gt_bufs[0]) for b in gt_bufs) and float(gt_bufs[0].max()) > 0 and float(acq[-1].max()) > 0
@@ -735,6 +765,8 @@ def main():
         }
         if serial_leg:
             out["serial"] = serial_leg
+        if no_empty:
+            out["no_empty_space"] = no_empty
         if stage:
             kernel_sha = build.source_sha()
             traffic, note = load_traffic(n, args.psf, args.inc, len(ctxs), args.conv_method, kernel_sha)

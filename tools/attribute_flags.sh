@@ -5,7 +5,7 @@ set -e
 for f in "$@"; do
   MVSIM_EXTRA_CFLAGS="$f" python -c "import importlib; b = importlib.import_module('multiview-simulation_amd.build'); b.build(force=True)"
   for r in 1 2; do
-  python bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams 2>/dev/null | python -c "
+  python bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

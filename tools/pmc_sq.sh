@@ -3,7 +3,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 export MVSIM_OPTIONS="$1"
 rm -rf gpurun_out/psq && mkdir -p gpurun_out/psq
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d gpurun_out/psq -o run -- python3 bench.py --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --serial --steps 1 --warmup 1 > gpurun_out/psq.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d gpurun_out/psq -o run -- python3 bench.py --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg --serial --steps 1 --warmup 1 > gpurun_out/psq.log 2>&1
 python3 - "$2" <<'PY'
 import glob, sqlite3, sys, collections
 db = sorted(glob.glob("gpurun_out/psq/**/*_results.db", recursive=True))[-1]

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
 # --serial: the library's default overlaps off, one kernel at a time, so that per-kernel durations add up to the stage times
-BENCH="bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams"
+BENCH="bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg"
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/trace -o run -- python3 $BENCH > $O/trace.log 2>&1
 python3 tools/kstats.py $O/trace 20 $O/kernel_stats.csv > $O/kernel_stats.txt
