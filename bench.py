@@ -125,19 +125,30 @@ def self_launch(args) -> int:
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     alive = set(range(n))
-    while alive:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            alive.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                sys.stderr.write(f"bench.py: rank {r} exited with status {code}; stopping the other ranks\n")
-                for q in alive:
-                    procs[q].terminate()
-        if alive:
-            time.sleep(0.05)
+    try:
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write(f"bench.py: rank {r} exited with status {code}; stopping the other ranks\n")
+                    for q in alive:
+                        procs[q].terminate()
+            if alive:
+                time.sleep(0.05)
+    finally:
+        # interrupted (Ctrl-C, a caller's timeout): the ranks are OUR children -- end exactly those, by PID
+        for q in alive:
+            if procs[q].poll() is None:
+                procs[q].terminate()
+        for q in alive:
+            try:
+                procs[q].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[q].kill()
     return rc
 
 
