@@ -149,6 +149,32 @@ def test_stencil_takes_the_psfs_the_path_uses(ctx, orc, synth, psf_kind):
     assert float(np.abs(got1.ravel()[idx] - want).max()) <= CONV_TOL * scale
 
 
+def test_stencil_at_config1_size_against_fft_and_sampled_oracle(ctx, orc, synth):
+    """The direct stencil on a whole BASELINE configs[1] volume (512^3, 31^3 anisotropic Gaussian; 8 Tflop, ~0.1 s): against
+    the FFT passes on every voxel and against the oracle's exact fp64 direct sum at 3 000 sampled voxels (boundary blocks at
+    two opposite corners, random and bright voxels).  1e-5 of the range, as everywhere."""
+    v = synth.sphere_phantom(512)
+    psf = synth.gaussian_psf(31, sigma=(2.0, 2.2, 6.0))
+    p2 = psf.copy()
+    got2 = ctx.convolve(v, p2, method=2)
+    got1 = ctx.convolve(v, psf.copy(), method=1)
+    scale = float(np.abs(got1).max())
+    assert scale > 0
+    # chunked comparison: no 512 MB temporaries beyond the two results
+    worst = max(float(np.abs(got2[z0:z0 + 64] - got1[z0:z0 + 64]).max()) for z0 in range(0, 512, 64))
+    assert worst <= CONV_TOL * scale
+    nz, ny, nx = v.shape
+    zz, yy, xx = np.meshgrid(np.arange(4), np.arange(8), np.arange(24), indexing="ij")
+    corner = (xx + nx * (yy + ny * zz)).ravel()
+    far = ((nx - 1 - xx) + nx * ((ny - 1 - yy) + ny * (nz - 1 - zz))).ravel()
+    rnd = np.random.default_rng(11).integers(0, v.size, 1200)
+    bright = np.flatnonzero(got1[200:312].ravel() > 0.25 * scale)[::4001][:300] + 200 * ny * nx
+    idx = np.unique(np.concatenate([corner, far, rnd, bright]))
+    want = orc.convolve_direct_at(v, p2, idx)
+    assert float(np.abs(got2.ravel()[idx] - want).max()) <= CONV_TOL * scale
+    assert float(np.abs(got1.ravel()[idx] - want).max()) <= CONV_TOL * scale
+
+
 # ------------------------------------------------------------------------------------------------ adjust / norm
 def test_adjust_and_norm_match_oracle(ctx, orc):
     rng = np.random.default_rng(5)
