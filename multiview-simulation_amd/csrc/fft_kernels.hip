@@ -532,7 +532,11 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
 // lies in HBM (pitch 17 to spread the banks); taps of the 16 lines in LDS.  A lane owns one line and ZU consecutive
 // outputs; taps are consumed in chunks of ZJ with a sliding register window over the inputs, so each LDS word is
 // read once per lane and chunk.  Out of place (chunks read each other's halo).
-constexpr int NLZ = 16, ZU = 16, ZJ = 8, ZT = 256, ZPITCH = NLZ + 1;
+// (MVSIM_EXP_NLZ = 32 -- 256-byte rows -- measured 0.35 ms with 160-output tiles, 0.42 ms with 112-output tiles, against 0.32 ms)
+#ifndef MVSIM_EXP_NLZ
+#define MVSIM_EXP_NLZ 16
+#endif
+constexpr int NLZ = MVSIM_EXP_NLZ, ZU = 16, ZJ = 8, ZT = 256, ZPITCH = NLZ + 1;
 constexpr int ZLPR = NLZ / 2;                    // lanes per staged row (16 B each)
 constexpr int ZRPI = ZT / ZLPR;                  // rows per staging iteration
 #ifndef MVSIM_ZNIT
@@ -652,12 +656,14 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
         for (int u = 0; u < ZU; ++u) acc[u] = v2f{0.f, 0.f};
         // window w[i] = f[base + i]; output u, tap j0 + t reads w[u - t + ZJ - 1]
         float2 w[ZU + ZJ - 1];
-        int base = padf + z0 + p.kz - 1 - (ZJ - 1);       // j0 = 0
-        // rows above the staged range (the last z block of a chunk may be partial) are clamped: their products only
-        // feed outputs that are not stored
-        const int rmax = rows - 1;
+        const int base = padf + z0 + p.kz - 1 - (ZJ - 1);   // j0 = 0
+        // No clamps on the row index: rows above the staged range (the last z block of a chunk may be partial) lie inside the LDS
+        // region all the same (it is sized for zc outputs) and whatever they hold only feeds outputs that are neither stored nor
+        // summed; base never goes below 0 (it ends at z0: padf + kz = kzp).  One address register plus immediate offsets instead
+        // of a 64-bit multiply-add per window element (24 quarter-rate v_mad_u64_u32 per z block).
+        const float2* __restrict__ fw = f + base * ZPITCH + line;
 #pragma unroll
-        for (int i = 0; i < ZU + ZJ - 1; ++i) w[i] = f[min(base + i, rmax) * ZPITCH + line];
+        for (int i = 0; i < ZU + ZJ - 1; ++i) w[i] = fw[i * ZPITCH];
 #pragma unroll 1
         for (int j0 = 0; j0 < kzp; j0 += ZJ) {
             float2 gg[ZJ];
@@ -677,9 +683,9 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
                 // next chunk of taps looks ZJ rows further down
 #pragma unroll
                 for (int i = ZU + ZJ - 2; i >= ZJ; --i) w[i] = w[i - ZJ];
-                base -= ZJ;
+                fw -= ZJ * ZPITCH;
 #pragma unroll
-                for (int i = 0; i < ZJ; ++i) w[i] = f[max(base + i, 0) * ZPITCH + line];
+                for (int i = 0; i < ZJ; ++i) w[i] = fw[i * ZPITCH];
             }
         }
         float2* d = p.dst + (long long)(zc0 + z0) * p.zs + dcol + line;
