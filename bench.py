@@ -763,8 +763,10 @@ def main():
                        "conv_method": conv_name,
                        "streams_per_gpu": len(ctxs),
                        "overlap": ("off (--serial)" if args.serial else
-                                   "library defaults: tail_overlap (extract + Poisson of view v beside rotate+attenuate of view v+1) + "
-                                   "psf_overlap (PSF spectrum beside passes A/B); bit-identical to the serial order"),
+                                   "library defaults: psf_overlap (PSF spectrum on a side stream beside the image's first passes) + tail_overlap "
+                                   "(extract + Poisson of view v beside the first kernel of view v+1 -- used only where the separate rotate kernel "
+                                   "runs: beside the fused rotate + attenuate + x-transform kernel it measured slower and is skipped); "
+                                   "bit-identical to the serial order"),
                        "launcher": ("self-launched by bench.py (one child process per rank)" if os.environ.get("MVSIM_BENCH_SELF_LAUNCHED") == "1"
                                     else "external launcher (torchrun)" if world > 1 else "single process"),
                        "ranks_seen": ranks_seen,
