@@ -70,6 +70,14 @@ int parse_option(Options& o, const char* name, const char* value)
         if (v == "scatter_allgather" || v == "auto") o.bcast_ring = false; else if (v == "ring") o.bcast_ring = true; else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
+    if (n == "cu_range") {
+        int a = 0, b = 0;
+        if (sscanf(v.c_str(), "%d:%d", &a, &b) != 2 || a < 0 || b < a || b > 1024) return MVSIM_EINVAL;
+        o.cu_lo = a; o.cu_hi = b;
+        return MVSIM_OK;
+    }
+    if (n == "tail_cus") { const int k = atoi(v.c_str()); if (k < 0 || k > 1024) return MVSIM_EINVAL; o.tail_cus = k; return MVSIM_OK; }
+    if (n == "kx_panel") { const int k = atoi(v.c_str()); if (k < 0 || k % 16 != 0) return MVSIM_EINVAL; o.kx_panel = k; return MVSIM_OK; }
     if (n == "fft_pad") {
         long long a = 0, b = 0, c = 0;
         if (v == "auto" || v.empty()) { o.fft_pad[0] = o.fft_pad[1] = o.fft_pad[2] = 0; return MVSIM_OK; }
@@ -236,6 +244,17 @@ static int check_dim(const int64_t dim[3])
 
 static int64_t nvox(const int64_t dim[3]) { return dim[0] * dim[1] * dim[2]; }
 
+// A stream whose kernels may only be placed on the CUs [lo, hi) of the runtime's mask order (hi <= lo: every CU).
+int create_stream_on_cus(hipStream_t* s, int lo, int hi, int num_cu)
+{
+    if (hi <= lo) { MVSIM_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return MVSIM_OK; }
+    if (hi > num_cu) hi = num_cu;
+    std::vector<uint32_t> mask((size_t)(num_cu + 31) / 32, 0u);
+    for (int c = lo; c < hi; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+    MVSIM_HIP(hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()));
+    return MVSIM_OK;
+}
+
 
 int join_tail(mvsim_ctx* ctx)
 {
@@ -373,8 +392,7 @@ int mvsim_create(int device, mvsim_ctx** out)
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
     ctx->opt = env_options();
-    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete ctx; set_error("hipStreamCreate: %s", hipGetErrorString(e)); return MVSIM_EHIP; }
+    if (create_stream_on_cus(&ctx->own_stream, ctx->opt.cu_lo, ctx->opt.cu_hi, ctx->num_cu) != MVSIM_OK) { delete ctx; return MVSIM_EHIP; }
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return MVSIM_OK;
@@ -419,9 +437,27 @@ int mvsim_join(mvsim_ctx* ctx)
 int mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value)
 {
     MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
+    const int lo = ctx->opt.cu_lo, hi = ctx->opt.cu_hi, tc = ctx->opt.tail_cus;
     if (parse_option(ctx->opt, name, value) != MVSIM_OK) {
         set_error("invalid argument: option %s = %s", name ? name : "(null)", value ? value : "(null)");
         return MVSIM_EINVAL;
+    }
+    if (ctx->opt.cu_lo != lo || ctx->opt.cu_hi != hi) {
+        // the context's own stream moves to the new CU set (a caller's stream is the caller's business)
+        MVSIM_TRY(set_device(ctx));
+        MVSIM_HIP(hipStreamSynchronize(ctx->own_stream));
+        hipStream_t ns = nullptr;
+        MVSIM_TRY(create_stream_on_cus(&ns, ctx->opt.cu_lo, ctx->opt.cu_hi, ctx->num_cu));
+        if (ctx->stream == ctx->own_stream) ctx->stream = ns;
+        (void)hipStreamDestroy(ctx->own_stream);
+        ctx->own_stream = ns;
+        view_graphs_release(ctx);
+    }
+    if (ctx->opt.tail_cus != tc && ctx->tail_stream) {
+        MVSIM_TRY(set_device(ctx));
+        MVSIM_HIP(hipStreamSynchronize(ctx->tail_stream));
+        (void)hipStreamDestroy(ctx->tail_stream); (void)hipEventDestroy(ctx->ev_tail_fork); (void)hipEventDestroy(ctx->ev_tail);
+        ctx->tail_stream = nullptr;
     }
     return MVSIM_OK;
 }
@@ -789,7 +825,7 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     hipStream_t tail_on = ctx->stream;
     if (overlap_ok) {
         if (!ctx->tail_stream) {
-            MVSIM_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
+            MVSIM_TRY(create_stream_on_cus(&ctx->tail_stream, 0, ctx->opt.tail_cus, ctx->num_cu));
             MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_tail_fork, hipEventDisableTiming));
             MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
         }

@@ -129,6 +129,11 @@ struct Options {
     int     graph = 0;                 // replay simulate_view_dev from a captured hipGraph (small, launch-bound volumes)
     bool    bcast_ring = false;        // ground-truth broadcast as one ncclBroadcast instead of scatter + all-gather
     int64_t fft_pad[3] = {0, 0, 0};    // explicit padded sizes on the rocFFT path (0: choose)
+    int     cu_lo = 0, cu_hi = 0;      // cu_range=a:b: the context's own stream may only use the CUs [a, b) of the mask order
+                                       // (hipExtStreamCreateWithCUMask; 0:0 = all).  Experiments on how kernels share the chip.
+    int     tail_cus = 0;              // > 0: the tail stream (extract + Poisson) is confined to that many CUs, see DESIGN 4.5
+    int     kx_panel = 0;              // > 0: passes B, C', D run panel by panel over kx (that many columns, multiple of 16), so
+                                       // that a panel's intermediates are re-read while still in the Infinity Cache (probe)
 };
 const Options& env_options();
 int parse_option(Options& o, const char* name, const char* value);   // MVSIM_OK / MVSIM_EINVAL

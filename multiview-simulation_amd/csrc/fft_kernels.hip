@@ -769,16 +769,17 @@ static int zconv_chunk(int nz, int kz)
 }
 
 // blocks (= partial sums) of the z pass for this geometry
-static long long zconv_blocks(const ZConvArgs& a, int py)
+static long long zconv_blocks(const ZConvArgs& a, int py, int cols = 0)
 {
-    return (long long)((a.nz + a.zc - 1) / a.zc) * (a.hxp / NLZ) * py;
+    return (long long)((a.nz + a.zc - 1) / a.zc) * ((cols > 0 ? cols : a.hxp) / NLZ) * py;
 }
 
-static int launch_zconv(mvsim_ctx* ctx, const ZConvArgs& a, int py)
+// cols > 0: only that many kx columns from the column the pointers of `a` start at (a kx panel)
+static int launch_zconv(mvsim_ctx* ctx, const ZConvArgs& a, int py, int cols = 0)
 {
     hipStream_t s = ctx->stream;
     const size_t lds = zconv_lds(a.zc, a.kz);
-    dim3 grid((a.nz + a.zc - 1) / a.zc, a.hxp / NLZ, py);
+    dim3 grid((a.nz + a.zc - 1) / a.zc, (cols > 0 ? cols : a.hxp) / NLZ, py);
     MVSIM_TRY(set_lds(ctx, k_zconv, lds));
     hipLaunchKernelGGL(k_zconv, grid, dim3(ZT), lds, s, a);
     MVSIM_HIP(hipGetLastError());
@@ -1272,6 +1273,57 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
             b.dst = G; b.dst_outer = (long long)ZB * hxp; b.dst_blk = (long long)nzs * ZB * hxp;
         }
+        // kx panels (option kx_panel, probe): passes B, C', D are independent per kx column, so they can run back to back on a
+        // panel of columns whose two intermediates (2 x Nz x Py x cols x 8 B) fit the 256 MiB Infinity Cache
+        const int pcols = (zdirect && !is_slab && ctx->opt.kx_panel > 0 && ctx->opt.kx_panel % tile_y == 0 && ctx->opt.kx_panel % NLZ == 0)
+                              ? ctx->opt.kx_panel : 0;
+        if (pcols > 0) {
+            ev_begin(ctx, ST_PASS_B);
+            if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+            ZConvArgs z{};
+            z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
+            z.zs = (long long)ZB * hxp; z.src_blk = (long long)nzs * ZB * hxp; z.dst_blk = (long long)nzo * ZB * hxp;
+            z.taps_blk = (long long)kz * ZB * hxp;
+            z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
+            z.zc = zconv_chunk(nzo, kz);
+            const float scale_f = (float)(0.25 / ((double)px * (double)py));
+            const double2 *wx0 = nullptr;
+            long long zblocks = 0;
+            if (early) {
+                MVSIM_TRY(ensure_box_weights(ctx, (int)dim[0], px, hxp, true, &wx0));
+                MVSIM_TRY(ensure_box_weights(ctx, (int)dim[1], py, py, false, &z.wy));
+                zblocks = zconv_blocks(z, py);
+                MVSIM_TRY(ctx->partials_z.reserve((size_t)zblocks * sizeof(double)));
+            }
+            const int nk = (nzo - 1) / zstride + 1;
+            long long sum_off = 0;
+            for (int c0 = 0; c0 < hxp; c0 += pcols) {
+                const int cols = std::min(pcols, hxp - c0);
+                LinesArgs pb = b;
+                pb.src = F + c0; pb.dst = G + c0;
+                MVSIM_TRY(launch_lines(ctx, py, FWD, false, pb, cols / tile_y, nzs));
+                z.src = G + c0; z.dst = F + c0; z.taps = G2 + c0;
+                if (early) { z.wx = wx0 + c0; z.sum_partial = ctx->partials_z.as<double>() + sum_off; sum_off += zconv_blocks(z, py, cols); }
+                MVSIM_TRY(launch_zconv(ctx, z, py, cols));
+                LinesArgs pd = b;
+                pd.lmap = ident_none; pd.src_mirror = 0; pd.gap_lo = pd.gap_hi = 0; pd.outer_skip_lo = 1 << 30; pd.outer_skip_len = 0;
+                pd.tw = tw_py; pd.store_limit = (int)dim[1];
+                pd.src = F + c0; pd.src_outer = (long long)ZB * hxp * zstride; pd.src_blk = (long long)nzo * ZB * hxp;
+                pd.dst = G + c0; pd.dst_outer = plane * zstride; pd.dst_blk = 0;
+                MVSIM_TRY(launch_lines(ctx, py, INV, false, pd, cols / tile_y, nk));
+            }
+            if (early) {
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_z.as<double>(), zblocks, scal, (double)scale_f,
+                                   corr_n, corr_min, corr_target);
+                MVSIM_HIP(hipGetLastError());
+            }
+            ev_end(ctx, ST_PASS_B);
+        }
+        float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
+        const int nzd = zdirect ? nzo : (int)dim[2];                  // planes z >= Nz are never read
+        const int nk = (nzd - 1) / zstride + 1;                       // planes 0, zstride, 2 zstride, ...
+        if (pcols > 0) Fz = G;
+        else {
         ev_begin(ctx, ST_PASS_B);
         MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
         ev_end(ctx, ST_PASS_B);
@@ -1279,7 +1331,6 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));    // the z pass reads the PSF spectrum
         ev_begin(ctx, ST_PASS_C);
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
-        float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
         if (zdirect) {
             ZConvArgs z{};
             z.src = G; z.dst = F; z.taps = G2; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
@@ -1318,14 +1369,13 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         b.src = b.dst = Fz;
         b.tw = tw_py;
         b.store_limit = (int)dim[1];                                  // pass E only reads rows y < Ny
-        const int nzd = zdirect ? nzo : (int)dim[2];                  // planes z >= Nz are never read
-        const int nk = (nzd - 1) / zstride + 1;                       // planes 0, zstride, 2 zstride, ...
         b.src_outer = b.dst_outer = plane * zstride;
         b.dst_blk = 0;
         if (zdirect) { b.src = F; b.src_outer = (long long)ZB * hxp * zstride; b.src_blk = (long long)nzo * ZB * hxp; }
         ev_begin(ctx, ST_PASS_D);
         MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, nk));
         ev_end(ctx, ST_PASS_D);
+        }
         C2RFuse fz{};
         if (fuse) {
             // adjustImage's factor must exist before pass E runs: (target - min) / (sum / n) from the early sum
