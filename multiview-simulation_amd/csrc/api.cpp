@@ -62,7 +62,7 @@ int parse_option(Options& o, const char* name, const char* value)
     }
     if (n == "tail_overlap") {
         if (v == "0" || v == "off") o.tail_overlap = 0; else if (v == "1" || v == "on" || v == "own") o.tail_overlap = 1;
-        else if (v == "2" || v == "any") o.tail_overlap = 2; else return MVSIM_EINVAL;
+        else if (v == "2" || v == "any") o.tail_overlap = 2; else if (v == "3" || v == "late") o.tail_overlap = 3; else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
     if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
@@ -77,6 +77,10 @@ int parse_option(Options& o, const char* name, const char* value)
         return MVSIM_OK;
     }
     if (n == "tail_cus") { const int k = atoi(v.c_str()); if (k < 0 || k > 1024) return MVSIM_EINVAL; o.tail_cus = k; return MVSIM_OK; }
+    if (n == "exp_guest") { o.exp_guest = atoi(v.c_str()); return MVSIM_OK; }
+    if (n == "guest_tail") return flag(&o.guest_tail);
+    if (n == "tail_prio") { o.tail_prio = atoi(v.c_str()); return MVSIM_OK; }
+    if (n == "guest_trips") { int a = -1, b = -1; if (sscanf(v.c_str(), "%d,%d", &a, &b) != 2) return MVSIM_EINVAL; o.guest_trips[0] = a; o.guest_trips[1] = b; return MVSIM_OK; }
     if (n == "kx_panel") { const int k = atoi(v.c_str()); if (k < 0 || k % 16 != 0) return MVSIM_EINVAL; o.kx_panel = k; return MVSIM_OK; }
     if (n == "fft_pad") {
         long long a = 0, b = 0, c = 0;
@@ -265,13 +269,29 @@ int join_tail(mvsim_ctx* ctx)
     return MVSIM_OK;
 }
 
+// A view's extract + Poisson that was left to ride in the next view's y passes (option guest_tail) and now has to run before
+// something else: as the two kernels of its own, on the context's stream.
+int flush_tail(mvsim_ctx* ctx)
+{
+    if (!ctx || !ctx->deferred.valid) return MVSIM_OK;
+    const DeferredTail t = ctx->deferred;
+    ctx->deferred.valid = false;
+    const int64_t n_out = t.dim[0] * t.dim[1] * mvsim_extract_nz(t.dim[2], t.inc);
+    MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(n_out, nullptr)));
+    ev_begin(ctx, ST_EXTRACT);
+    MVSIM_TRY(launch_extract(ctx->stream, t.in, t.out, t.dim, t.inc, t.adjust, t.scal, t.min_value, true, t.mul, t.seed, t.stream, 0,
+                             ctx->pqueue.p, 1, t.index_inc));
+    ev_end(ctx, ST_EXTRACT);
+    return MVSIM_OK;
+}
+
 // every entry point starts here: the device, and a pending tail ordered in front of what the call enqueues
 static int set_device(mvsim_ctx* ctx, bool keep_tail = false)
 {
     MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
     ev_rebalance(ctx);
     MVSIM_HIP(hipSetDevice(ctx->device));
-    if (!keep_tail) MVSIM_TRY(join_tail(ctx));
+    if (!keep_tail) { MVSIM_TRY(join_tail(ctx)); MVSIM_TRY(flush_tail(ctx)); }
     return MVSIM_OK;
 }
 
@@ -344,7 +364,7 @@ static int scal_ptr(mvsim_ctx* ctx, double** partial, double** scal)
 {
     MVSIM_TRY(ctx->partials.reserve((SUM_BLOCKS + 8) * sizeof(double)));
     *partial = ctx->partials.as<double>();
-    *scal = *partial + SUM_BLOCKS;
+    *scal = scal_of(ctx);
     return MVSIM_OK;
 }
 
@@ -403,6 +423,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     if (!ctx) return MVSIM_OK;
     (void)hipSetDevice(ctx->device);
     (void)join_tail(ctx);
+    (void)flush_tail(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     mvsim_comm_destroy(ctx);
     async_release(ctx);
@@ -437,7 +458,7 @@ int mvsim_join(mvsim_ctx* ctx)
 int mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value)
 {
     MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
-    const int lo = ctx->opt.cu_lo, hi = ctx->opt.cu_hi, tc = ctx->opt.tail_cus;
+    const int lo = ctx->opt.cu_lo, hi = ctx->opt.cu_hi, tc = ctx->opt.tail_cus + 4096 * ctx->opt.tail_prio;
     if (parse_option(ctx->opt, name, value) != MVSIM_OK) {
         set_error("invalid argument: option %s = %s", name ? name : "(null)", value ? value : "(null)");
         return MVSIM_EINVAL;
@@ -453,7 +474,7 @@ int mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value)
         ctx->own_stream = ns;
         view_graphs_release(ctx);
     }
-    if (ctx->opt.tail_cus != tc && ctx->tail_stream) {
+    if (ctx->opt.tail_cus + 4096 * ctx->opt.tail_prio != tc && ctx->tail_stream) {
         MVSIM_TRY(set_device(ctx));
         MVSIM_HIP(hipStreamSynchronize(ctx->tail_stream));
         (void)hipStreamDestroy(ctx->tail_stream); (void)hipEventDestroy(ctx->ev_tail_fork); (void)hipEventDestroy(ctx->ev_tail);
@@ -745,6 +766,20 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     float* att = o->att;
     float* con = o->con;
     if (!att) { MVSIM_TRY(ctx->vol_b.reserve(vbytes)); att = ctx->vol_b.as<float>(); }
+    if (ctx->deferred.valid || ctx->tail_pending) ctx->scal_slot ^= 1;          // the deferred tail reads its view's adjust factor until it has run
+    if (ctx->deferred.valid) {
+        // the previous view's extract + Poisson has not run yet (it rides in this view's y passes): nothing this view does before
+        // them may touch what it reads or writes
+        const DeferredTail& d = ctx->deferred;
+        const size_t dout = (size_t)(d.dim[0] * d.dim[1] * mvsim_extract_nz(d.dim[2], d.inc)) * sizeof(float);
+        const char* lo[2] = {reinterpret_cast<const char*>(d.out), reinterpret_cast<const char*>(d.in)};
+        const char* hi[2] = {lo[0] + dout, lo[1] + (size_t)(d.dim[0] * d.dim[1] * d.dim[2]) * sizeof(float)};
+        bool meet = false;
+        for (int r = 0; r < 2; ++r)
+            meet = meet || ranges_meet(gt, vbytes, lo[r], hi[r]) || ranges_meet(rot, vbytes, lo[r], hi[r]) || ranges_meet(o->att, vbytes, lo[r], hi[r]) ||
+                   ranges_meet(o->con, vbytes, lo[r], hi[r]);
+        if (meet) MVSIM_TRY(flush_tail(ctx));
+    }
     if (ctx->tail_pending) {
         // the previous view's tail still writes its acquisition and reads its convolved volume: this view's first stage
         // may run beside it only if it touches neither
@@ -774,7 +809,10 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
         MVSIM_TRY(launch_rotate(ctx->stream, gt, rot, dim, inv));
     }
     ev_end(ctx, ST_ROTATE);
-    MVSIM_TRY(join_tail(ctx));                          // everything below reuses the workspaces of the previous view
+    // everything below reuses the workspaces of the previous view -- except, behind the fused kernel, up to pass E: the
+    // spectrum buffers are not the tail's, the [sum, factor] slot alternates, and only pass E writes the volume the tail reads
+    const bool late_join = ctx->opt.tail_overlap == 3 && x_done && ctx->tail_pending && !o->con && pick_method(p->conv_method, kdim) == 1;
+    if (!late_join) MVSIM_TRY(join_tail(ctx));
     if (!fused) {
         ev_begin(ctx, ST_ATTENUATE);
         MVSIM_TRY(launch_attenuate(ctx->stream, rot, att, dim, p->delta));
@@ -794,6 +832,7 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     tail.zstride = (!materialise && p->inc > 1 && plane_vox % 4 == 0 && (!noise || ctx->opt.poisson_queue == 1)) ? p->inc : 1;
     tail.corr_n = n; tail.min_value = p->min_value; tail.target_average = p->target_average;
     tail.x_done = x_done;
+    tail.join_before_e = late_join;
     if (method == 1 && ctx->opt.fuse_tail && (!noise || ctx->opt.poisson_queue == 1)) {
         const size_t qb = noise ? fused_tail_queue_bytes(dim, kdim, p->inc, materialise, ctx->opt) : 0;
         if (!noise || qb > 0) {
@@ -805,7 +844,13 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
             tail.mul = mvsim_poisson_mul((double)p->snr); tail.seed = p->seed; tail.stream = p->stream;
         }
     }
+    if (ctx->deferred.valid) {
+        // the y passes of this view carry the previous view's sampler -- or it runs now, before pass E reuses its input
+        if (method == 1 && !tail.want_fuse && fft_can_host_guest(ctx, dim, kdim) ) tail.guest = &ctx->deferred;
+        else MVSIM_TRY(flush_tail(ctx));
+    }
     MVSIM_TRY(convolve_dev_impl(ctx, att, dim, kdim, method, con, &tail));
+    if (tail.guest && ctx->deferred.valid) { set_error("guest tail: the convolution did not carry the previous view's sampler"); return MVSIM_EHIP; }
     if (tail.fused) return MVSIM_OK;   // pass E adjusted, extracted and sampled (phase 1); the resolver is enqueued behind it
 
     ev_begin(ctx, ST_ADJUST);
@@ -821,10 +866,30 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     // rotate+attenuate leaves most of the chip idle and runs beside it.
     // (not beside the fused rotate + attenuate + x transform of the next view: that kernel is bound by vector issue like the
     // sampler itself, and the two together measured slower than one after the other -- 17.6 against 17.2 ms per 8 views)
-    if (x_done) overlap_ok = false;
+    // ... but INSIDE the next view's y passes -- HBM-bound tile copies that leave half of the vector issue slots idle -- it fits:
+    // the tail is not enqueued at all now; the next view's passes B and D carry it as guest waves (or flush_tail runs it as
+    // kernels of its own when anything else comes first).  Same visibility contract as the stream overlap.
+    const int64_t ndim[3] = {dim[0], dim[1], tail.zstride > 1 ? mvsim_extract_nz(dim[2], p->inc) : dim[2]};
+    if (overlap_ok && ctx->opt.guest_tail && noise && ctx->opt.poisson_queue == 1 && !materialise && method == 1 && !ctx->timing &&
+        plane_vox % 4 == 0 && ((reinterpret_cast<uintptr_t>(con) | reinterpret_cast<uintptr_t>(o->acq)) & 15) == 0 &&
+        fft_can_host_guest(ctx, dim, kdim)) {
+        DeferredTail& d = ctx->deferred;
+        d.valid = true; d.in = con; d.out = o->acq;
+        d.dim[0] = ndim[0]; d.dim[1] = ndim[1]; d.dim[2] = ndim[2];
+        d.inc = tail.zstride > 1 ? 1 : p->inc; d.index_inc = tail.zstride > 1 ? p->inc : 0;
+        d.adjust = true; d.scal = scal; d.min_value = p->min_value; d.mul = mvsim_poisson_mul((double)p->snr);
+        d.seed = p->seed; d.stream = p->stream;
+        return MVSIM_OK;
+    }
+    if (x_done && ctx->opt.tail_overlap != 3) overlap_ok = false;
     hipStream_t tail_on = ctx->stream;
     if (overlap_ok) {
         if (!ctx->tail_stream) {
+            if (ctx->opt.tail_prio != 0 && ctx->opt.tail_cus == 0) {
+                int least = 0, greatest = 0;
+                MVSIM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                MVSIM_HIP(hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, ctx->opt.tail_prio > 0 ? greatest : least));
+            } else
             MVSIM_TRY(create_stream_on_cus(&ctx->tail_stream, 0, ctx->opt.tail_cus, ctx->num_cu));
             MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_tail_fork, hipEventDisableTiming));
             MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
@@ -951,7 +1016,7 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     const bool overlap = ctx->opt.tail_overlap != 0 && (ctx->opt.tail_overlap == 2 || ctx->stream == ctx->own_stream) &&
                          !ctx->opt.graph && !correction && dim &&
                          dim[0] > 0 && dim[1] > 0 && dim[2] > 0 && dim[0] * dim[1] * dim[2] >= ((int64_t)1 << 24);
-    if (!overlap) MVSIM_TRY(join_tail(ctx));
+    if (!overlap) { MVSIM_TRY(join_tail(ctx)); MVSIM_TRY(flush_tail(ctx)); }
     MVSIM_TRY(check_dim(dim));
     MVSIM_CHECK_ARG(gt && p && o, "null pointer");
     MVSIM_CHECK_ARG(o->acq != nullptr, "outputs.acq is required");

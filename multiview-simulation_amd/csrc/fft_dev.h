@@ -324,6 +324,10 @@ struct __attribute__((packed, aligned(8))) Pair16 {
 };
 
 // ---------------------------------------------------------------------------------- size table
+// (MVSIM_DEV_SIZES: experiment builds that only need the 512^3 / 31^3 workload compile in seconds; never defined in the product build)
+#ifdef MVSIM_DEV_SIZES
+#define MVSIM_FFT_SIZES(X) X(280, 7, 5, 8) X(560, 7, 8, 10)
+#else
 #define MVSIM_FFT_SIZES(X) \
     X(16, 4, 4)            \
     X(18, 9, 2)            \
@@ -369,6 +373,7 @@ struct __attribute__((packed, aligned(8))) Pair16 {
     X(2048, 8, 8, 8, 4)    \
     X(2160, 10, 8, 9, 3)   \
     X(2240, 7, 8, 8, 5)
+#endif
 
 // fused rotate + attenuate + x transform (rotate_fft.hip)
 struct RotFftArgs {

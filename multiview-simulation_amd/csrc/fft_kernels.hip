@@ -46,6 +46,14 @@ struct LinesArgs {
     long long     src_blk, dst_blk;
     int           src_mirror;       // != 0 (non-SPARSE): position n reads source position map_src(lmap, n) -- the mirrored halo rows
                                     // of the padded image are the rows themselves, read twice instead of transformed twice
+    // GW > 0 (guest waves, see k_fft_lines): work the block's extra waves do beside the transform
+    struct Guest {
+        int        kind;            // 0: none, 1: phase 1 of the sampler, 2: the resolver, 3: experiment (chain of `nseg` Philox blocks per wave)
+        long long  nseg;            // resolver: queue segments (dealt over the blocks of this launch)
+        long long  it0, it1;        // phase 1: the trips [it0, it1) of every block's walk (p1_block_body)
+        P1Job      p1;
+        ResolveJob rs;
+    } guest;
 };
 
 #ifndef MVSIM_ZBS
@@ -61,13 +69,27 @@ __device__ __forceinline__ long long line_off(int n, long long es, long long blk
 // second launch bound: as many blocks as the LDS lets a CU hold (two, or one for the long lines) must stay resident
 // (w = blocks*T/256 waves per SIMD, rounded up) -- the register budget follows from that
 template <int L> constexpr int lines_blocks_per_cu() { return 2 * Cfg<L>::LDS <= 160 * 1024 ? 2 : 1; }
-template <class PLAN, int MODE, bool SPARSE>
-__global__ __launch_bounds__(Cfg<PLAN::len>::T, (lines_blocks_per_cu<PLAN::len>() * Cfg<PLAN::len>::T + 255) / 256)
+// guest waves (below): four per block -- one per SIMD; two measured no better than none, because both land on the same two
+// SIMDs of every block -- with their 1.1 KB of sampler scratch each behind the tile.  Only tiles that leave that room with
+// two blocks per CU, and that are large enough for the transform to need the time (eight waves), host guests.
+constexpr int LINES_GW = 4;
+template <int L> constexpr size_t lines_guest_lds() { return ((Cfg<L>::LDS + 15) & ~(size_t)15) + LINES_GW * sizeof(P1Scratch); }
+template <int L> constexpr bool lines_guest_capable()
+{
+    return lines_blocks_per_cu<L>() == 2 && 2 * lines_guest_lds<L>() <= 160 * 1024 && Cfg<L>::NW == 8;
+}
+
+// GW: guest waves per block.  The y passes are tile copies at 85 % of the HBM copy ceiling that leave half of the vector
+// issue slots idle; GW extra waves per block use them for work that needs no HBM bandwidth to speak of -- the
+// Poisson sampler of the PREVIOUS view (vector-issue-bound).  Guests share nothing with the transform but the CU: the
+// transform's two block barriers become waves_barrier over its own NW waves.
+template <class PLAN, int MODE, bool SPARSE, int GW = 0>
+__global__ __launch_bounds__(Cfg<PLAN::len>::T + 64 * GW, (lines_blocks_per_cu<PLAN::len>() * (Cfg<PLAN::len>::T + 64 * GW) + 255) / 256)
 void k_fft_lines(LinesArgs p)
 {
     constexpr int L = PLAN::len;
     using C = Cfg<L>;
-    constexpr int NL = C::NL, LP = C::LP, T = C::T, LW = C::LW;
+    constexpr int NL = C::NL, LP = C::LP, T = C::T, LW = C::LW, NW = C::NW;
     constexpr int LPR = NL / 2;             // lanes per position: one float4 = two adjacent columns
     constexpr int ROWS = T / LPR;
     constexpr int NIT = (L + ROWS - 1) / ROWS;
@@ -78,6 +100,34 @@ void k_fft_lines(LinesArgs p)
     const int c2 = (tid % LPR) * 2;
     const int r0 = tid / LPR;
     float2* wbuf = buf + wave * LW * LP;    // the lines this wave transforms
+    unsigned int* bar = reinterpret_cast<unsigned int*>(lds + NL * LP + L);   // Cfg::LDS leaves 256 bytes behind the twiddles
+    if (GW > 0) {
+        // bar[0]: the transform waves' barrier counter; bar[1]: the guests'; bar[2..3]: the guests' queue counters / ticket
+        if (tid < 4) bar[tid] = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave >= NW) {
+            __builtin_amdgcn_s_setprio(3);                    // measured: guests at default priority crawl (B + half of phase 1: 0.55 ms; with it 0.52)
+            const int t = tid - T;
+            const long long gb = (long long)blockIdx.y * gridDim.x + blockIdx.x, gn = (long long)gridDim.x * gridDim.y;
+            WavesBarrier gbar{bar + 1, (unsigned int)GW, 0u, lane};
+            P1Scratch* sc = reinterpret_cast<P1Scratch*>(reinterpret_cast<char*>(lds) + ((C::LDS + 15) & ~(size_t)15));
+            if (p.guest.kind == 1) {
+                p1_block_body<true, true>(p.guest.p1, gb, gn, t, sc, bar + 2, gbar, p.guest.it0, p.guest.it1, p.guest.it0 > 0);
+            } else if (p.guest.kind == 2) {
+                for (long long seg = gb; seg < p.guest.nseg; seg += gn) {
+                    resolve_segment_body(p.guest.rs, seg, t, bar + 2, gbar);
+                    gbar();                                   // the ticket is reset for the next segment
+                }
+            } else if (p.guest.kind == 3) {
+                // experiment (tools/guest_probe.py): the sampler's instruction mix without its memory traffic
+                Philox4 r = Philox4{(uint32_t)tid, blockIdx.x, blockIdx.y, 7u};
+                for (long long i = 0; i < p.guest.nseg; ++i) r = philox4x32_10(r.x, r.y, r.z, r.w, 0x1234u + (uint32_t)i, 0x5678u);
+                if ((r.x ^ r.y ^ r.z ^ r.w) == 0x9E3779B9u && p.guest.rs.out) p.guest.rs.out[0] = (float)r.x;
+            }
+            return;
+        }
+    }
 
     // all global loads of the tile are issued before anything waits
     const int by = (int)blockIdx.y >= p.outer_skip_lo ? (int)blockIdx.y + p.outer_skip_len : (int)blockIdx.y;
@@ -108,7 +158,7 @@ void k_fft_lines(LinesArgs p)
             buf[(c2 + 1) * LP + n] = b;
         }
     }
-    __syncthreads();
+    if (GW > 0) waves_barrier(bar, NW, lane); else __syncthreads();
     PLAN::template run<LW>(wbuf, tw, lane);
     if (MODE == CONV) {
         // x PSF spectrum, conjugate, transform again (inverse = conj FFT conj).  The spectrum is stored tile-major
@@ -128,7 +178,7 @@ void k_fft_lines(LinesArgs p)
             }
         return;
     }
-    __syncthreads();
+    if (GW > 0) waves_barrier(bar, 2 * NW, lane); else __syncthreads();
     float2* dbase = p.dst + (long long)by * p.dst_outer + (long long)blockIdx.x * NL + c2;
     const int nstore = p.store_limit > 0 ? p.store_limit : L;
 #pragma unroll
@@ -797,6 +847,25 @@ static int launch_lines_t(mvsim_ctx* ctx, int mode, bool sparse, const LinesArgs
         MVSIM_TRY(set_lds(ctx, k_fft_lines<PLAN, MODE_, SP_>, C::LDS));                           \
         hipLaunchKernelGGL((k_fft_lines<PLAN, MODE_, SP_>), grid, block, C::LDS, s, a);      \
     } while (0)
+    if (a.guest.kind != 0) {
+        if constexpr (lines_guest_capable<PLAN::len>()) {
+            if (sparse || mode == CONV) { set_error("guest waves ride on the plain y passes only"); return MVSIM_EINVAL; }
+            constexpr size_t glds = lines_guest_lds<PLAN::len>();
+            dim3 gblock(C::T + 64 * LINES_GW);
+            if (mode == FWD) {
+                MVSIM_TRY(set_lds(ctx, k_fft_lines<PLAN, FWD, false, LINES_GW>, glds));
+                hipLaunchKernelGGL((k_fft_lines<PLAN, FWD, false, LINES_GW>), grid, gblock, glds, s, a);
+            } else {
+                MVSIM_TRY(set_lds(ctx, k_fft_lines<PLAN, INV, false, LINES_GW>, glds));
+                hipLaunchKernelGGL((k_fft_lines<PLAN, INV, false, LINES_GW>), grid, gblock, glds, s, a);
+            }
+            MVSIM_HIP(hipGetLastError());
+            return MVSIM_OK;
+        } else {
+            set_error("guest waves: the y pass of length %d cannot host them", PLAN::len);
+            return MVSIM_EINVAL;
+        }
+    }
     if (mode == FWD && sparse) MVSIM_LL(FWD, true);
     else if (mode == FWD) MVSIM_LL(FWD, false);
     else if (mode == INV) MVSIM_LL(INV, false);
@@ -903,6 +972,17 @@ static int lines_per_tile(int L)
     return 16;
 }
 
+template <int L> static constexpr bool guest_capable_of() { return lines_guest_capable<L>(); }
+static bool lines_can_host(int L)
+{
+    switch (L) {
+#define X(LL, ...) case LL: return guest_capable_of<LL>();
+        MVSIM_FFT_SIZES(X)
+#undef X
+    }
+    return false;
+}
+
 static int pick_size(int64_t need)
 {
     for (int v : kSizes)
@@ -929,6 +1009,19 @@ bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3],
         }
     }
     return true;
+}
+
+bool fft_can_host_guest(mvsim_ctx* ctx, const int64_t dim[3], const int64_t kdim[3])
+{
+    using namespace fft;
+    int64_t P[3];
+    if (!custom_fft_sizes(dim, kdim, P, ctx->opt)) return false;
+    const bool zdirect = ctx->opt.zpass == 2 ? false : kdim[2] <= 64;
+    if (!zdirect || ctx->opt.kx_panel > 0 || ctx->opt.fuse_tail || !lines_can_host((int)P[1])) return false;
+    const int tile_y = lines_per_tile((int)P[1]);
+    const int tw_max = tile_y > NLZ ? tile_y : NLZ;
+    const int hxp = (((int)(P[0] / 2) + 1 + tw_max - 1) / tw_max) * tw_max;
+    return (long long)(hxp / tile_y) * dim[2] <= 256 * 64;        // one queue segment per block of pass B
 }
 
 // kind 0: per-pass transform table of the plan for length L (see wpasses); kind 1: plain exp(-2 pi i k / L),
@@ -1163,7 +1256,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     MVSIM_TRY(ctx->cfft_g2.reserve((size_t)hxp * pyb * kz * sizeof(float2)));
     MVSIM_TRY(ctx->partials.reserve((size_t)(SUM_BLOCKS + 8) * sizeof(double)));
     MVSIM_TRY(ctx->partials_e.reserve((size_t)((rows_out_early + 3) / 4 + 16) * sizeof(double)));
-    double* scal = ctx->partials.as<double>() + SUM_BLOCKS;
+    double* scal = scal_of(ctx);
 
     const float2 *tw_m, *tw_px, *tw_py, *tw_pz;
     MVSIM_TRY(ensure_twiddles(ctx, M, 0, &tw_m));
@@ -1324,10 +1417,42 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         const int nk = (nzd - 1) / zstride + 1;                       // planes 0, zstride, 2 zstride, ...
         if (pcols > 0) Fz = G;
         else {
+        // the previous view's extract + Poisson as guest waves: phase 1 beside pass B, the resolver beside pass D (option guest_tail)
+        DeferredTail* guest = (tail && tail->guest && tail->guest->valid && zdirect && !is_slab && !fuse) ? tail->guest : nullptr;
+        if (tail && tail->guest && tail->guest->valid && (!guest || !lines_can_host(py))) {
+            set_error("guest tail: this convolution cannot carry the previous view's sampler (the caller must flush it first)");
+            return MVSIM_EINVAL;
+        }
+        const long long gblocks = (long long)(hxp / tile_y) * nzs;
+        ResolveJob guest_rs{};
+        long long guest_trips = 0, guest_split = 0, guest_end = 0;
+        P1Job guest_p1{};
+        if (guest) {
+            const int64_t n_out = guest->dim[0] * guest->dim[1] * ((guest->dim[2] - 1) / guest->inc + 1);
+            MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_blocks(n_out, gblocks)));
+            b.guest.kind = 1;
+            if (!poisson_make_jobs(*guest, gblocks, ctx->pqueue.p, &b.guest.p1, &guest_rs)) {
+                set_error("guest tail: the deferred extract + Poisson cannot take the vector path");
+                return MVSIM_EINVAL;
+            }
+            // phase 1 is dealt over the two y passes (half of every block's trips each) when pass D runs the same grid
+            guest_trips = (long long)(b.guest.p1.segcap / 1024u);
+            guest_split = (nzo == nzs && zstride == 1) ? (guest_trips + 1) / 2 : guest_trips;
+            guest_end = guest_trips;
+            if (ctx->opt.guest_trips[0] >= 0) {
+                guest_split = std::min<long long>(ctx->opt.guest_trips[0], guest_trips);
+                guest_end = (nzo == nzs && zstride == 1) ? std::min<long long>(guest_split + std::max(ctx->opt.guest_trips[1], 0), guest_trips) : guest_split;
+            }
+            b.guest.it0 = 0; b.guest.it1 = guest_split;
+            if (guest_split == 0) b.guest.kind = 0;
+        } else if (ctx->opt.exp_guest >= 0 && zdirect && !is_slab && lines_can_host(py)) {
+            b.guest.kind = 3; b.guest.nseg = ctx->opt.exp_guest;
+        }
         ev_begin(ctx, ST_PASS_B);
         MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
         ev_end(ctx, ST_PASS_B);
         b.lmap = ident_none; b.src_mirror = 0;
+        if (guest) { guest_p1 = b.guest.p1; b.guest.kind = guest_split < guest_end ? 1 : 0; b.guest.it0 = guest_split; b.guest.it1 = guest_end; }
         if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));    // the z pass reads the PSF spectrum
         ev_begin(ctx, ST_PASS_C);
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
@@ -1375,6 +1500,14 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         ev_begin(ctx, ST_PASS_D);
         MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, nk));
         ev_end(ctx, ST_PASS_D);
+        if (guest) {
+            if (guest_end < guest_trips) MVSIM_TRY(launch_poisson_phase1(s, guest_p1, gblocks, guest_end, guest_trips, guest_end > 0));
+            // the resolver as a kernel of its own: its work items are dependent 32-byte reads, nothing a guest wave can wait for
+            MVSIM_TRY(launch_poisson_resolve(s, guest_rs.out, const_cast<PItem*>(guest_rs.queue), guest_rs.qcount, (int)gblocks, guest_rs.segcap,
+                                             guest_rs.mul, guest->seed, guest_rs.stream));
+            guest->valid = false;                                     // all of it is enqueued
+        }
+        b.guest.kind = 0;
         }
         C2RFuse fz{};
         if (fuse) {
@@ -1398,6 +1531,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
                 fz.segcap = fsegcap;
             }
         }
+        if (tail && tail->join_before_e) MVSIM_TRY(join_tail(ctx));
         ev_begin(ctx, ST_PASS_E);
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
         const float scale = (float)(0.25 / ((double)px * (double)py * (zdirect ? 1.0 : (double)pz)));

@@ -275,7 +275,7 @@ int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], con
     float2* F = ctx->fft_spec_img.as<float2>();
     float2* G = ctx->fft_spec_psf.as<float2>();
     double* partial = ctx->partials.as<double>();
-    double* scal = partial + SUM_BLOCKS;
+    double* scal = scal_of(ctx);
 
     // kernel spectrum
     ev_begin(ctx, ST_PSF);

@@ -653,12 +653,6 @@ int launch_adjust_corr(hipStream_t s, double* scal, int64_t n, float min_value, 
     return MVSIM_OK;
 }
 
-__device__ __forceinline__ float adjust_one(float v, double corr, float min_value)
-{
-    const float t = (float)((double)v * corr);  // pass 1, Tools.java:150-151
-    return t + min_value;                       // pass 2, Tools.java:154-155 (second rounding, Q6)
-}
-
 __global__ __launch_bounds__(256) void k_adjust_apply(float* __restrict__ img, long long n,
                                                       const double* __restrict__ scal, float min_value)
 {
@@ -784,120 +778,36 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
 //                      runs once per voxel slot with 1-in-7 lanes active.
 // Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.
 template <bool ADJUST>
-__global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict__ in, float* __restrict__ out,
-                                                         long long plane4, long long nzo, int inc, int idx_inc,
-                                                         const double* __restrict__ scal, float min_value, double mul,
-                                                         uint32_t k0, uint32_t k1, uint32_t stream,
-                                                         unsigned long long index_offset, PItem* __restrict__ queue,
-                                                         unsigned int* __restrict__ qcount, unsigned int segcap)
+__global__ __launch_bounds__(256) void k_extract4_noise2(P1Job job, long long it0, long long it1, int resume)
 {
-    __shared__ unsigned int nq, nqs;
+    __shared__ unsigned int ctr[2];
     __shared__ P1Scratch scratch[4];
-    if (threadIdx.x == 0) { nq = 0u; nqs = 0u; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    P1Args pa;
-    pa.mul = mul; pa.mulf = (float)mul; pa.k0 = k0; pa.k1 = k1; pa.stream = stream;
-    pa.seg = queue + (unsigned long long)blockIdx.x * segcap; pa.segcap = segcap; pa.nq = &nq; pa.nqs = &nqs;
-    double corr = 1.0;
-    if (ADJUST) corr = scal[1];
-    const long long total4 = plane4 * nzo;
-    const long long nthreads = (long long)gridDim.x * 256;
-    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
-    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
-    const bool small32 = total4 < (1ll << 32);
-    // the trip count is uniform per wave (lanes past the end carry invalid voxels): ballots need every lane
-    const long long wave_first = (long long)blockIdx.x * 256 + wave * 64;
-    for (long long o0 = wave_first; o0 < total4; o0 += nthreads) {
-        const long long o = o0 + lane;
-        const bool valid = o < total4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        long long src4 = o, idx4 = o;                 // where the voxels are read / what the RNG counter says they are
-        if (valid) {
-            if (inc != 1 || idx_inc != 1) {
-                const long long k = small32 ? (long long)((unsigned)o / (unsigned)plane4) : o / plane4;
-                src4 = k * inc * plane4 + (o - k * plane4);
-                idx4 = k * idx_inc * plane4 + (o - k * plane4);
-            }
-            v = in4[src4];
-            if (ADJUST) {
-                v.x = adjust_one(v.x, corr, min_value);
-                v.y = adjust_one(v.y, corr, min_value);
-                v.z = adjust_one(v.z, corr, min_value);
-                v.w = adjust_one(v.w, corr, min_value);
-            }
-        }
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        float ov[4];
-        poisson_phase1(vv, valid, index_offset + 4ull * (unsigned long long)idx4, 4ull * (unsigned long long)o, pa, &scratch[wave], lane, ov);
-        if (valid) out4[o] = make_float4(ov[0], ov[1], ov[2], ov[3]);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        qcount[2 * blockIdx.x] = nq;
-        qcount[2 * blockIdx.x + 1] = nqs;
-    }
+    BlockBarrier bar;
+    p1_block_body<ADJUST, false>(job, (long long)blockIdx.x, (long long)gridDim.x, (int)threadIdx.x, scratch, ctr, bar, it0, it1, resume != 0);
 }
 
-// One block per queue segment (same grid as k_extract4_noise; the grid-stride walk of that kernel spreads the
-// bright voxels evenly over the segments).
-__global__ __launch_bounds__(256) void k_poisson_resolve(float* __restrict__ out, const PItem* __restrict__ queue,
-                                                         const unsigned int* __restrict__ qcount, unsigned int segcap,
-                                                         double mul, uint32_t k0, uint32_t k1, uint32_t stream)
+// the trips [it0, it1) of phase 1 as a kernel of its own over `blocks` blocks (what guest waves left over: resume = 1)
+int launch_poisson_phase1(hipStream_t s, const P1Job& job, long long blocks, long long it0, long long it1, bool resume)
 {
-    const unsigned int n = qcount[2 * blockIdx.x], ns = qcount[2 * blockIdx.x + 1];
-    const PItem* __restrict__ seg = queue + (unsigned long long)blockIdx.x * segcap;
-    // inversion items (0 < lambda < 10 that the shortcut of k_extract4_noise could not settle), from the back
-    for (unsigned int i = threadIdx.x; i < ns; i += 256u) {
-        const PItem it = seg[segcap - 1u - i];
-        out[it.out] = poisson_small((double)it.v * mul, it.w0);     // w0: the voxel's word of its group block
-    }
-    // PTRS items.  A lane works on ONE ATTEMPT per trip and, the moment its item is resolved, takes the next item of the
-    // segment (LDS ticket): every trip has every lane on a live attempt, instead of the wave idling until its unluckiest
-    // item -- retries come in geometrically distributed numbers -- has been accepted.  The loop ends when the tickets run
-    // out: each attempt succeeds with probability > 0.8 and the attempt count is capped, so every lane gets there.
+    hipLaunchKernelGGL((k_extract4_noise2<true>), dim3((unsigned)blocks), dim3(256), 0, s, job, it0, it1, resume ? 1 : 0);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// One block per queue segment (same grid as k_extract4_noise2; the grid-stride walk of that kernel spreads the
+// bright voxels evenly over the segments).
+__global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job)
+{
     __shared__ unsigned int ticket;
-    if (threadIdx.x == 0) ticket = 256u;
-    __syncthreads();
-    unsigned int i = threadIdx.x;
-    PItem it;
-    it.index = 0ull; it.out = 0ull; it.v = 0.f; it.attempt = 0u; it.w0 = 0u; it.w1 = 0u;
-    bool have = i < n;
-    if (have) it = seg[i];
-    uint32_t a = it.attempt;
-    while (have) {
-        const double lam = (double)it.v * mul;
-        float val = 0.f;
-        bool done;
-        if (a >= kPtrsMaxAttempts) {
-            val = (float)(long long)lam;
-            done = true;
-        } else {
-            uint32_t w0, w1;
-            if (a == 0u) {
-                w0 = it.w0;                                          // the words phase 1 drew for attempt 0
-                w1 = it.w1;
-            } else {
-                ptrs_retry_words(it.index, a, k0, k1, stream, w0, w1);
-            }
-            done = ptrs_step_words(lam, w0, w1, val);
-        }
-        if (done) {
-            out[it.out] = val;
-            i = atomicAdd(&ticket, 1u);
-            have = i < n;
-            if (have) { it = seg[i]; a = it.attempt; }
-        } else {
-            a += 1u;
-        }
-    }
+    BlockBarrier bar;
+    resolve_segment_body(job, (long long)blockIdx.x, (int)threadIdx.x, &ticket, bar);
 }
 
 int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
                            double mul, uint64_t seed, uint32_t stream)
 {
-    hipLaunchKernelGGL(k_poisson_resolve, dim3(segments), dim3(256), 0, s, out, reinterpret_cast<const PItem*>(queue_items), qcount, segcap,
-                       mul, (uint32_t)seed, (uint32_t)(seed >> 32), stream);
+    const ResolveJob job{out, reinterpret_cast<const PItem*>(queue_items), qcount, segcap, mul, (uint32_t)seed, (uint32_t)(seed >> 32), stream};
+    hipLaunchKernelGGL(k_poisson_resolve, dim3(segments), dim3(256), 0, s, job);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
@@ -923,6 +833,40 @@ size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)
     return (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);   // [counts][segments]
 }
 
+static unsigned int segcap_for_blocks(int64_t n_out, long long blocks)
+{
+    const long long iters = (n_out / 4 + blocks * 256 - 1) / (blocks * 256);
+    return (unsigned int)(iters * 1024);
+}
+
+size_t poisson_queue_bytes_blocks(int64_t n_out, long long blocks)
+{
+    if (blocks <= 0) return poisson_queue_bytes(n_out, nullptr);
+    return (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap_for_blocks(n_out, blocks) * sizeof(PItem);
+}
+
+static bool extract_vec_ok(const float* in, const float* out, long long plane, uint64_t index_offset)
+{
+    return (plane % 4 == 0) && (index_offset % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+}
+
+bool poisson_make_jobs(const DeferredTail& t, long long blocks, void* queue_ws, P1Job* p1, ResolveJob* rs)
+{
+    const int index_inc = t.index_inc > 0 ? t.index_inc : t.inc;
+    const long long plane = (long long)t.dim[0] * t.dim[1];
+    const long long nzo = (t.dim[2] - 1) / t.inc + 1;
+    if (!extract_vec_ok(t.in, t.out, plane, 0) || blocks < 1 || blocks > POISSON_MAX_BLOCKS || !queue_ws ||
+        (long long)(index_inc - 1) * plane >= (1ll << 31))
+        return false;
+    const unsigned int segcap = segcap_for_blocks(plane * nzo, blocks);
+    unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
+    PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int));
+    const uint32_t k0 = (uint32_t)t.seed, k1 = (uint32_t)(t.seed >> 32);
+    *p1 = P1Job{t.in, t.out, plane / 4, nzo, t.inc, index_inc, t.scal, t.min_value, t.mul, k0, k1, t.stream, 0ull, queue, qcount, segcap};
+    *rs = ResolveJob{t.out, queue, qcount, segcap, t.mul, k0, k1, t.stream};
+    return true;
+}
+
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
                    uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc)
@@ -930,8 +874,10 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
     // index_inc: plane stride of the RNG counter when it differs from the plane stride of the reads (a compact input
     // that holds only the planes k * index_inc of the source volume); 0 = the same as inc
     if (index_inc <= 0) index_inc = inc;
-    const bool use_queue = queue_mode != 0;
     const long long plane = (long long)dim[0] * dim[1];
+    // phase 1 hands a slot's RNG counters across lanes as 32-bit offsets from lane 0's (poisson_phase1): a slot that straddles
+    // two acquired planes must not see them 2^32 voxels apart
+    const bool use_queue = queue_mode != 0 && (long long)(index_inc - 1) * plane < (1ll << 31);
     const long long nzo = (dim[2] - 1) / inc + 1;
     const long long total = plane * nzo;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -949,14 +895,12 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
             poisson_geometry(total, &qblocks, &segcap);
             unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
             PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int));
-            if (adjust) {
-                hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
-                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
-            } else {
-                hipLaunchKernelGGL((k_extract4_noise2<false>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
-                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
-            }
-            hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks), dim3(256), 0, s, out, queue, qcount, segcap, mul, k0, k1, stream);
+            const P1Job job{in, out, plane / 4, nzo, inc, index_inc, scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset,
+                            queue, qcount, segcap};
+            if (adjust) hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks), dim3(256), 0, s, job, 0ll, 1ll << 40, 0);
+            else hipLaunchKernelGGL((k_extract4_noise2<false>), dim3(qblocks), dim3(256), 0, s, job, 0ll, 1ll << 40, 0);
+            const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream};
+            hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks), dim3(256), 0, s, rjob);
         }
         else if (adjust && noise) MVSIM_LAUNCH_EX4(true, true);
         else if (adjust) MVSIM_LAUNCH_EX4(true, false);
