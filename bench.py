@@ -125,6 +125,14 @@ def self_launch(args) -> int:
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     alive = set(range(n))
+
+    # SIGTERM / SIGINT to the launcher must not orphan its ranks (they would keep the GPUs and the rendezvous port): turn
+    # the signal into an exception so that the `finally` below runs.  A SIGKILL cannot be caught here: for that case every
+    # rank asks the kernel for a SIGTERM when its parent dies (die_with_parent, first thing in the child).
+    def on_signal(signum, _frame):
+        raise KeyboardInterrupt(f"signal {signum}")
+    import signal
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     try:
         while alive:
             for r in sorted(alive):
@@ -149,7 +157,24 @@ def self_launch(args) -> int:
                 procs[q].wait(timeout=10)
             except subprocess.TimeoutExpired:
                 procs[q].kill()
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
+
+
+def die_with_parent() -> None:
+    """A rank started by self_launch: have the kernel send SIGTERM when the launcher dies, however it dies (SIGKILL from a
+    caller's timeout included).  prctl(PR_SET_PDEATHSIG) through ctypes, before torch or HIP are touched; if the launcher
+    is gone already, leave now."""
+    import signal
+    try:
+        libc = C.CDLL(None, use_errno=True)
+        PR_SET_PDEATHSIG = 1
+        libc.prctl(PR_SET_PDEATHSIG, int(signal.SIGTERM), 0, 0, 0)
+    except Exception:
+        return
+    if os.getppid() == 1:
+        sys.exit(1)
 
 
 def rccl_report(mvs, torch) -> dict:
@@ -496,6 +521,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: become one.  Nothing in this process has imported torch or touched a GPU yet.
         raise SystemExit(self_launch(args))
+    if os.environ.get("MVSIM_BENCH_SELF_LAUNCHED") == "1":
+        die_with_parent()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -38,9 +38,22 @@ def source_sha() -> str:
     return h.hexdigest()[:16]
 
 
+def _common_flags():
+    return [
+        "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+        *os.environ.get("MVSIM_EXTRA_CFLAGS", "").split(),
+        "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROCM, "include"),
+    ]
+
+
 def is_current() -> bool:
-    if not os.path.exists(LIB):
+    """The library exists, is newer than every source and was built with the flags this process would use (an experiment
+    build with MVSIM_EXTRA_CFLAGS never passes for the product build)."""
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".flags"):
         return False
+    with open(LIB + ".flags") as fh:
+        if fh.read() != " ".join(_common_flags()):
+            return False
     t = os.path.getmtime(LIB)
     deps = sources() + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)]
     return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
@@ -57,27 +70,38 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    common = [
-        "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-        *os.environ.get("MVSIM_EXTRA_CFLAGS", "").split(),
-        "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROCM, "include"),
-    ]
+    common = _common_flags()
+    # per-object rebuild: an object is kept when it is newer than its source, every header and this recipe, and was built
+    # with the same flags (recorded beside it) -- fft_kernels.hip alone takes ~1.5 min
+    flags_id = " ".join(common)
+    hdr_time = max(os.path.getmtime(os.path.normpath(os.path.join(CSRC, h))) for h in HEADERS)
+    hdr_time = max(hdr_time, os.path.getmtime(os.path.abspath(__file__)))
     procs = []
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        objs.append(obj)
+        stamp = obj + ".flags"
+        fresh = (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == flags_id
+                 and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time))
+        if fresh:
+            continue
         cmd = [hipcc, "-x", "hip", "-c", src, "-o", obj] + common
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
+        procs.append((src, stamp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
-    for src, p in procs:
+    for src, stamp, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             failed = True
+            if os.path.exists(stamp):
+                os.remove(stamp)
             sys.stderr.write(f"--- {src} ---\n{out}\n")
-        elif verbose and out.strip():
-            sys.stderr.write(out)
+        else:
+            with open(stamp, "w") as fh:
+                fh.write(flags_id)
+            if verbose and out.strip():
+                sys.stderr.write(out)
     if failed:
         raise RuntimeError("hipcc failed")
     link = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + [
@@ -86,6 +110,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)
+    with open(LIB + ".flags", "w") as fh:
+        fh.write(flags_id)
     return LIB
 
 

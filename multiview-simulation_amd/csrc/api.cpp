@@ -285,6 +285,12 @@ int flush_tail(mvsim_ctx* ctx)
     return MVSIM_OK;
 }
 
+int settle_tail(mvsim_ctx* ctx)
+{
+    MVSIM_TRY(join_tail(ctx));
+    return flush_tail(ctx);
+}
+
 // every entry point starts here: the device, and a pending tail ordered in front of what the call enqueues
 static int set_device(mvsim_ctx* ctx, bool keep_tail = false)
 {
@@ -743,6 +749,12 @@ int mvsim_normalize_weights(mvsim_ctx* ctx, float* const* weights, int n_views, 
 // ---- fused per-view pipeline ------------------------------------------------------------------------
 // Everything a view enqueues on the context stream behind the PSF upload: kernel launches only (no allocation once the
 // workspaces have their size, no host synchronisation) -- which is what makes it capturable into a hipGraph.
+// The host slabs of the *_zslabs entry points belong to the caller again when the call returns -- on EVERY path: copies from
+// page-locked slabs are truly asynchronous, so an error return must not leave one in flight.
+struct SyncOnExit {
+    mvsim_ctx* c;
+    ~SyncOnExit() { if (c && c->stream) (void)hipStreamSynchronize(c->stream); }
+};
 struct StreamSwap {               // enqueue on another stream for a scope; the context's stream comes back on every exit path
     mvsim_ctx* c;
     hipStream_t saved;
@@ -1329,7 +1341,7 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], f
     if (rc == MVSIM_OK) rc = ctx->out_buf.reserve(obytes);
     dev.acq = ctx->out_buf.as<float>();
     if (rc == MVSIM_OK) rc = mvsim_simulate_view_dev(ctx, gt_d.as<float>(), dim, psf_host, kdim, p, &dev, correction);
-    if (rc == MVSIM_OK) rc = join_tail(ctx);                  // the copies below read what the tail writes
+    if (rc == MVSIM_OK) rc = settle_tail(ctx);                // the copies below read what the tail writes
     if (rc == MVSIM_OK && o->rot) rc = down(ctx, o->rot, dev.rot, vbytes);
     if (rc == MVSIM_OK && o->att) rc = down(ctx, o->att, dev.att, vbytes);
     if (rc == MVSIM_OK && o->con) rc = down(ctx, o->con, dev.con, vbytes);
@@ -1441,7 +1453,7 @@ int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt, uint64_t gt_gener
             if (ctx->async_inflight[q]) MVSIM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_d2h[q], 0));
     }
     int rc = mvsim_simulate_view_dev(ctx, ctx->async_gt[s].as<float>(), dim, psf_host, kdim, p, &dev, nullptr);
-    if (rc == MVSIM_OK) rc = join_tail(ctx);                  // the copies below read what the tail writes
+    if (rc == MVSIM_OK) rc = settle_tail(ctx);                // the copies below read what the tail writes
     if (rc != MVSIM_OK) { ctx->async_gt_src[s] = nullptr; return rc; }
     {
         double *partial, *scal;
@@ -1485,6 +1497,7 @@ int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, con
                                float* const* acq_slabs, const int64_t* acq_slab_nz, int n_acq_slabs, double* correction)
 {
     MVSIM_TRY(set_device(ctx));
+    SyncOnExit sync{ctx};
     MVSIM_TRY(check_dim(dim));
     MVSIM_CHECK_ARG(gt_slabs && gt_slab_nz && acq_slabs && acq_slab_nz && p, "null pointer");
     MVSIM_CHECK_ARG(n_gt_slabs >= 1 && n_acq_slabs >= 1 && p->inc >= 1, "slab counts and inc must be >= 1");
@@ -1505,7 +1518,7 @@ int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, con
     }
     mvsim_view_outputs dev = {nullptr, nullptr, nullptr, ctx->out_buf.as<float>()};
     int rc = mvsim_simulate_view_dev(ctx, ctx->host_gt.as<float>(), dim, psf_host, kdim, p, &dev, correction);
-    if (rc == MVSIM_OK) rc = join_tail(ctx);                  // the copies below read what the tail writes
+    if (rc == MVSIM_OK) rc = settle_tail(ctx);                // the copies below read what the tail writes
     z = 0;
     for (int j = 0; j < n_acq_slabs && rc == MVSIM_OK; ++j) {
         if (hipMemcpyAsync(acq_slabs[j], dev.acq + plane * z, (size_t)(plane * acq_slab_nz[j]) * sizeof(float), hipMemcpyDeviceToHost,
@@ -1576,6 +1589,7 @@ int mvsim_rotate_around_axis_zslabs(mvsim_ctx* ctx, const float* const* in_slabs
                                     int axis, int degrees, float* const* out_slabs, const int64_t* out_slab_nz, int n_out)
 {
     SlabList in, out;
+    SyncOnExit sync{ctx};
     MVSIM_TRY(slabs_in(ctx, in_slabs, in_slab_nz, n_in, dim, out_slabs, out_slab_nz, n_out, dim ? dim[2] : 0, &in, &out));
     MVSIM_TRY(mvsim_rotate_around_axis_dev(ctx, ctx->vol_a.as<float>(), dim, axis, degrees, ctx->vol_b.as<float>()));
     return download_slabs(ctx, out, dim[0] * dim[1], ctx->vol_b.as<float>());
@@ -1585,6 +1599,7 @@ int mvsim_attenuate3d_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const
                              double delta, float* const* out_slabs, const int64_t* out_slab_nz, int n_out)
 {
     SlabList in, out;
+    SyncOnExit sync{ctx};
     MVSIM_TRY(slabs_in(ctx, in_slabs, in_slab_nz, n_in, dim, out_slabs, out_slab_nz, n_out, dim ? dim[2] : 0, &in, &out));
     MVSIM_TRY(mvsim_attenuate3d_dev(ctx, ctx->vol_a.as<float>(), dim, delta, ctx->vol_b.as<float>()));
     return download_slabs(ctx, out, dim[0] * dim[1], ctx->vol_b.as<float>());
@@ -1594,6 +1609,7 @@ int mvsim_convolve_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, const in
                           float* psf, const int64_t kdim[3], int method, float* const* out_slabs, const int64_t* out_slab_nz, int n_out)
 {
     SlabList in, out;
+    SyncOnExit sync{ctx};
     MVSIM_TRY(slabs_in(ctx, in_slabs, in_slab_nz, n_in, dim, out_slabs, out_slab_nz, n_out, dim ? dim[2] : 0, &in, &out));
     MVSIM_TRY(mvsim_convolve_dev(ctx, ctx->vol_a.as<float>(), dim, psf, kdim, method, ctx->vol_b.as<float>()));
     return download_slabs(ctx, out, dim[0] * dim[1], ctx->vol_b.as<float>());
@@ -1605,9 +1621,10 @@ int mvsim_extract_slices_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, co
 {
     MVSIM_CHECK_ARG(inc >= 1, "inc must be >= 1");
     SlabList in, out;
+    SyncOnExit sync{ctx};
     MVSIM_TRY(slabs_in(ctx, in_slabs, in_slab_nz, n_in, dim, out_slabs, out_slab_nz, n_out, dim ? mvsim_extract_nz(dim[2], inc) : 0, &in, &out));
     MVSIM_TRY(mvsim_extract_slices_dev(ctx, ctx->vol_a.as<float>(), dim, inc, snr, seed, stream, ctx->vol_b.as<float>()));
-    MVSIM_TRY(join_tail(ctx));
+    MVSIM_TRY(settle_tail(ctx));
     return download_slabs(ctx, out, dim[0] * dim[1], ctx->vol_b.as<float>());
 }
 

@@ -121,7 +121,7 @@ int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, i
     MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
     MVSIM_CHECK_ARG(root >= 0 && root < ctx->nranks, "root out of range");
     MVSIM_HIP(hipSetDevice(ctx->device));
-    MVSIM_TRY(mvsim::join_tail(ctx));
+    MVSIM_TRY(mvsim::settle_tail(ctx));
     if (count == 0) return MVSIM_OK;
     for (int phase = 0; phase < 3; ++phase) MVSIM_TRY(bcast_phase(ctx, vol_dev, count, root, phase));
     return MVSIM_OK;
@@ -132,7 +132,7 @@ int mvsim_comm_allreduce_sum(mvsim_ctx* ctx, float* buf_dev, int64_t count)
     MVSIM_CHECK_ARG(ctx != nullptr && buf_dev != nullptr && count >= 0, "null pointer or negative count");
     MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
     MVSIM_HIP(hipSetDevice(ctx->device));
-    MVSIM_TRY(mvsim::join_tail(ctx));
+    MVSIM_TRY(mvsim::settle_tail(ctx));
     MVSIM_NCCL(ncclAllReduce(buf_dev, buf_dev, (size_t)count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
     return MVSIM_OK;
 }
@@ -142,7 +142,7 @@ int mvsim_comm_allreduce_sum_f64(mvsim_ctx* ctx, double* value_host)
     MVSIM_CHECK_ARG(ctx != nullptr && value_host != nullptr, "null pointer");
     MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
     MVSIM_HIP(hipSetDevice(ctx->device));
-    MVSIM_TRY(mvsim::join_tail(ctx));
+    MVSIM_TRY(mvsim::settle_tail(ctx));
     MVSIM_TRY(ctx->partials.reserve((mvsim::SUM_BLOCKS + 8) * sizeof(double)));
     double* slot = ctx->partials.as<double>() + mvsim::SUM_BLOCKS + 4;        // scratch behind [sum, corr]
     MVSIM_HIP(hipMemcpyAsync(slot, value_host, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -254,10 +254,11 @@ int mvsim_group_broadcast_volume(mvsim_group* g, const float* gt_host, const int
     // gt_host belongs to the caller again when this function returns (header: "keeps no reference to the pointers
     // afterwards"): the upload is waited for below, after the collectives behind it have been enqueued
     hipEvent_t uploaded = nullptr;
-    MVSIM_HIP(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming));
-    if (hipEventRecord(uploaded, g->ctx[0]->stream) != hipSuccess) {
-        (void)hipEventDestroy(uploaded);
-        mvsim::set_error("hipEventRecord failed");
+    if (hipEventCreateWithFlags(&uploaded, hipEventDisableTiming) != hipSuccess || hipEventRecord(uploaded, g->ctx[0]->stream) != hipSuccess) {
+        // no event to wait on later: wait for the upload here, so that gt_host is the caller's again on this path too
+        if (uploaded) (void)hipEventDestroy(uploaded);
+        (void)hipStreamSynchronize(g->ctx[0]->stream);
+        mvsim::set_error("hipEventCreate / hipEventRecord failed");
         return MVSIM_EHIP;
     }
     struct EventGuard {
@@ -297,7 +298,7 @@ int mvsim_group_simulate_views(mvsim_group* g, float* const* psf_host, const int
         rc = g->acq[(size_t)i].reserve(obytes);                               // stream order makes the reuse per device safe
         mvsim_view_outputs o = {nullptr, nullptr, nullptr, g->acq[(size_t)i].as<float>()};
         if (rc == MVSIM_OK) rc = mvsim_simulate_view_dev(c, g->gt[(size_t)i].as<float>(), g->dim, psf_host[v], kdim, &params[v], &o, nullptr);
-        if (rc == MVSIM_OK) rc = mvsim::join_tail(c);                       // the download below reads what the tail writes
+        if (rc == MVSIM_OK) rc = mvsim::settle_tail(c);                     // the download below reads what the tail writes
         if (rc == MVSIM_OK && hipMemcpyAsync(acq_host[v], o.acq, obytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
             mvsim::set_error("download of view %d failed", v);
             rc = MVSIM_EHIP;

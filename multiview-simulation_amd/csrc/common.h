@@ -355,6 +355,8 @@ struct ConvTail {
 bool fft_can_host_guest(mvsim_ctx* ctx, const int64_t dim[3], const int64_t kdim[3]);
 // enqueue a deferred tail as kernels of its own on the context's stream (no-op without one)
 int  flush_tail(mvsim_ctx* ctx);
+// join_tail + flush_tail: after it everything the last view produces is ordered on ctx->stream
+int  settle_tail(mvsim_ctx* ctx);
 // bytes of the Poisson work queue when `blocks` blocks share the n_out voxels (blocks <= 0: the stand-alone geometry)
 size_t poisson_queue_bytes_blocks(int64_t n_out, long long blocks);
 // bytes of queue workspace the fused tail needs for this geometry (0: the geometry has no fused tail)

@@ -64,8 +64,44 @@ def phantom():
     json.dump(d, open(os.path.join(HERE, "phantom_vectors.json"), "w"), indent=1)
 
 
+REF_CASES = [
+    # name        nx  ny  nz  kx ky kz axis deg  delta inc  min     target snr  seed
+    ("c24",       24, 24, 24, 7, 7, 9, 0,   60,  0.01, 3,   1e-4,   1.0,   25., 464232194),
+    ("a404420",   40, 44, 20, 5, 7, 9, 0,  -15,  0.01, 2,   1e-4,   1.0,   25., 464232194),
+    ("ax1",       20, 24, 28, 5, 5, 5, 1,   30,  0.02, 1,   1e-4,   1.0,   10., 7),
+    ("ax2",       20, 24, 28, 3, 5, 7, 2,  135,  0.005, 4,  1e-4,   2.0,   40., 11),
+]
+
+
+def ref_case_inputs(name, nx, ny, nz, kx, ky, kz):
+    """The (deterministic) inputs of a reference-dump case: a sphere cloud cropped to the shape, an anisotropic Gaussian PSF
+    with a small non-separable term, un-normalised."""
+    n = max(nx, ny, nz)
+    gt = np.ascontiguousarray(synth.sphere_phantom(n)[(n - nz) // 2:(n - nz) // 2 + nz, (n - ny) // 2:(n - ny) // 2 + ny,
+                                                      (n - nx) // 2:(n - nx) // 2 + nx])
+    psf = synth.gaussian_psf(kx, ky, kz, sigma=(0.9 + kx / 8, 1.0 + ky / 8, 1.2 + kz / 6)).astype(np.float64)
+    z, y, x = np.meshgrid(np.arange(kz) - kz // 2, np.arange(ky) - ky // 2, np.arange(kx) - kx // 2, indexing="ij")
+    psf = (psf * (1.0 + 0.25 * np.tanh(0.5 * x * z) + 0.1 * np.tanh(y))).astype(np.float32)
+    return gt.astype(np.float32), psf
+
+
+def ref_inputs():
+    """Raw float32 inputs + manifest for java/harness/DumpReference.java (the reference run on a host with a JDK)."""
+    d = os.path.join(HERE, "ref_in")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "manifest.txt"), "w") as fh:
+        fh.write("# name nx ny nz kx ky kz axis degrees delta inc minValue targetAverage snr seed\n")
+        for c in REF_CASES:
+            name = c[0]
+            gt, psf = ref_case_inputs(*c[:7])
+            gt.astype("<f4").tofile(os.path.join(d, name + ".gt.raw"))
+            psf.astype("<f4").tofile(os.path.join(d, name + ".psf.raw"))
+            fh.write(" ".join(repr(v) if isinstance(v, float) else str(v) for v in c) + "\n")
+
+
 if __name__ == "__main__":
     jdk()
     view()
     phantom()
+    ref_inputs()
     print("golden fixtures written to", HERE)
