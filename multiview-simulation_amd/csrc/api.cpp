@@ -777,7 +777,8 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     float* rot = o->rot;
     float* att = o->att;
     float* con = o->con;
-    if (!att) { MVSIM_TRY(ctx->vol_b.reserve(vbytes)); att = ctx->vol_b.as<float>(); }
+    // (the attenuated volume gets its scratch only where a kernel writes it: behind the fused rotate + attenuate + x transform
+    // nothing does, and a 512^3 / 1024^3 view keeps 0.5 / 4 GiB of HBM it would never touch)
     if (ctx->deferred.valid || ctx->tail_pending) ctx->scal_slot ^= 1;          // the deferred tail reads its view's adjust factor until it has run
     if (ctx->deferred.valid) {
         // the previous view's extract + Poisson has not run yet (it rides in this view's y passes): nothing this view does before
@@ -814,9 +815,13 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     if (pick_method(p->conv_method, kdim) == 1)
         MVSIM_TRY(rotate_attenuate_fftx(ctx, gt, rot, o->att, dim, kdim, inv, p->delta, &x_done));
     fused = x_done;
-    if (!x_done) MVSIM_TRY(launch_rotate_attenuate(ctx->stream, gt, rot, att, dim, inv, p->delta, ctx->opt.fused_rotate, &fused));
+    if (!x_done) {
+        if (!att) { MVSIM_TRY(ctx->vol_b.reserve(vbytes)); att = ctx->vol_b.as<float>(); }
+        MVSIM_TRY(launch_rotate_attenuate(ctx->stream, gt, rot, att, dim, inv, p->delta, ctx->opt.fused_rotate, &fused));
+    }
     if (!fused) {
         MVSIM_TRY(join_tail(ctx));                      // the rotation scratch is the buffer a pending tail reads
+        MVSIM_TRY(flush_tail(ctx));                     // ... and a deferred one (it runs now, as kernels of its own)
         if (!rot) { MVSIM_TRY(ctx->vol_a.reserve(vbytes)); rot = ctx->vol_a.as<float>(); }
         MVSIM_TRY(launch_rotate(ctx->stream, gt, rot, dim, inv));
     }

@@ -1346,6 +1346,66 @@ def test_hipgraph_replay_of_views(mvs, synth):
             c.dev_free(d)
 
 
+def test_coscheduling_options_keep_the_results(mvs, synth):
+    """Round 4's ways of letting the sampler share the chip with the next view's convolution (profiles/r04_coschedule.txt):
+    guest waves inside passes B and D (guest_tail, with the trips split several ways), the tail stream joined only in front of pass E
+    (tail_overlap=late), CU-masked streams (cu_range, tail_cus) and kx panels (kx_panel).  None is faster than the serial order, all must
+    give its voxels: back-to-back views into distinct and shared outputs, a view that reads the previous view's output, a stage
+    operator and a download right behind a view, a view whose requested `att` is the pending tail's output."""
+    nx, ny, nz = 512, 512, 64                                           # 2^24 voxels, padded y length 560: the y passes can host guests
+    gt = np.ascontiguousarray(synth.sphere_phantom(512)[224:288])
+    psfs = [synth.gaussian_psf(15, sigma=(1.5, 1.7, 3.0 + 0.2 * v)) for v in range(4)]
+    dim = (nx, ny, nz)
+
+    def run(c):
+        d_gt = _dev_volume(c, gt)
+        acq = [c.dev_alloc(gt.nbytes) for _ in range(3)]
+        params = [c.view_params(degrees=15 + 45 * v, inc=1, snr=25.0, seed=SEED, stream=v, conv_method=1) for v in range(4)]
+        out = []
+        for v in range(3):
+            c.simulate_view_dev(d_gt, dim, psfs[v].copy(), params[v], acq[v])
+        out += [c.download(a, gt.shape) for a in acq]
+        for v in range(3):
+            c.simulate_view_dev(d_gt, dim, psfs[v].copy(), params[v], acq[0])
+        out.append(c.download(acq[0], gt.shape))
+        c.simulate_view_dev(d_gt, dim, psfs[0].copy(), params[0], acq[1])
+        c.simulate_view_dev(acq[1], dim, psfs[1].copy(), params[1], acq[2])        # reads what the previous tail has yet to write
+        c.rotate_around_axis_dev(acq[2], dim, 0, 30, acq[0])
+        out += [c.download(acq[2], gt.shape), c.download(acq[0], gt.shape)]
+        c.simulate_view_dev(d_gt, dim, psfs[3].copy(), params[3], acq[1], att_dptr=acq[2])
+        c.simulate_view_dev(d_gt, dim, psfs[2].copy(), params[2], acq[0], att_dptr=acq[1])  # `att` is the previous tail's output
+        c.simulate_view_dev(d_gt, dim, psfs[1].copy(), params[1], acq[2])
+        c.synchronize()
+        out += [c.download(a, gt.shape) for a in acq]
+        for d in [d_gt] + acq:
+            c.dev_free(d)
+        return out
+
+    with mvs.Context(0) as c:
+        c.set_option("tail_overlap", 0)
+        c.set_option("guest_tail", 0)
+        want = run(c)
+    assert want[0].mean() > 1.0
+    variants = [
+        {"guest_tail": 1, "tail_overlap": 1},                                        # separate rotate kernel: the deferred tail is flushed
+        {"guest_tail": 1, "tail_overlap": 1, "fused_fftx": 1},                       # fused kernel: it rides in passes B and D
+        {"guest_tail": 1, "tail_overlap": 1, "fused_fftx": 1, "guest_trips": "1,1"},
+        {"guest_tail": 1, "tail_overlap": 1, "fused_fftx": 1, "guest_trips": "8,0"},
+        {"guest_tail": 1, "tail_overlap": 1, "fused_fftx": 1, "guest_trips": "0,0"},
+        {"guest_tail": 0, "tail_overlap": "late", "fused_fftx": 1},
+        {"guest_tail": 0, "tail_overlap": "late", "fused_fftx": 1, "tail_prio": 1},
+        {"guest_tail": 0, "tail_overlap": 1, "cu_range": "32:256", "tail_cus": 32, "fused_fftx": 0},
+        {"guest_tail": 0, "tail_overlap": 0, "kx_panel": 64},
+    ]
+    for opts in variants:
+        with mvs.Context(0) as c:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            got = run(c)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a, b), (opts, i)
+
+
 def test_tail_overlap_keeps_stream_order_semantics(mvs, synth):
     """Option tail_overlap (the default from round 3 on; device views of >= 2^24 voxels on the context's own stream): the extract +
     Poisson tail of view v runs on a stream of its own beside the rotate+attenuate of view v+1.  Same voxels as the
