@@ -102,7 +102,10 @@ def parse_args():
     ap.add_argument("--collective", choices=("auto", "mvsim", "torch"), default="auto",
                     help="who broadcasts the ground truth: the C ABI's RCCL collective (default with the nccl backend) or "
                          "torch.distributed (gloo rehearsals: RCCL cannot place two ranks on one GPU)")
-    ap.add_argument("--broadcast", choices=("scatter_allgather", "ring"), default="scatter_allgather")
+    ap.add_argument("--broadcast", choices=("scatter_allgather", "ring", "peer_copy"), default="scatter_allgather",
+                    help="form of the ground-truth broadcast in the C ABI: RCCL scatter + all-gather over all links (default), one RCCL "
+                         "ring broadcast, or the same scatter + all-gather as copy-engine transfers between IPC-mapped buffers "
+                         "(peer_copy: no CUs taken from the views; two 16-byte all-reduces per broadcast remain as barriers)")
     ap.add_argument("--serial-broadcast", action="store_true",
                     help="N > 1: broadcast the ground truth at the start of each step instead of one step ahead")
     return ap.parse_args()
@@ -631,18 +634,27 @@ def main():
     bcast_done = [None, None]  # per ground-truth buffer: event after the broadcast that filled it
     step_no = [0]
 
+    bc_events = []             # (start, end) timing events around every broadcast of the timed region (on bc_stream)
+    view_events = []           # (start, end) around this rank's views of every timed step (on the first view stream)
+    record_diag = [False]
+
     def issue_broadcast(b):
         with torch.cuda.stream(bc_stream):
             for e in views_done[b]:
                 bc_stream.wait_event(e)             # readers of the previous contents have finished
+            if record_diag[0]:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(bc_stream)
             if bc_ctx is not None:
                 bc_ctx.comm_broadcast_volume(gt_bufs[b].data_ptr(), nvox, 0)      # enqueued on bc_stream
             else:
                 work = dist.broadcast(gt_bufs[b], src=0, async_op=True)
                 work.wait()                         # nccl: bc_stream waits for the collective; gloo: host waits
-            e = torch.cuda.Event()
+            e = torch.cuda.Event(enable_timing=record_diag[0])
             e.record(bc_stream)
             bcast_done[b] = e
+            if record_diag[0]:
+                bc_events.append((e0, e))
     params = [ctx.view_params(degrees=angles[v], inc=args.inc, snr=args.snr, seed=464232194, stream=v,
                               conv_method=args.conv_method) for v in my_views]
 
@@ -657,8 +669,16 @@ def main():
             if not args.serial_broadcast:
                 issue_broadcast(1 - cur)                # next dataset's ground truth, overlapped with these views
         gt_ptr = gt_bufs[cur].data_ptr()
+        if multi and record_diag[0] and my_views:
+            v0 = torch.cuda.Event(enable_timing=True)
+            v0.record(view_streams[0])
         for i in range(len(my_views)):
             ctxs[i % len(ctxs)].simulate_view_dev(gt_ptr, dims, psfs[i].copy(), params[i], acq[i].data_ptr())
+        if multi and record_diag[0] and my_views:
+            ctxs[0].join()                              # a pending tail belongs to this step's views
+            v1 = torch.cuda.Event(enable_timing=True)
+            v1.record(view_streams[0])
+            view_events.append((v0, v1))
         if multi:
             views_done[cur] = []
             for vs in view_streams:
@@ -693,11 +713,41 @@ def main():
     if timed_with_events:
         for c in ctxs:
             c.enable_timing(True)
+    record_diag[0] = multi
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    record_diag[0] = False
+    own_elapsed = elapsed
+    multi_diag = None
+    if multi:
+        # What a scaling run needs to be attributable: per step, the broadcast's own duration on its stream, this
+        # rank's views on theirs, how much of the broadcast the views hid, and every rank's own wall clock.  Events, read after the
+        # timed region; nothing here is inside it but the event records themselves.
+        bc_ms = [a.elapsed_time(b) for a, b in bc_events]
+        vw_ms = [a.elapsed_time(b) for a, b in view_events]
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, sum(bc_ms) / max(1, len(bc_ms)), sum(vw_ms) / max(1, len(vw_ms)),
+                             float(len(my_views))], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(every, mine)
+        else:
+            every = [mine]
+        rows = [[float(x) for x in t.tolist()] for t in every]
+        step_ms = [r[0] for r in rows]
+        b_ms = max(r[1] for r in rows)                 # the collective ends when its slowest rank does
+        v_ms = max(r[2] for r in rows)
+        exposed = min(max(max(step_ms) - v_ms, 0.0), b_ms) if b_ms > 0 else 0.0
+        multi_diag = {"broadcast_ms": round(b_ms, 4), "views_ms": round(v_ms, 4),
+                      "broadcast_hidden_frac": round(1.0 - exposed / b_ms, 4) if b_ms > 0 else None,
+                      "ms_per_step_min": round(min(step_ms), 4), "ms_per_step_max": round(max(step_ms), 4),
+                      "per_rank": [{"rank": i, "ms_per_step": round(r[0], 4), "broadcast_ms": round(r[1], 4), "views_ms": round(r[2], 4),
+                                    "views": int(r[3])} for i, r in enumerate(rows)],
+                      "note": "per step: broadcast_ms = scatter + all-gather of the next dataset's ground truth on its own stream (HIP events, "
+                              "slowest rank); views_ms = this dataset's views on the busiest rank; broadcast_hidden_frac = share of the broadcast "
+                              "that did not extend the step beyond the views (1 = fully hidden); expected from link rates: DESIGN.md section 6"}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -803,6 +853,8 @@ def main():
                                        else f"torch.distributed.broadcast ({args.backend})")
                                       + ", one per step, " + ("serial" if args.serial_broadcast else "issued one dataset ahead"))},
         }
+        if multi_diag:
+            out["multi_gpu"] = multi_diag
         if serial_leg:
             out["serial"] = serial_leg
         if no_empty:

@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstring>
 #include <new>
@@ -71,6 +72,160 @@ int mvsim_comm_init(mvsim_ctx* ctx, int nranks, int rank, const unsigned char id
     return MVSIM_OK;
 }
 
+// ---- broadcast=peer_copy: the same scatter + all-gather as copy-engine transfers ---------------------------------------
+// RCCL's collectives are kernels: they take CUs from the views that run beside the broadcast.  This form moves the
+// chunks with hipMemcpyAsync between the ranks' buffers -- mapped into each other's processes through IPC handles -- so that
+// the SDMA engines carry them; RCCL is left with two 16-byte all-reduces per broadcast that act as the barriers between the
+// phases (a rank's all-reduce is enqueued behind its copies, so its completion anywhere implies that every rank's copies of
+// the phase before have landed).
+struct PeerMap {
+    const void*        local = nullptr;      // the buffer of this rank the map belongs to
+    std::vector<char*> peer;                 // [rank] -> that rank's buffer in this process's address space (null for me)
+    std::vector<void*> opened;               // what hipIpcCloseMemHandle must be called on
+};
+struct PeerCopyState {
+    std::vector<PeerMap>     maps;
+    std::vector<hipStream_t> streams;        // one per peer: copies to different peers run on different engines / links
+    std::vector<hipEvent_t>  done;
+    hipEvent_t               fork = nullptr;
+    float*                   flag = nullptr; // 16 bytes for the barrier all-reduces
+    void*                    xch = nullptr;  // exchange buffer for the handles: nranks * 128 bytes
+};
+
+static void peer_copy_release(mvsim_ctx* ctx)
+{
+    PeerCopyState* st = reinterpret_cast<PeerCopyState*>(ctx->peer_copy);
+    if (!st) return;
+    for (auto& m : st->maps)
+        for (void* o : m.opened) (void)hipIpcCloseMemHandle(o);
+    for (hipStream_t s : st->streams) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : st->done) if (e) (void)hipEventDestroy(e);
+    if (st->fork) (void)hipEventDestroy(st->fork);
+    if (st->flag) (void)hipFree(st->flag);
+    if (st->xch) (void)hipFree(st->xch);
+    delete st;
+    ctx->peer_copy = nullptr;
+}
+
+static int peer_copy_state(mvsim_ctx* ctx, PeerCopyState** out)
+{
+    if (!ctx->peer_copy) {
+        PeerCopyState* st = new (std::nothrow) PeerCopyState();
+        if (!st) { mvsim::set_error("out of host memory"); return MVSIM_ENOMEM; }
+        ctx->peer_copy = st;
+        st->streams.assign((size_t)ctx->nranks, nullptr);
+        st->done.assign((size_t)ctx->nranks, nullptr);
+        for (int r = 0; r < ctx->nranks; ++r) {
+            if (r == ctx->rank) continue;
+            MVSIM_HIP(hipStreamCreateWithFlags(&st->streams[(size_t)r], hipStreamNonBlocking));
+            MVSIM_HIP(hipEventCreateWithFlags(&st->done[(size_t)r], hipEventDisableTiming));
+        }
+        MVSIM_HIP(hipEventCreateWithFlags(&st->fork, hipEventDisableTiming));
+        MVSIM_HIP(hipMalloc(reinterpret_cast<void**>(&st->flag), 16));
+        MVSIM_HIP(hipMemset(st->flag, 0, 16));
+        MVSIM_HIP(hipMalloc(&st->xch, (size_t)ctx->nranks * 128));
+    }
+    *out = reinterpret_cast<PeerCopyState*>(ctx->peer_copy);
+    return MVSIM_OK;
+}
+
+// every rank's view of `vol` (same call on every rank, collective): IPC handle of the allocation + offset into it, exchanged
+// through the communicator itself
+static int peer_copy_map(mvsim_ctx* ctx, PeerCopyState* st, float* vol, PeerMap** out)
+{
+    for (auto& m : st->maps) if (m.local == vol) { *out = &m; return MVSIM_OK; }
+    struct Record { hipIpcMemHandle_t h; unsigned long long offset; int pid; char pad[128 - sizeof(hipIpcMemHandle_t) - 12]; };
+    static_assert(sizeof(Record) == 128, "exchange record");
+    Record mine;
+    std::memset(&mine, 0, sizeof(mine));
+    void* base = nullptr;
+    size_t size = 0;
+    MVSIM_HIP(hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, vol));
+    mine.offset = (unsigned long long)(reinterpret_cast<char*>(vol) - reinterpret_cast<char*>(base));
+    mine.pid = (int)getpid();
+    if (ctx->nranks > 1) MVSIM_HIP(hipIpcGetMemHandle(&mine.h, base));
+    std::vector<Record> all((size_t)ctx->nranks);
+    char* slot = reinterpret_cast<char*>(st->xch) + (size_t)ctx->rank * sizeof(Record);
+    MVSIM_HIP(hipMemcpyAsync(slot, &mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    MVSIM_NCCL(ncclAllGather(slot, st->xch, sizeof(Record), ncclChar, (ncclComm_t)ctx->comm, ctx->stream));
+    MVSIM_HIP(hipMemcpyAsync(all.data(), st->xch, all.size() * sizeof(Record), hipMemcpyDeviceToHost, ctx->stream));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    PeerMap m;
+    m.local = vol;
+    m.peer.assign((size_t)ctx->nranks, nullptr);
+    for (int r = 0; r < ctx->nranks; ++r) {
+        if (r == ctx->rank) continue;
+        if (all[(size_t)r].pid == mine.pid) {
+            mvsim::set_error("broadcast=peer_copy needs one process per rank (ranks %d and %d share a process: use the RCCL forms)", ctx->rank, r);
+            return MVSIM_EINVAL;
+        }
+        void* p = nullptr;
+        MVSIM_HIP(hipIpcOpenMemHandle(&p, all[(size_t)r].h, hipIpcMemLazyEnablePeerAccess));
+        m.opened.push_back(p);
+        m.peer[(size_t)r] = reinterpret_cast<char*>(p) + all[(size_t)r].offset;
+    }
+    st->maps.push_back(std::move(m));
+    *out = &st->maps.back();
+    return MVSIM_OK;
+}
+
+static int peer_copy_barrier(mvsim_ctx* ctx, PeerCopyState* st)
+{
+    MVSIM_NCCL(ncclAllReduce(st->flag, st->flag, 4, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    return MVSIM_OK;
+}
+
+// phase: the copies this rank issues (from = first float, n floats, to every rank in `to`), forked from and joined to ctx->stream
+static int peer_copy_push(mvsim_ctx* ctx, PeerCopyState* st, const PeerMap& m, const float* vol, int64_t from, int64_t n, int skip_rank)
+{
+    if (n <= 0) return MVSIM_OK;
+    MVSIM_HIP(hipEventRecord(st->fork, ctx->stream));
+    for (int r = 0; r < ctx->nranks; ++r) {
+        if (r == ctx->rank || r == skip_rank) continue;
+        hipStream_t s = st->streams[(size_t)r];
+        MVSIM_HIP(hipStreamWaitEvent(s, st->fork, 0));
+        MVSIM_HIP(hipMemcpyAsync(m.peer[(size_t)r] + (size_t)from * sizeof(float), vol + from, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        MVSIM_HIP(hipEventRecord(st->done[(size_t)r], s));
+        MVSIM_HIP(hipStreamWaitEvent(ctx->stream, st->done[(size_t)r], 0));
+    }
+    return MVSIM_OK;
+}
+
+static int bcast_peer_copy(mvsim_ctx* ctx, float* vol, int64_t count, int root)
+{
+    PeerCopyState* st = nullptr;
+    MVSIM_TRY(peer_copy_state(ctx, &st));
+    PeerMap* m = nullptr;
+    MVSIM_TRY(peer_copy_map(ctx, st, vol, &m));
+    const int n = ctx->nranks, me = ctx->rank;
+    const int64_t chunk = (count / n) & ~(int64_t)15;
+    const int64_t tail = count - chunk * n;
+    // every rank's previous readers of `vol` are ordered on its own stream; nobody may be written into before all are there
+    MVSIM_TRY(peer_copy_barrier(ctx, st));
+    if (me == root) {
+        // scatter: chunk r to rank r (one copy per link); the unaligned tail to everybody
+        MVSIM_HIP(hipEventRecord(st->fork, ctx->stream));
+        for (int r = 0; r < n; ++r) {
+            if (r == me) continue;
+            hipStream_t s = st->streams[(size_t)r];
+            MVSIM_HIP(hipStreamWaitEvent(s, st->fork, 0));
+            if (chunk > 0)
+                MVSIM_HIP(hipMemcpyAsync(m->peer[(size_t)r] + (size_t)(r * chunk) * sizeof(float), vol + r * chunk, (size_t)chunk * sizeof(float),
+                                         hipMemcpyDeviceToDevice, s));
+            if (tail > 0)
+                MVSIM_HIP(hipMemcpyAsync(m->peer[(size_t)r] + (size_t)(chunk * n) * sizeof(float), vol + chunk * n, (size_t)tail * sizeof(float),
+                                         hipMemcpyDeviceToDevice, s));
+            MVSIM_HIP(hipEventRecord(st->done[(size_t)r], s));
+            MVSIM_HIP(hipStreamWaitEvent(ctx->stream, st->done[(size_t)r], 0));
+        }
+    }
+    MVSIM_TRY(peer_copy_barrier(ctx, st));                   // every rank holds its own chunk
+    // all-gather: my chunk to every rank but the root (which has it all); the root's own chunk goes out here as well
+    MVSIM_TRY(peer_copy_push(ctx, st, *m, vol, (int64_t)me * chunk, chunk, root));
+    MVSIM_TRY(peer_copy_barrier(ctx, st));                   // every chunk has landed everywhere
+    return MVSIM_OK;
+}
+
 // Broadcast of the ground truth.  xGMI is point-to-point (7 links per GPU): a ring/chain broadcast moves the whole
 // volume over ONE link of every GPU (0.54 GB at 512^3: ~3.5 ms, longer than a 2.4 ms view), so the default form is
 //   phase 0  scatter: root sends chunk r (count / nranks floats) to rank r -- nranks-1 concurrent sends, one per link
@@ -123,6 +278,7 @@ int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, i
     MVSIM_HIP(hipSetDevice(ctx->device));
     MVSIM_TRY(mvsim::settle_tail(ctx));
     if (count == 0) return MVSIM_OK;
+    if (ctx->opt.bcast_peer_copy) return bcast_peer_copy(ctx, vol_dev, count, root);
     for (int phase = 0; phase < 3; ++phase) MVSIM_TRY(bcast_phase(ctx, vol_dev, count, root, phase));
     return MVSIM_OK;
 }
@@ -156,6 +312,8 @@ int mvsim_comm_destroy(mvsim_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return MVSIM_OK;
     (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    peer_copy_release(ctx);
     ncclCommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
     ctx->nranks = 1;

@@ -128,6 +128,7 @@ struct Options {
                                        // at 512^3): measured neutral to slightly slower, so off by default
     int     graph = 0;                 // replay simulate_view_dev from a captured hipGraph (small, launch-bound volumes)
     bool    bcast_ring = false;        // ground-truth broadcast as one ncclBroadcast instead of scatter + all-gather
+    bool    bcast_peer_copy = false;   // ... or as copy-engine transfers between IPC-mapped buffers (comm.cpp: bcast_peer_copy)
     int64_t fft_pad[3] = {0, 0, 0};    // explicit padded sizes on the rocFFT path (0: choose)
     int     cu_lo = 0, cu_hi = 0;      // cu_range=a:b: the context's own stream may only use the CUs [a, b) of the mask order
                                        // (hipExtStreamCreateWithCUMask; 0:0 = all).  Experiments on how kernels share the chip.
@@ -260,6 +261,7 @@ struct mvsim_ctx {
 
     // RCCL
     void* comm = nullptr;
+    void* peer_copy = nullptr;             // broadcast=peer_copy: IPC maps, copy streams (comm.cpp)
     int   nranks = 1, rank = 0;
 };
 

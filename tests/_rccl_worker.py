@@ -32,7 +32,7 @@ def main():
         n = 1_000_003
         truth = np.random.default_rng(17).random(n, dtype=np.float32)
         d = c.dev_alloc(n * 4)
-        for form in ("scatter_allgather", "ring"):
+        for form in ("scatter_allgather", "ring", "peer_copy", "peer_copy"):
             c.set_option("broadcast", form)
             c.upload(d, truth if rank == 0 else np.full(n, -1.0, np.float32))
             c.comm_broadcast_volume(d, n, 0)

@@ -1060,6 +1060,11 @@ def test_rccl_entry_points_single_rank(mvs, synth):
             assert np.array_equal(c.download(d, vol.shape), vol)
             c.set_option("broadcast", "ring")
             c.comm_broadcast_volume(d, vol.size, 0)
+            c.set_option("broadcast", "peer_copy")                        # copy-engine form: with one rank its barriers and the map
+            c.comm_broadcast_volume(d, vol.size, 0)
+            c.comm_broadcast_volume(d, vol.size, 0)                       # (second call: the cached map)
+            c.synchronize()
+            assert np.array_equal(c.download(d, vol.shape), vol)
             c.set_option("broadcast", "scatter_allgather")
             c.comm_allreduce_sum(d, vol.size)
             c.synchronize()
@@ -1095,8 +1100,8 @@ def test_group_single_process_views(mvs, synth):
 
 
 def test_rccl_two_processes_two_gpus(mvs, tmp_path):
-    """Two ranks, one process per GPU, through the C ABI only (no torch): broadcast (both forms), all-reduce, f64
-    all-reduce.  Needs two GPUs: skipped on the one-GPU box, runs on the driver's multi-GPU node."""
+    """Two ranks, one process per GPU, through the C ABI only (no torch): broadcast (RCCL scatter + all-gather, RCCL ring, and the
+    copy-engine form over IPC-mapped buffers), all-reduce, f64 all-reduce.  Needs two GPUs: skipped on the one-GPU box, runs on the driver's multi-GPU node."""
     import ctypes
     import subprocess
     import sys
@@ -1479,7 +1484,7 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
     import subprocess
     import sys
     bench = os.path.join(ROOT, "bench.py")
-    for extra in (["--broadcast", "scatter_allgather"], ["--broadcast", "ring", "--serial"]):
+    for extra in (["--broadcast", "scatter_allgather"], ["--broadcast", "ring", "--serial"], ["--broadcast", "peer_copy"]):
         r = subprocess.run([sys.executable, bench, "--rehearse-multi", "--size", "256", "--psf", "15", "--steps", "2", "--warmup", "1",
                             "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -1489,6 +1494,9 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
         assert extra[1] in d["config"]["collective"]
         assert d["config"]["rccl"]["libmvsim"]["version_code"] > 0 and d["config"]["rccl"]["libmvsim"]["path"]
         assert ("off" in d["config"]["overlap"]) == ("--serial" in extra)
+        # what makes a scaling run attributable: per-step broadcast / view times and every rank's own clock
+        mg = d["multi_gpu"]
+        assert mg["broadcast_ms"] >= 0 and mg["views_ms"] > 0 and len(mg["per_rank"]) == 1 and mg["ms_per_step_max"] >= mg["ms_per_step_min"] > 0
 
 
 @pytest.mark.parametrize("shape,kshape,degrees,inc", [((40, 64, 64), (9, 5, 7), 33, 1),       # one wave per row batch
