@@ -407,14 +407,15 @@ class Context:
         _lib.check(self._L.mvsim_wait(self._h, ticket, C.byref(corr)))
         return corr.value
 
-    def simulate_view_zslabs(self, gt_slabs: list, psf: np.ndarray, params: ViewParams, acq_slab_nz: list) -> tuple:
+    def simulate_view_zslabs(self, gt_slabs: list, psf: np.ndarray, params: ViewParams, acq_slab_nz: list, pinned: bool = False) -> tuple:
         """Host buffers as z slabs (volumes beyond 2^31-1 voxels do not fit one Java array): ``gt_slabs`` is a list of
-        contiguous float32 (nz_i, Ny, Nx) arrays, ``acq_slab_nz`` the plane counts of the acquisition slabs to return."""
+        contiguous float32 (nz_i, Ny, Nx) arrays, ``acq_slab_nz`` the plane counts of the acquisition slabs to return
+        (``pinned``: in page-locked blocks of mvsim_host_alloc, as the Java facade hands them over)."""
         _check_inplace(psf, "psf")
         gs = [np.ascontiguousarray(g, dtype=np.float32) for g in gt_slabs]
         ny, nx = gs[0].shape[1:]
         nz = sum(g.shape[0] for g in gs)
-        acq = [np.empty((int(k), ny, nx), dtype=np.float32) for k in acq_slab_nz]
+        acq = [(self.pinned_empty((int(k), ny, nx)) if pinned else np.empty((int(k), ny, nx), dtype=np.float32)) for k in acq_slab_nz]
         ga = (C.c_void_p * len(gs))(*[g.ctypes.data for g in gs])
         gn = (C.c_int64 * len(gs))(*[g.shape[0] for g in gs])
         aa = (C.c_void_p * len(acq))(*[a.ctypes.data for a in acq])

@@ -363,8 +363,9 @@ int  settle_tail(mvsim_ctx* ctx);
 size_t poisson_queue_bytes_blocks(int64_t n_out, long long blocks);
 // bytes of queue workspace the fused tail needs for this geometry (0: the geometry has no fused tail)
 size_t fused_tail_queue_bytes(const int64_t dim[3], const int64_t kdim[3], int inc, bool con_wanted, const Options& opt);
+// plane / idx_inc / index_offset: how the RNG counter of an output element follows from its position (ResolveJob)
 int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
-                           double mul, uint64_t seed, uint32_t stream);
+                           double mul, uint64_t seed, uint32_t stream, long long plane, int idx_inc, uint64_t index_offset);
 int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, float* att_or_null, const int64_t dim[3],
                           const int64_t kdim[3], const Affine& inv, double delta, bool* done);
 int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,

@@ -50,7 +50,7 @@ struct LinesArgs {
     struct Guest {
         int        kind;            // 0: none, 1: phase 1 of the sampler, 2: the resolver, 3: experiment (chain of `nseg` Philox blocks per wave)
         long long  nseg;            // resolver: queue segments (dealt over the blocks of this launch)
-        long long  it0, it1;        // phase 1: the trips [it0, it1) of every block's walk (p1_block_body)
+        int        it0, it1;        // phase 1: the trips [it0, it1) of every block's walk (p1_block_body)
         P1Job      p1;
         ResolveJob rs;
     } guest;
@@ -1112,6 +1112,7 @@ static bool fused_tail_geometry(const int64_t dim[3], const int64_t kdim[3], int
     if (nr <= 0) return false;
     const long long nk = con_wanted ? dim[2] : (dim[2] - 1) / inc + 1;
     const long long rows = dim[1] * nk;
+    if (rows * dim[0] >= (1ll << 32)) return false;               // work items carry the output position in 32 bits
     *blocks = (rows + nr - 1) / nr;
     *segcap = (unsigned int)(nr * dim[0]);
     return true;
@@ -1443,7 +1444,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
                 guest_split = std::min<long long>(ctx->opt.guest_trips[0], guest_trips);
                 guest_end = (nzo == nzs && zstride == 1) ? std::min<long long>(guest_split + std::max(ctx->opt.guest_trips[1], 0), guest_trips) : guest_split;
             }
-            b.guest.it0 = 0; b.guest.it1 = guest_split;
+            b.guest.it0 = 0; b.guest.it1 = (int)guest_split;
             if (guest_split == 0) b.guest.kind = 0;
         } else if (ctx->opt.exp_guest >= 0 && zdirect && !is_slab && lines_can_host(py)) {
             b.guest.kind = 3; b.guest.nseg = ctx->opt.exp_guest;
@@ -1452,7 +1453,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
         ev_end(ctx, ST_PASS_B);
         b.lmap = ident_none; b.src_mirror = 0;
-        if (guest) { guest_p1 = b.guest.p1; b.guest.kind = guest_split < guest_end ? 1 : 0; b.guest.it0 = guest_split; b.guest.it1 = guest_end; }
+        if (guest) { guest_p1 = b.guest.p1; b.guest.kind = guest_split < guest_end ? 1 : 0; b.guest.it0 = (int)guest_split; b.guest.it1 = (int)guest_end; }
         if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));    // the z pass reads the PSF spectrum
         ev_begin(ctx, ST_PASS_C);
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
@@ -1501,10 +1502,10 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, nk));
         ev_end(ctx, ST_PASS_D);
         if (guest) {
-            if (guest_end < guest_trips) MVSIM_TRY(launch_poisson_phase1(s, guest_p1, gblocks, guest_end, guest_trips, guest_end > 0));
+            if (guest_end < guest_trips) MVSIM_TRY(launch_poisson_phase1(s, guest_p1, gblocks, (int)guest_end, (int)guest_trips, guest_end > 0));
             // the resolver as a kernel of its own: its work items are dependent 32-byte reads, nothing a guest wave can wait for
             MVSIM_TRY(launch_poisson_resolve(s, guest_rs.out, const_cast<PItem*>(guest_rs.queue), guest_rs.qcount, (int)gblocks, guest_rs.segcap,
-                                             guest_rs.mul, guest->seed, guest_rs.stream));
+                                             guest_rs.mul, guest->seed, guest_rs.stream, guest_rs.plane, (int)guest_rs.idx_inc, 0));
             guest->valid = false;                                     // all of it is enqueued
         }
         b.guest.kind = 0;
@@ -1546,7 +1547,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         if (fuse && tail->noise) {
             ev_end(ctx, ST_CONVOLVE);
             ev_begin(ctx, ST_EXTRACT);
-            MVSIM_TRY(launch_poisson_resolve(s, tail->acq, fz.queue, fz.qcount, (int)fblocks, fsegcap, tail->mul, tail->seed, tail->stream));
+            MVSIM_TRY(launch_poisson_resolve(s, tail->acq, fz.queue, fz.qcount, (int)fblocks, fsegcap, tail->mul, tail->seed, tail->stream,
+                                             (long long)dim[0] * dim[1], fz.acq_every * fz.idx_zstride, 0));
             ev_end(ctx, ST_EXTRACT);
             return MVSIM_OK;
         }

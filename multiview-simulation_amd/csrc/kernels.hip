@@ -778,18 +778,74 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
 //                      runs once per voxel slot with 1-in-7 lanes active.
 // Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.
 template <bool ADJUST>
-__global__ __launch_bounds__(256) void k_extract4_noise2(P1Job job, long long it0, long long it1, int resume)
+__global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict__ in, float* __restrict__ out,
+                                                         long long plane4, long long nzo, int inc, int idx_inc,
+                                                         const double* __restrict__ scal, float min_value, double mul,
+                                                         uint32_t k0, uint32_t k1, uint32_t stream,
+                                                         unsigned long long index_offset, PItem* __restrict__ queue,
+                                                         unsigned int* __restrict__ qcount, unsigned int segcap)
+{
+    __shared__ unsigned int nq, nqs;
+    __shared__ P1Scratch scratch[4];
+    if (threadIdx.x == 0) { nq = 0u; nqs = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    P1Args pa;
+    pa.mul = mul; pa.mulf = (float)mul; pa.k0 = k0; pa.k1 = k1; pa.stream = stream;
+    pa.seg = queue + (unsigned long long)blockIdx.x * segcap; pa.segcap = segcap; pa.nq = &nq; pa.nqs = &nqs;
+    double corr = 1.0;
+    if (ADJUST) corr = scal[1];
+    const long long total4 = plane4 * nzo;
+    const long long nthreads = (long long)gridDim.x * 256;
+    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+    const bool small32 = total4 < (1ll << 32);
+    // the trip count is uniform per wave (lanes past the end carry invalid voxels): ballots need every lane
+    const long long wave_first = (long long)blockIdx.x * 256 + wave * 64;
+    for (long long o0 = wave_first; o0 < total4; o0 += nthreads) {
+        const long long o = o0 + lane;
+        const bool valid = o < total4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        long long src4 = o, idx4 = o;                 // where the voxels are read / what the RNG counter says they are
+        if (valid) {
+            if (inc != 1 || idx_inc != 1) {
+                const long long k = small32 ? (long long)((unsigned)o / (unsigned)plane4) : o / plane4;
+                src4 = k * inc * plane4 + (o - k * plane4);
+                idx4 = k * idx_inc * plane4 + (o - k * plane4);
+            }
+            v = in4[src4];
+            if (ADJUST) {
+                v.x = adjust_one(v.x, corr, min_value);
+                v.y = adjust_one(v.y, corr, min_value);
+                v.z = adjust_one(v.z, corr, min_value);
+                v.w = adjust_one(v.w, corr, min_value);
+            }
+        }
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float ov[4];
+        poisson_phase1(vv, valid, index_offset + 4ull * (unsigned long long)idx4, 4ull * (unsigned long long)o, pa, &scratch[wave], lane, ov);
+        if (valid) out4[o] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        qcount[2 * blockIdx.x] = nq;
+        qcount[2 * blockIdx.x + 1] = nqs;
+    }
+}
+
+// the same phase 1 restricted to the trips [it0, it1) of every block's walk, continuing a segment (what guest waves left over)
+__global__ __launch_bounds__(256) void k_extract4_noise2_part(P1Job job, int it0, int it1, int resume)
 {
     __shared__ unsigned int ctr[2];
     __shared__ P1Scratch scratch[4];
     BlockBarrier bar;
-    p1_block_body<ADJUST, false>(job, (long long)blockIdx.x, (long long)gridDim.x, (int)threadIdx.x, scratch, ctr, bar, it0, it1, resume != 0);
+    p1_block_body<true, false>(job, (long long)blockIdx.x, (long long)gridDim.x, (int)threadIdx.x, scratch, ctr, bar, it0, it1, resume != 0);
 }
 
 // the trips [it0, it1) of phase 1 as a kernel of its own over `blocks` blocks (what guest waves left over: resume = 1)
-int launch_poisson_phase1(hipStream_t s, const P1Job& job, long long blocks, long long it0, long long it1, bool resume)
+int launch_poisson_phase1(hipStream_t s, const P1Job& job, long long blocks, int it0, int it1, bool resume)
 {
-    hipLaunchKernelGGL((k_extract4_noise2<true>), dim3((unsigned)blocks), dim3(256), 0, s, job, it0, it1, resume ? 1 : 0);
+    hipLaunchKernelGGL(k_extract4_noise2_part, dim3((unsigned)blocks), dim3(256), 0, s, job, it0, it1, resume ? 1 : 0);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
@@ -804,16 +860,17 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job)
 }
 
 int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
-                           double mul, uint64_t seed, uint32_t stream)
+                           double mul, uint64_t seed, uint32_t stream, long long plane, int idx_inc, uint64_t index_offset)
 {
-    const ResolveJob job{out, reinterpret_cast<const PItem*>(queue_items), qcount, segcap, mul, (uint32_t)seed, (uint32_t)(seed >> 32), stream};
+    const ResolveJob job{out, reinterpret_cast<const PItem*>(queue_items), qcount, segcap, mul, (uint32_t)seed, (uint32_t)(seed >> 32), stream,
+                         (unsigned int)plane, (unsigned int)idx_inc, (unsigned long long)index_offset};
     hipLaunchKernelGGL(k_poisson_resolve, dim3(segments), dim3(256), 0, s, job);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
 
 // Work-queue geometry for n_out output voxels: `blocks` blocks of 256 lanes x 4 voxels walk the volume with a
-// grid stride; each owns a segment that can hold all of its voxels (32 B per output voxel of HBM workspace).
+// grid stride; each owns a segment that can hold all of its voxels (16 B per output voxel of HBM workspace).
 constexpr int POISSON_MAX_BLOCKS = 256 * 64;
 static void poisson_geometry(int64_t n_out, int* blocks, unsigned int* segcap)
 {
@@ -856,14 +913,14 @@ bool poisson_make_jobs(const DeferredTail& t, long long blocks, void* queue_ws, 
     const long long plane = (long long)t.dim[0] * t.dim[1];
     const long long nzo = (t.dim[2] - 1) / t.inc + 1;
     if (!extract_vec_ok(t.in, t.out, plane, 0) || blocks < 1 || blocks > POISSON_MAX_BLOCKS || !queue_ws ||
-        (long long)(index_inc - 1) * plane >= (1ll << 31))
+        (long long)(index_inc - 1) * plane >= (1ll << 31) || plane * nzo >= (1ll << 32))
         return false;
     const unsigned int segcap = segcap_for_blocks(plane * nzo, blocks);
     unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
     PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int));
     const uint32_t k0 = (uint32_t)t.seed, k1 = (uint32_t)(t.seed >> 32);
     *p1 = P1Job{t.in, t.out, plane / 4, nzo, t.inc, index_inc, t.scal, t.min_value, t.mul, k0, k1, t.stream, 0ull, queue, qcount, segcap};
-    *rs = ResolveJob{t.out, queue, qcount, segcap, t.mul, k0, k1, t.stream};
+    *rs = ResolveJob{t.out, queue, qcount, segcap, t.mul, k0, k1, t.stream, (unsigned int)plane, (unsigned int)index_inc, 0ull};
     return true;
 }
 
@@ -877,7 +934,9 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
     const long long plane = (long long)dim[0] * dim[1];
     // phase 1 hands a slot's RNG counters across lanes as 32-bit offsets from lane 0's (poisson_phase1): a slot that straddles
     // two acquired planes must not see them 2^32 voxels apart
-    const bool use_queue = queue_mode != 0 && (long long)(index_inc - 1) * plane < (1ll << 31);
+    // ... and a work item carries its output position in 32 bits
+    const bool use_queue = queue_mode != 0 && (long long)(index_inc - 1) * plane < (1ll << 31) && plane * ((dim[2] - 1) / inc + 1) < (1ll << 32) &&
+                           plane < (1ll << 32);
     const long long nzo = (dim[2] - 1) / inc + 1;
     const long long total = plane * nzo;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -895,11 +954,15 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
             poisson_geometry(total, &qblocks, &segcap);
             unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
             PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int));
-            const P1Job job{in, out, plane / 4, nzo, inc, index_inc, scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset,
-                            queue, qcount, segcap};
-            if (adjust) hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks), dim3(256), 0, s, job, 0ll, 1ll << 40, 0);
-            else hipLaunchKernelGGL((k_extract4_noise2<false>), dim3(qblocks), dim3(256), 0, s, job, 0ll, 1ll << 40, 0);
-            const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream};
+            if (adjust) {
+                hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
+                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
+            } else {
+                hipLaunchKernelGGL((k_extract4_noise2<false>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
+                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
+            }
+            const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream, (unsigned int)plane, (unsigned int)index_inc,
+                                  (unsigned long long)index_offset};
             hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks), dim3(256), 0, s, rjob);
         }
         else if (adjust && noise) MVSIM_LAUNCH_EX4(true, true);

@@ -416,14 +416,13 @@ __device__ __forceinline__ float4 poisson_counter4(double l0, double l1, double 
 //   - the squeeze of PTRS attempt 0 is evaluated in fp32 (ptrs_squeeze_f32) and only trusted with guard bands; whatever
 //     it cannot certify goes to the resolver as "attempt 0 not evaluated", where the fp64 recipe runs.
 // ------------------------------------------------------------------------------------------------------------
+// 16 bytes per work item (round 3: 32): the RNG counter of the voxel follows from its output position (plane arithmetic, needed
+// for retries only), the first attempt to evaluate is 0 for every bright item and implied by the segment end for inversion items.
 struct __attribute__((aligned(16))) PItem {
-    unsigned long long index;     // source voxel index (RNG counter)
-    unsigned long long out;       // element index in the output
+    unsigned int out;             // element index in the output (< 2^32: larger outputs take the queue-less kernel)
     float v;                      // adjusted voxel value (lambda = v * mul)
-    unsigned int attempt;         // first attempt still to evaluate (kSmallLambdaItem: inversion item)
     unsigned int w0, w1;          // random words of attempt 0 (inversion item: w0 = the voxel's word of its group block)
 };
-constexpr unsigned int kSmallLambdaItem = 0xFFFFFFFFu;   // PItem::attempt of an inversion (lambda < 10) work item
 
 // wave-private LDS scratch of phase 1 (1.1 KB: a block of four waves fits beside the two resident 75 KB blocks of the
 // convolution's y passes, which is what lets the hardware run the sampler on a second stream beside them -- DESIGN 4.5)
@@ -487,13 +486,9 @@ __device__ __forceinline__ bool ptrs_squeeze_f32(double lambda, uint32_t w0, uin
            lambda < 1.0e9;
 }
 
-__device__ __forceinline__ void p1_push(PItem* slot, unsigned long long index, unsigned long long out, float v, unsigned int attempt,
-                                        unsigned int w0, unsigned int w1)
+__device__ __forceinline__ void p1_push(PItem* slot, unsigned long long out, float v, unsigned int w0, unsigned int w1)
 {
-    // two 16-byte stores
-    uint4* q = reinterpret_cast<uint4*>(slot);
-    q[0] = make_uint4((unsigned int)index, (unsigned int)(index >> 32), (unsigned int)out, (unsigned int)(out >> 32));
-    q[1] = make_uint4(__float_as_uint(v), attempt, w0, w1);
+    *reinterpret_cast<uint4*>(slot) = make_uint4((unsigned int)out, __float_as_uint(v), w0, w1);     // one 16-byte store
 }
 
 // (MVSIM_EXP_NOPHILOX / _NOSMALLPUSH / _NOBRIGHT: instruction-attribution builds of tools/attribute_valu.sh -- each removes one
@@ -528,8 +523,7 @@ __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, un
 #ifndef MVSIM_EXP_NOSMALLPUSH
                 if (!(w[c] < thr)) {
                     const unsigned int pos = atomicAdd(a.nqs, 1u);
-                    p1_push(a.seg + (a.segcap - 1u - pos), index4 + (unsigned long long)c, out4 + (unsigned long long)c, vv[c],
-                            kSmallLambdaItem, w[c], 0u);
+                    p1_push(a.seg + (a.segcap - 1u - pos), out4 + (unsigned long long)c, vv[c], w[c], 0u);
                 }
 #else
                 if (!(w[c] < thr)) ov[c] = 1.f;
@@ -593,7 +587,7 @@ __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, un
                     // the segment holds every voxel of the block (worst case: all pending), so this cannot overflow.
                     // (Measured: one LDS atomic per lane is cheaper here than a ballot-aggregated append.)
                     const unsigned int pos = atomicAdd(a.nq, 1u);
-                    p1_push(a.seg + pos, idx + (unsigned long long)e, out_base + 4u * owner + first + (unsigned long long)e, v, 0u, w0, w1);
+                    p1_push(a.seg + pos, out_base + 4u * owner + first + (unsigned long long)e, v, w0, w1);
                 }
             }
         }
@@ -661,7 +655,7 @@ struct P1Job {
 // before this trip's are worked on -- for guest waves, which have no other wave to hide the load behind.
 template <bool ADJUST, bool PREFETCH, class BAR>
 __device__ __forceinline__ void p1_block_body(const P1Job& j, long long block, long long nblocks, int t, P1Scratch* scratch4,
-                                              unsigned int* ctr, BAR& bar, long long it0 = 0, long long it1 = 1ll << 40, bool resume = false)
+                                              unsigned int* ctr, BAR& bar, int it0, int it1, bool resume)
 {
     if (t == 0) { ctr[0] = resume ? j.qcount[2 * block] : 0u; ctr[1] = resume ? j.qcount[2 * block + 1] : 0u; }
     bar();
@@ -678,8 +672,9 @@ __device__ __forceinline__ void p1_block_body(const P1Job& j, long long block, l
     const bool small32 = total4 < (1ll << 32);
     const bool strided = j.inc != 1 || j.idx_inc != 1;
     // the trip count is uniform per wave (lanes past the end carry invalid voxels): ballots need every lane
-    const long long wave_first = block * 256 + wave * 64 + it0 * nthreads;
-    const long long wave_end = (it1 >= (1ll << 40) / nthreads) ? total4 : (total4 < it1 * nthreads ? total4 : it1 * nthreads);
+    // (it1 never exceeds the block's trip count segcap / 1024, so it1 * nthreads stays within a trip of total4: no overflow, no division)
+    const long long wave_first = block * 256 + wave * 64 + (long long)it0 * nthreads;
+    const long long wave_end = total4 < (long long)it1 * nthreads ? total4 : (long long)it1 * nthreads;
     auto source = [&](long long o, long long& idx4) {
         long long src4 = o; idx4 = o;                 // where the voxels are read / what the RNG counter says they are
         if (strided) {
@@ -729,6 +724,10 @@ struct ResolveJob {
     unsigned int        segcap;
     double              mul;
     uint32_t            k0, k1, stream;
+    // RNG counter of output element o (retries only): k = o / plane; index = index_offset + k * idx_inc * plane + (o - k * plane)
+    unsigned int        plane;
+    unsigned int        idx_inc;
+    unsigned long long  index_offset;
 };
 
 // One queue segment resolved by 256 lanes.
@@ -750,10 +749,10 @@ __device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long l
     bar();
     unsigned int i = (unsigned int)t;
     PItem it;
-    it.index = 0ull; it.out = 0ull; it.v = 0.f; it.attempt = 0u; it.w0 = 0u; it.w1 = 0u;
+    it.out = 0u; it.v = 0.f; it.w0 = 0u; it.w1 = 0u;
     bool have = i < n;
     if (have) it = seg[i];
-    uint32_t a = it.attempt;
+    uint32_t a = 0u;
     while (have) {
         const double lam = (double)it.v * j.mul;
         float val = 0.f;
@@ -767,7 +766,9 @@ __device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long l
                 w0 = it.w0;                                          // the words phase 1 drew for attempt 0
                 w1 = it.w1;
             } else {
-                ptrs_retry_words(it.index, a, j.k0, j.k1, j.stream, w0, w1);
+                const unsigned int kpl = j.idx_inc == 1u ? 0u : it.out / j.plane;
+                const unsigned long long index = j.index_offset + (unsigned long long)it.out + (unsigned long long)kpl * (j.idx_inc - 1u) * j.plane;
+                ptrs_retry_words(index, a, j.k0, j.k1, j.stream, w0, w1);
             }
             done = ptrs_step_words(lam, w0, w1, val);
         }
@@ -775,7 +776,7 @@ __device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long l
             j.out[it.out] = val;
             i = atomicAdd(ticket, 1u);
             have = i < n;
-            if (have) { it = seg[i]; a = it.attempt; }
+            if (have) { it = seg[i]; a = 0u; }
         } else {
             a += 1u;
         }
@@ -786,6 +787,6 @@ __device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long l
 // poisson_queue_bytes_blocks(n_out, blocks) bytes.  False when the tail cannot take the vector path (unaligned, odd plane).
 struct DeferredTail;
 bool poisson_make_jobs(const DeferredTail& t, long long blocks, void* queue_ws, P1Job* p1, ResolveJob* rs);
-int  launch_poisson_phase1(hipStream_t s, const P1Job& job, long long blocks, long long it0, long long it1, bool resume);
+int  launch_poisson_phase1(hipStream_t s, const P1Job& job, long long blocks, int it0, int it1, bool resume);
 
 }  // namespace mvsim

@@ -1038,6 +1038,72 @@ def test_host_streaming_entry_points_at_512_cubed(ctx, synth):
         assert np.array_equal(outs[v]["acq"], ctx.simulate_view(gt, psf.copy(), params[v])["acq"]), v
 
 
+def test_config4_as_stated_stencil_through_pinned_zslabs(mvs, orc):
+    """BASELINE configs[4] as it is worded: a 2048 x 2048 x 512 volume -- 2^31 voxels, one more than a Java array (and the reference's
+    ArrayImgFactory, SimulateMultiViewDataset.java:109) can hold --, the measured-like non-separable 63^3 PSF, the LDS-tiled DIRECT
+    STENCIL (conv_method 2: 1.07 Pflop, ~14 s), ground truth in and acquisition out as lists of PAGE-LOCKED z slabs through
+    mvsim_simulate_view_zslabs.  Checked against the FFT passes through the same entry point on every acquired voxel, and against the
+    oracle's exact fp64 direct sum (orc_convolve_direct_at) at sampled voxels in two z windows: the z = 0 face, where the mirror
+    boundary acts in all three axes, and the middle of the volume."""
+    synth = importlib.import_module("multiview-simulation_amd.synthetic")
+    nx, ny, nz, inc, slab = 2048, 2048, 512, 3, 64
+    nzo = (nz - 1) // inc + 1
+    psf = synth.hourglass_psf(63)
+    # the window volume of _window_volume, built slab by slab straight into page-locked memory
+    def w(n, frac):
+        t = (np.arange(n, dtype=np.float32) - (n - 1) / 2) / (frac * n / 2)
+        return np.clip(1 - t * t, 0, None) ** 2
+    wz, plane = w(nz, 0.55), (w(ny, 0.6)[:, None] * w(nx, 0.5)[None, :]).astype(np.float32)
+    with mvs.Context(0) as c:
+        slabs = []
+        for z0 in range(0, nz, slab):
+            h = c.pinned_empty((slab, ny, nx))
+            np.multiply(wz[z0:z0 + slab, None, None], plane[None], out=h)
+            slabs.append(h)
+        slabs[4][10, 1000, 1100] += np.float32(3.0)                      # an isolated bright voxel in the middle window
+        out_nz = [64, 64, nzo - 128]
+        ps = c.view_params(degrees=60, delta=REF_DELTA, inc=inc, snr=-1.0, seed=SEED, stream=0, conv_method=2)
+        pf = c.view_params(degrees=60, delta=REF_DELTA, inc=inc, snr=-1.0, seed=SEED, stream=0, conv_method=1)
+        import time
+        t0 = time.perf_counter()
+        acq_s, corr_s = c.simulate_view_zslabs(slabs, psf.copy(), ps, out_nz, pinned=True)
+        t_stencil = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        acq_f, corr_f = c.simulate_view_zslabs(slabs, psf.copy(), pf, out_nz, pinned=True)
+        t_fft = time.perf_counter() - t0
+        print(f"configs[4] through page-locked z slabs: direct stencil {t_stencil:.2f} s, FFT passes {t_fft:.3f} s (host to host)")
+        assert abs(corr_s / corr_f - 1) <= 1e-6
+        scale = max(float(a.max()) for a in acq_f)
+        assert scale > 0
+        for a, b in zip(acq_s, acq_f):                                    # every acquired voxel
+            for k0 in range(0, a.shape[0], 16):
+                assert float(np.abs(a[k0:k0 + 16] - b[k0:k0 + 16]).max()) <= CONV_TOL * scale
+        # the attenuated volume of the same view, device-resident, for the oracle: only the planes the sampled voxels' taps reach
+        d_gt, d_att, d_acq = c.dev_alloc(nx * ny * nz * 4), c.dev_alloc(nx * ny * nz * 4), c.dev_alloc(nx * ny * nzo * 4)
+        try:
+            for i, h in enumerate(slabs):
+                c.upload(d_gt + i * slab * ny * nx * 4, h)
+            corr = c.simulate_view_dev(d_gt, (nx, ny, nz), psf.copy(), pf, d_acq, att_dptr=d_att, want_corr=True)
+            assert abs(corr / corr_f - 1) <= 1e-6
+            pn = psf.copy()
+            orc.norm_image(pn)
+            acq_all = np.concatenate([a.reshape(-1, ny, nx) for a in acq_s], axis=0)
+            rng = np.random.default_rng(4)
+            for zlo, zhi, zs in ((0, 35, (0, 3)), (219, 285, (249, 252))):
+                win = c.download(d_att + zlo * ny * nx * 4, (zhi - zlo, ny, nx))
+                ys = np.concatenate([np.arange(3), rng.integers(0, ny, 60), [1000]])
+                xs = np.concatenate([np.arange(3), rng.integers(0, nx, 60), [1100]])
+                for z in zs:
+                    idx = np.unique(xs + nx * (ys + ny * (z - zlo)))
+                    want = orc.convolve_direct_at(win, pn, idx)
+                    want = (want.astype(np.float64) * corr).astype(np.float32) + np.float32(1e-4)      # Tools.adjustImage, two roundings
+                    got = acq_all[z // inc].ravel()[idx - nx * ny * (z - zlo)]
+                    assert float(np.abs(got - want).max()) <= CONV_TOL * scale, (z, float(np.abs(got - want).max()), scale)
+        finally:
+            for d in (d_gt, d_att, d_acq):
+                c.dev_free(d)
+
+
 def test_config4_2048x2048x512_psf63(mvs):
     """BASELINE configs[4]: 2048 x 2048 x 512 volume, non-separable 63^3 PSF (the tilted hour-glass of SURVEY 8d; padded
     2240 x 2160 on the hand-written FFT path), resident in HBM."""
