@@ -90,6 +90,8 @@ def parse_args():
                          "{n_gpus, ranks_seen}; no GPU, no libmvsim (what the CPU test of the self-launcher runs with --backend gloo)")
     ap.add_argument("--no-size-1024", action="store_true", help="skip the 1024^3 sub-record")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the `no_empty_space` sub-record (N = 1 only)")
+    ap.add_argument("--no-main-iteration", action="store_true",
+                    help="skip the `main_iteration` sub-record (N = 1 only): whole iterations of the reference's view loop, device-resident")
     ap.add_argument("--cpu-slab", type=int, default=64, help="z extent of the CPU-baseline sample slab")
     ap.add_argument("--cpu-poisson-planes", type=int, default=64,
                     help="planes of the slab the reference-exact (inter-arrival) Poisson sampler is timed on; the rest is scaled")
@@ -867,6 +869,33 @@ def main():
             out["roofline"] = roofline_record(mvs, stage, nvox, n * n * nzo, n, args.psf, args.conv_method, traffic, note,
                                               view_wall_ms=wall_view, overlapped=stage_overlapped)
             out["kernel_sha"] = kernel_sha
+    if rank == 0 and not multi and len(ctxs) == 1 and not args.no_main_iteration and args.conv_method == 1 and my_views:
+        # The whole body of `main`'s view loop (SimulateMultiViewDataset.java:567-613): the view, then makeIsotropic and the
+        # rotate-backs of the isotropic view, the weight image and the PSF (mvsim_simulate_iteration_dev), all outputs in HBM.
+        try:
+            niso = (nzo - 1) * args.inc + 1
+            extra = {"iso": torch.empty(n * n * niso, dtype=torch.float32, device=dev), "view": torch.empty(n * n * niso, dtype=torch.float32, device=dev),
+                     "w": torch.empty(nvox, dtype=torch.float32, device=dev), "psf": torch.empty(args.psf ** 3, dtype=torch.float32, device=dev)}
+
+            def iterations():
+                for i in range(len(my_views)):
+                    ctx.simulate_iteration_dev(gt_bufs[0].data_ptr(), dims, psfs[i].copy(), params[i], -angles[my_views[i]], acq[i].data_ptr(),
+                                               iso_dptr=extra["iso"].data_ptr(), view_dptr=extra["view"].data_ptr(),
+                                               view_weights_dptr=extra["w"].data_ptr(), view_psf_dptr=extra["psf"].data_ptr())
+            iterations(); sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                iterations()
+            sync()
+            dt = time.perf_counter() - t1
+            out["main_iteration"] = {"ms_per_iteration": dt / (args.steps * len(my_views)) * 1e3,
+                                     "value": total_views * args.steps / dt * nvox / 1e6, "unit": "Mvoxel/s",
+                                     "note": "one iteration = the view (rotate .. Poisson) + makeIsotropic + rotateAroundAxis(iso, -angle) + "
+                                             "rotateAroundAxis(computeWeightImage, -angle) + rotateAroundAxis(psf, -angle), device-resident "
+                                             "(SimulateMultiViewDataset.java:567-613 without the TIFF writes); same workload as `value`"}
+            del extra
+        except Exception as e:
+            out["main_iteration"] = {"failed": repr(e)}
     if rank == 0 and not multi and len(ctxs) == 1 and not args.no_two_streams and args.conv_method == 1:
         # two contexts on the GPU: views alternate between them (reported beside `value`)
         def timed_steps():

@@ -216,6 +216,25 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
                             float* psf_host, const int64_t kdim[3],
                             const mvsim_view_params* params, const mvsim_view_outputs* out,
                             double* correction);
+/* One whole iteration of `main`'s view loop (SimulateMultiViewDataset.java:567-613), device-resident: the view above
+ * (rotate, attenuate, convolve, adjust, extractSlices + Poisson) followed by what the loop does with its results --
+ *   iso          = makeIsotropic(acq, inc)                                    (:588)   Nx*Ny*isotropic_nz
+ *   view         = rotateAroundAxis(iso, axis, back_degrees)                  (:591)   same size (the reference passes -angle)
+ *   view_weights = rotateAroundAxis(computeWeightImage(rot, delta), axis, back_degrees)   (:576,592)   Nx*Ny*Nz
+ *   view_psf     = rotateAroundAxis(psf, axis, back_degrees)                  (:593)   Kx*Ky*Kz, the PSF as convolve() left it (normalised, Q5)
+ * Every non-NULL member of `more` is a device buffer of that size; `iso` may be NULL with `view` set (library scratch).
+ * computeWeightImage depends on the dimensions alone: it is rendered once per context and size and reused.
+ * `out->acq` is required; the call is asynchronous on the context's stream. */
+typedef struct mvsim_iteration_outputs {
+    float* iso;
+    float* view;
+    float* view_weights;
+    float* view_psf;
+} mvsim_iteration_outputs;
+int mvsim_simulate_iteration_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3],
+                                 float* psf_host, const int64_t kdim[3],
+                                 const mvsim_view_params* params, int back_degrees,
+                                 const mvsim_view_outputs* out, const mvsim_iteration_outputs* more);
 /* Host buffers in / out (what the JNI shim calls). */
 int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3],
                         float* psf_host, const int64_t kdim[3],

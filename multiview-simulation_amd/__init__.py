@@ -464,6 +464,18 @@ class Context:
             C.byref(o), C.byref(corr) if want_corr else None))
         return corr.value if want_corr else None
 
+    def simulate_iteration_dev(self, gt_dptr: int, dim_xyz, psf: np.ndarray, params: ViewParams, back_degrees: int, acq_dptr: int,
+                               iso_dptr: int = 0, view_dptr: int = 0, view_weights_dptr: int = 0, view_psf_dptr: int = 0,
+                               rot_dptr: int = 0, att_dptr: int = 0, con_dptr: int = 0) -> None:
+        """One iteration of `main`'s view loop (SimulateMultiViewDataset.java:567-613), device-resident: the view, then
+        makeIsotropic and the three rotate-backs (iso, the weight image, the PSF) into whichever buffers are given."""
+        _check_inplace(psf, "psf")
+        o = ViewOutputs(rot_dptr or None, att_dptr or None, con_dptr or None, acq_dptr or None)
+        more = _lib.IterationOutputs(iso_dptr or None, view_dptr or None, view_weights_dptr or None, view_psf_dptr or None)
+        _lib.check(self._L.mvsim_simulate_iteration_dev(
+            self._h, C.c_void_p(gt_dptr), (C.c_int64 * 3)(*dim_xyz), _ptr(psf), _dim(psf), C.byref(params), int(back_degrees),
+            C.byref(o), C.byref(more)))
+
     # -- z-slab tiling of one view across GPUs (BASELINE configs[3]/[4])
     def slab_range(self, nz: int, nranks: int, rank: int):
         z0, z1 = C.c_int64(), C.c_int64()

@@ -36,6 +36,10 @@ class ViewOutputs(C.Structure):
     _fields_ = [("rot", C.c_void_p), ("att", C.c_void_p), ("con", C.c_void_p), ("acq", C.c_void_p)]
 
 
+class IterationOutputs(C.Structure):
+    _fields_ = [("iso", C.c_void_p), ("view", C.c_void_p), ("view_weights", C.c_void_p), ("view_psf", C.c_void_p)]
+
+
 class Sphere(C.Structure):
     _fields_ = [("cx", C.c_int32), ("cy", C.c_int32), ("cz", C.c_int32), ("radius", C.c_int32), ("value", C.c_float)]
 
@@ -103,6 +107,8 @@ SIGNATURES = {
     "mvsim_view_params_default": (None, [C.POINTER(ViewParams)]),
     "mvsim_simulate_view_dev": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams),
                                           C.POINTER(ViewOutputs), C.POINTER(C.c_double)]),
+    "mvsim_simulate_iteration_dev": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams), C.c_int,
+                                               C.POINTER(ViewOutputs), C.POINTER(IterationOutputs)]),
     "mvsim_simulate_view": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams),
                                       C.POINTER(ViewOutputs), C.POINTER(C.c_double)]),
     "mvsim_splat_spheres": (C.c_int, [_vp, _vp, _i64p, _vp, C.c_int64]),

@@ -30,7 +30,8 @@ int parse_option(Options& o, const char* name, const char* value)
     const std::string n(name), v(value);
     auto flag = [&](bool* dst) { if (v == "1" || v == "on" || v == "true") *dst = true; else if (v == "0" || v == "off" || v == "false") *dst = false; else return MVSIM_EINVAL; return MVSIM_OK; };
     if (n == "fft_zpass") {
-        if (v == "auto") o.zpass = 0; else if (v == "direct") o.zpass = 1; else if (v == "fft") o.zpass = 2; else return MVSIM_EINVAL;
+        if (v == "auto") o.zpass = 0; else if (v == "direct") o.zpass = 1; else if (v == "fft") o.zpass = 2; else if (v == "inline") o.zpass = 3;
+        else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
     if (n == "fft_backend") {
@@ -439,7 +440,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     view_graphs_release(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release();
+    ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0;
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
@@ -507,7 +508,7 @@ int mvsim_release_caches(mvsim_ctx* ctx)
     view_graphs_release(ctx);                             // captured launches point into the workspaces released below
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->sphere_list.release();
+    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0;
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     return MVSIM_OK;
 }
@@ -1057,6 +1058,47 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
         MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
         MVSIM_HIP(hipMemcpyAsync(correction, scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MVSIM_OK;
+}
+
+int mvsim_simulate_iteration_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host, const int64_t kdim[3],
+                                 const mvsim_view_params* p, int back_degrees, const mvsim_view_outputs* o,
+                                 const mvsim_iteration_outputs* more)
+{
+    MVSIM_CHECK_ARG(ctx && more, "null pointer");
+    MVSIM_TRY(mvsim_simulate_view_dev(ctx, gt, dim, psf_host, kdim, p, o, nullptr));
+    MVSIM_TRY(set_device(ctx));                            // the rest reads the acquisition: a pending tail runs first
+    Affine inv;
+    double m[12];
+    if (more->iso || more->view) {
+        const int64_t adim[3] = {dim[0], dim[1], mvsim_extract_nz(dim[2], p->inc)};
+        const int64_t idim[3] = {dim[0], dim[1], mvsim_isotropic_nz(adim[2], p->inc)};
+        float* iso = more->iso;
+        if (!iso) { MVSIM_TRY(ctx->vol_c.reserve((size_t)(idim[0] * idim[1] * idim[2]) * sizeof(float))); iso = ctx->vol_c.as<float>(); }
+        MVSIM_CHECK_ARG(iso != more->view, "iso and view must be different buffers");
+        MVSIM_TRY(launch_make_isotropic(ctx->stream, o->acq, iso, adim, p->inc));
+        if (more->view) {
+            axis_rotation_host(idim, p->axis, back_degrees, m);
+            affine_invert_host(m, inv.m);
+            MVSIM_TRY(launch_rotate(ctx->stream, iso, more->view, idim, inv));
+        }
+    }
+    if (more->view_weights) {
+        if (ctx->weight_dim[0] != dim[0] || ctx->weight_dim[1] != dim[1] || ctx->weight_dim[2] != dim[2] || !ctx->weight_img.p) {
+            MVSIM_TRY(ctx->weight_img.reserve((size_t)nvox(dim) * sizeof(float)));
+            MVSIM_TRY(launch_weight_image(ctx->stream, ctx->weight_img.as<float>(), dim));
+            for (int d = 0; d < 3; ++d) ctx->weight_dim[d] = dim[d];
+        }
+        axis_rotation_host(dim, p->axis, back_degrees, m);
+        affine_invert_host(m, inv.m);
+        MVSIM_TRY(launch_rotate(ctx->stream, ctx->weight_img.as<float>(), more->view_weights, dim, inv));
+    }
+    if (more->view_psf) {
+        // psf_dev holds the normalised PSF this view was convolved with (psf_prepare)
+        axis_rotation_host(kdim, p->axis, back_degrees, m);
+        affine_invert_host(m, inv.m);
+        MVSIM_TRY(launch_rotate(ctx->stream, ctx->psf_dev.as<float>(), more->view_psf, kdim, inv));
     }
     return MVSIM_OK;
 }

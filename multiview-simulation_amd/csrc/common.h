@@ -96,7 +96,9 @@ struct PinnedRing {
 // Run-time switches of a context.  Defaults come from the environment, read ONCE per process (env_options); the tests
 // reach every code path through mvsim_set_option.  Nothing on a launch path calls getenv.
 struct Options {
-    int     zpass = 0;                 // z pass of the hand-written convolution: 0 auto (direct for Kz <= 64), 1 direct, 2 FFT
+    int     zpass = 0;                 // z pass of the hand-written convolution: 0 auto, 1 direct Kz-tap convolution (Kz <= 64), 2 FFT on a
+                                       // z-padded spectrum, 3 FFT inline: no z padding, mirrored planes through the index map, the PSF's z
+                                       // spectrum computed per tile (k_fft_lines<CONVZ>); auto: inline from MVSIM_ZINLINE_MIN_KZ taps up, else direct
     bool    rocfft = false;            // library fallback instead of the hand-written passes
     int     fused_rotate = 3;          // rotate+attenuate as one kernel when the rotation is about x: 0 off, 1 row geometry
                                        // shared through LDS, 2 recomputed per lane (kept for A/B runs), 3 auto (production):
@@ -195,6 +197,8 @@ struct mvsim_ctx {
     mvsim::DevBuf fft_work;
     mvsim::DevBuf pqueue;                   // Poisson work queue: [count][items]
     mvsim::DevBuf sphere_list;              // phantom generator: (centre, radius, value) items
+    mvsim::DevBuf weight_img;               // computeWeightImage of the last volume size (mvsim_simulate_iteration_dev)
+    int64_t       weight_dim[3] = {0, 0, 0};
     mvsim::DevBuf host_gt, host_rot, host_att, host_con;   // device twins of the host-buffer simulate_view (grow-only)
     mvsim::DevBuf partials;                 // doubles: block partial sums + [sum, corr]
     mvsim::DevBuf partials_e;               // per-block sums of the c2r/crop pass
@@ -268,7 +272,7 @@ struct mvsim_ctx {
 inline mvsim_ctx::mvsim_ctx()
 {
     for (mvsim::DevBuf* b : {&vol_a, &vol_b, &vol_c, &out_buf, &psf_dev, &stencil_psf, &fft_real, &fft_spec_img, &fft_spec_psf, &fft_work,
-                             &pqueue, &sphere_list, &host_gt, &host_rot, &host_att, &host_con, &partials, &partials_e, &cfft_f, &cfft_g,
+                             &pqueue, &sphere_list, &weight_img, &host_gt, &host_rot, &host_att, &host_con, &partials, &partials_e, &cfft_f, &cfft_g,
                              &cfft_g1, &cfft_g2, &partials_z, &async_gt[0], &async_gt[1], &async_acq[0], &async_acq[1]})
         b->epoch = &alloc_epoch;
 }

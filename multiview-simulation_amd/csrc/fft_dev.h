@@ -176,16 +176,23 @@ __device__ __forceinline__ void wave_order()
 // twiddle + DFT + write back in Stockham order.
 // Identity / "multiply by the PSF spectrum and conjugate" operators applied to the inputs of the FIRST radix
 // pass (the spectrum product of pass C rides on the second transform's loads: no separate LDS pass).
+// (it, r: the butterfly's place in the first pass's register tile -- compile-time constants once the loops are unrolled)
 struct LoadIdentity {
-    __device__ __forceinline__ float2 operator()(float2 v, int, int) const { return v; }
+    __device__ __forceinline__ float2 operator()(float2 v, int, int, int, int) const { return v; }
 };
 struct LoadMulConj {
     const float2* g;        // spectrum lines of this wave, line-major: g[line * glen + n]
     int glen;
-    __device__ __forceinline__ float2 operator()(float2 v, int line, int n) const
+    __device__ __forceinline__ float2 operator()(float2 v, int line, int n, int, int) const
     {
         return cconj(cmul(v, g[line * glen + n]));
     }
+};
+// the same product with the spectrum held in REGISTERS, laid out as the first pass reads its operands (ps[it][r]: what
+// capture_first_pass took from the transformed PSF lines of this wave)
+template <int IT, int R> struct LoadMulConjReg {
+    const float2 (&ps)[IT][R];
+    __device__ __forceinline__ float2 operator()(float2 v, int, int, int it, int r) const { return cconj(cmul(v, ps[it][r])); }
 };
 
 // Twiddles: one table per transform length, laid out PER PASS and r-major -- pass (P, R) owns (R-1)*P entries at
@@ -210,7 +217,7 @@ __device__ __forceinline__ void wpasses(float2* __restrict__ wbuf, const float2*
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 u[it][r] = src[r * STR];
-                if (P == 1) u[it][r] = op(u[it][r], line, i + r * STR);
+                if (P == 1) u[it][r] = op(u[it][r], line, i + r * STR, it, r);
             }
         }
     }
@@ -268,8 +275,29 @@ template <int M> struct CfgX {
     static constexpr size_t LDS = (size_t)(NL * LP + M) * sizeof(float2) + 32 * sizeof(double);
 };
 
+template <int A, int...> struct FirstOf { static constexpr int value = A; };
+
 template <int L, int... Rs> struct Plan {
     static constexpr int len = L;
+    static constexpr int R1 = FirstOf<Rs...>::value;            // radix of the first pass
+    // the wave's transformed lines as the operands of the NEXT transform's first pass: ps[it][r] = wbuf[line][i + r * STR]
+    template <int LW, int IT>
+    static __device__ __forceinline__ void capture_first_pass(const float2* wbuf, int lane, float2 (&ps)[IT][R1])
+    {
+        constexpr int STR = L / R1, NB = LW * STR;
+        static_assert(IT == (NB + 63) / 64, "register tile of the first pass");
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int b = lane + it * 64;
+#pragma unroll
+            for (int r = 0; r < R1; ++r) ps[it][r] = make_float2(0.f, 0.f);
+            if ((NB % 64 == 0) || b < NB) {
+                const int line = b / STR, i = b - line * STR;
+#pragma unroll
+                for (int r = 0; r < R1; ++r) ps[it][r] = wbuf[line * (L + 1) + i + r * STR];
+            }
+        }
+    }
     // transform the LW lines starting at wbuf (owned by the calling wave)
     template <int LW>
     static __device__ __forceinline__ void run(float2* wbuf, const float2* tw, int lane)

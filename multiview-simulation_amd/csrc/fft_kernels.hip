@@ -27,7 +27,10 @@ namespace mvsim {
 namespace fft {
 
 // ---------------------------------------------------------------------------------- y / z pass kernel
-enum Mode { FWD = 0, INV = 1, CONV = 2 };
+// CONVZ: the z pass as FFT -> product -> inverse FFT on a spectrum WITHOUT z padding (the geometry of the direct z pass): the
+// mirrored halo planes are read from their mirror images through the index map, and the PSF's z spectrum is never stored --
+// every block transforms the Kz taps of its own 16 lines first and keeps the result in registers for the product.
+enum Mode { FWD = 0, INV = 1, CONV = 2, CONVZ = 3 };
 
 struct LinesArgs {
     const float2* src;      // element (line c, position n) of tile (bx, by): src[by*src_outer + n'*src_es + bx*NL + c]
@@ -46,6 +49,17 @@ struct LinesArgs {
     long long     src_blk, dst_blk;
     int           src_mirror;       // != 0 (non-SPARSE): position n reads source position map_src(lmap, n) -- the mirrored halo rows
                                     // of the padded image are the rows themselves, read twice instead of transformed twice
+    // blocked OUTER addressing (0: linear): outer index by sits at (by >> ZBS) * oblk + (by & (ZB - 1)) * outer -- the z-blocked
+    // spectrum layout seen from a pass whose lines run along z (CONVZ)
+    long long     src_oblk, dst_oblk;
+    // CONVZ: the PSF's (x, y) spectrum, Kz planes in the z-blocked layout of the direct z pass (ZConvArgs::taps); pmap embeds tap
+    // t at position (t - Kz / 2) mod L; adjustImage's sum from this pass's output as in k_zconv (null: not wanted)
+    const float2* taps;
+    long long     taps_es, taps_oblk, taps_outer;
+    DimMap        pmap;
+    const double2* wx;
+    const double2* wy;
+    double*       sum_partial;
     // GW > 0 (guest waves, see k_fft_lines): work the block's extra waves do beside the transform
     struct Guest {
         int        kind;            // 0: none, 1: phase 1 of the sampler, 2: the resolver, 3: experiment (chain of `nseg` Philox blocks per wave)
@@ -58,6 +72,9 @@ struct LinesArgs {
 
 #ifndef MVSIM_ZBS
 #define MVSIM_ZBS 4
+#endif
+#ifndef MVSIM_ZINLINE_MIN_KZ
+#define MVSIM_ZINLINE_MIN_KZ 48           // measured (profiles/r04_zpass_sweep.txt): see custom_fft_convolve_slab
 #endif
 constexpr int ZBS = MVSIM_ZBS, ZB = 1 << ZBS;        // rows per block of the z-blocked layout
 
@@ -131,7 +148,23 @@ void k_fft_lines(LinesArgs p)
 
     // all global loads of the tile are issued before anything waits
     const int by = (int)blockIdx.y >= p.outer_skip_lo ? (int)blockIdx.y + p.outer_skip_len : (int)blockIdx.y;
-    const float2* sbase = p.src + (long long)by * p.src_outer + (long long)blockIdx.x * NL + c2;
+    auto outer_off = [&](long long outer, long long oblk) {
+        return oblk ? (long long)(by >> ZBS) * oblk + (long long)(by & (ZB - 1)) * outer : (long long)by * outer;
+    };
+    const float2* sbase = p.src + outer_off(p.src_outer, p.src_oblk) + (long long)blockIdx.x * NL + c2;
+    float4 vp[MODE == CONVZ ? NIT : 1];
+    if (MODE == CONVZ) {
+        const float2* tbase = p.taps + outer_off(p.taps_outer, p.taps_oblk) + (long long)blockIdx.x * NL + c2;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int n = r0 + it * ROWS;
+            vp[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((L % ROWS == 0) || n < L) {
+                const int t = map_src(p.pmap, n);
+                if (t >= 0) vp[it] = *reinterpret_cast<const float4*>(tbase + (long long)t * p.taps_es);
+            }
+        }
+    }
     float4 v[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -148,6 +181,23 @@ void k_fft_lines(LinesArgs p)
         }
     }
     for (int i = tid; i < L; i += T) tw[i] = p.tw[i];
+    constexpr int R1 = PLAN::R1, IT1 = (LW * (L / R1) + 63) / 64;
+    float2 ps[MODE == CONVZ ? IT1 : 1][MODE == CONVZ ? R1 : 1];
+    if constexpr (MODE == CONVZ) {
+        // the PSF's z lines of this tile: taps into the (zeroed) lines, transform, keep the spectrum as the product's operands
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int n = r0 + it * ROWS;
+            if ((L % ROWS == 0) || n < L) {
+                buf[c2 * LP + n] = make_float2(vp[it].x, vp[it].y);
+                buf[(c2 + 1) * LP + n] = make_float2(vp[it].z, vp[it].w);
+            }
+        }
+        __syncthreads();
+        PLAN::template run<LW>(wbuf, tw, lane);
+        PLAN::template capture_first_pass<LW, IT1>(wbuf, lane, ps);
+        __syncthreads();                                  // every wave has read its PSF lines: the image tile may overwrite them
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int n = r0 + it * ROWS;
@@ -167,6 +217,7 @@ void k_fft_lines(LinesArgs p)
         const float2* gl = p.spec + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * NL + (long long)wave * LW) * L;
         PLAN::template run_op<LW>(wbuf, tw, lane, LoadMulConj{gl, L});
     }
+    if constexpr (MODE == CONVZ) PLAN::template run_op<LW>(wbuf, tw, lane, LoadMulConjReg<IT1, R1>{ps});
     if (MODE == FWD && p.dst_tile_major) {
         // wave-private store: every line of the tile contiguous (consumed by LoadMulConj above)
         float2* gl = p.dst + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * NL + (long long)wave * LW) * L;
@@ -179,8 +230,9 @@ void k_fft_lines(LinesArgs p)
         return;
     }
     if (GW > 0) waves_barrier(bar, 2 * NW, lane); else __syncthreads();
-    float2* dbase = p.dst + (long long)by * p.dst_outer + (long long)blockIdx.x * NL + c2;
+    float2* dbase = p.dst + outer_off(p.dst_outer, p.dst_oblk) + (long long)blockIdx.x * NL + c2;
     const int nstore = p.store_limit > 0 ? p.store_limit : L;
+    float2 sa = make_float2(0.f, 0.f), sb = make_float2(0.f, 0.f);       // CONVZ: this thread's share of its two lines' sums over z
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int n = r0 + it * ROWS;
@@ -188,6 +240,31 @@ void k_fft_lines(LinesArgs p)
             float2 a = buf[c2 * LP + n], b = buf[(c2 + 1) * LP + n];
             if (MODE != FWD) { a = cconj(a); b = cconj(b); }
             *reinterpret_cast<float4*>(dbase + line_off(n, p.dst_es, p.dst_blk)) = make_float4(a.x, a.y, b.x, b.y);
+            if (MODE == CONVZ) { sa = cadd(sa, a); sb = cadd(sb, b); }
+        }
+    }
+    if constexpr (MODE == CONVZ) {
+        if (p.sum_partial) {
+            // adjustImage's sum from the spectrum side, as k_zconv's epilogue: SUM_z of every line (fp32 over a thread's <= NIT rows,
+            // double from there on), weighted with wx[kx] * wy[ky], one double per block
+            __syncthreads();                              // everybody has read its outputs: the tile serves as scratch
+            float2* red = buf;                            // [ROWS][NL]
+            red[r0 * NL + c2] = sa;
+            red[r0 * NL + c2 + 1] = sb;
+            __syncthreads();
+            double t = 0.0;
+            if (tid < NL) {
+                double sre = 0.0, sim = 0.0;
+                for (int r = 0; r < ROWS; ++r) { const float2 q = red[r * NL + tid]; sre += (double)q.x; sim += (double)q.y; }
+                const double2 a = p.wx[(int)blockIdx.x * NL + tid], b = p.wy[by];
+                const double wr = a.x * b.x - a.y * b.y, wi = a.x * b.y + a.y * b.x;
+                t = sre * wr - sim * wi;                  // Re( s * W )
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+                if (lane == 0) p.sum_partial[(long long)blockIdx.y * gridDim.x + blockIdx.x] = t;
+            }
         }
     }
 }
@@ -869,6 +946,7 @@ static int launch_lines_t(mvsim_ctx* ctx, int mode, bool sparse, const LinesArgs
     if (mode == FWD && sparse) MVSIM_LL(FWD, true);
     else if (mode == FWD) MVSIM_LL(FWD, false);
     else if (mode == INV) MVSIM_LL(INV, false);
+    else if (mode == CONVZ) MVSIM_LL(CONVZ, false);
     else MVSIM_LL(CONV, false);
 #undef MVSIM_LL
     MVSIM_HIP(hipGetLastError());
@@ -977,6 +1055,17 @@ static bool lines_can_host(int L)
 {
     switch (L) {
 #define X(LL, ...) case LL: return guest_capable_of<LL>();
+        MVSIM_FFT_SIZES(X)
+#undef X
+    }
+    return false;
+}
+
+template <int L> static constexpr bool two_blocks_of() { return lines_blocks_per_cu<L>() == 2; }
+static bool lines_two_blocks_per_cu(int L)
+{
+    switch (L) {
+#define X(LL, ...) case LL: return two_blocks_of<LL>();
         MVSIM_FFT_SIZES(X)
 #undef X
     }
@@ -1259,12 +1348,20 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     MVSIM_TRY(ctx->partials_e.reserve((size_t)((rows_out_early + 3) / 4 + 16) * sizeof(double)));
     double* scal = scal_of(ctx);
 
+    // the z pass on the unpadded spectrum as FFT -> product -> inverse FFT with the PSF's z spectrum computed per tile (CONVZ): from
+    // MVSIM_ZINLINE_MIN_KZ taps up the Kz-tap direct convolution is bound by its FMAs and this form by HBM (profiles/r04_zpass_sweep.txt)
+    // Measured, whole views with 31 x 31 x Kz PSFs: 2048 x 2048 x 512 (padded z length 576, two blocks per CU) -- pass C 8.1 ms whatever
+    // Kz against 8.1 / 9.0 / 10.2 ms for the direct form at Kz = 41 / 51 / 63; 1024^3 (length 1120: one 81 KB tile per CU) -- 5.6 ms
+    // against 3.9 / 4.4 / 4.9 ms: three transforms per tile on eight waves are no longer hidden behind HBM.  Hence auto = deep PSFs on
+    // z lengths whose tiles fit twice per CU.
+    const bool zinline = zdirect && !is_slab &&
+                         (ctx->opt.zpass == 3 || (ctx->opt.zpass == 0 && kz >= MVSIM_ZINLINE_MIN_KZ && lines_two_blocks_per_cu(pz)));
     const float2 *tw_m, *tw_px, *tw_py, *tw_pz;
     MVSIM_TRY(ensure_twiddles(ctx, M, 0, &tw_m));
     MVSIM_TRY(ensure_twiddles(ctx, px, 1, &tw_px));
     MVSIM_TRY(ensure_twiddles(ctx, py, 0, &tw_py));
     tw_pz = nullptr;
-    if (!zdirect) MVSIM_TRY(ensure_twiddles(ctx, pz, 0, &tw_pz));
+    if (!zdirect || zinline) MVSIM_TRY(ensure_twiddles(ctx, pz, 0, &tw_pz));
 
     float2* F = ctx->cfft_f.as<float2>();
     float2* G = ctx->cfft_g.as<float2>();
@@ -1457,7 +1554,34 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));    // the z pass reads the PSF spectrum
         ev_begin(ctx, ST_PASS_C);
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
-        if (zdirect) {
+        if (zinline) {
+            LinesArgs c{};
+            c.src = G; c.dst = F; c.tw = tw_pz;
+            c.src_es = c.dst_es = (long long)ZB * hxp; c.src_outer = c.dst_outer = hxp;
+            c.src_oblk = (long long)nzs * ZB * hxp; c.dst_oblk = (long long)nzo * ZB * hxp;
+            c.lmap = DimMap{(int)dim[2], pz, (int)dim[2] + kz / 2, kz - 1 - kz / 2, 0, 0};
+            c.src_mirror = 1;
+            c.gap_lo = (int)dim[2] + kz / 2; c.gap_hi = pz - (kz - 1 - kz / 2);
+            c.outer_skip_lo = 1 << 30;
+            c.store_limit = (int)dim[2];
+            c.taps = G2; c.taps_es = (long long)ZB * hxp; c.taps_outer = hxp; c.taps_oblk = (long long)kz * ZB * hxp;
+            c.pmap = DimMap{kz, pz, kz - kz / 2, kz / 2, 1, kz / 2};
+            const float scale_f = (float)(0.25 / ((double)px * (double)py * (double)pz));
+            const long long zblocks = (long long)(hxp / tile_z) * py;
+            if (early) {
+                MVSIM_TRY(ensure_box_weights(ctx, (int)dim[0], px, hxp, true, &c.wx));
+                MVSIM_TRY(ensure_box_weights(ctx, (int)dim[1], py, py, false, &c.wy));
+                MVSIM_TRY(ctx->partials_z.reserve((size_t)zblocks * sizeof(double)));
+                c.sum_partial = ctx->partials_z.as<double>();
+            }
+            MVSIM_TRY(launch_lines(ctx, pz, CONVZ, false, c, hxp / tile_z, py));
+            if (early) {
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, c.sum_partial, zblocks, scal, (double)scale_f,
+                                   corr_n, corr_min, corr_target);
+                MVSIM_HIP(hipGetLastError());
+            }
+            Fz = G;
+        } else if (zdirect) {
             ZConvArgs z{};
             z.src = G; z.dst = F; z.taps = G2; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
             z.zs = (long long)ZB * hxp; z.src_blk = (long long)nzs * ZB * hxp; z.dst_blk = (long long)nzo * ZB * hxp;
@@ -1535,7 +1659,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         if (tail && tail->join_before_e) MVSIM_TRY(join_tail(ctx));
         ev_begin(ctx, ST_PASS_E);
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
-        const float scale = (float)(0.25 / ((double)px * (double)py * (zdirect ? 1.0 : (double)pz)));
+        const float scale = (float)(0.25 / ((double)px * (double)py * ((zdirect && !zinline) ? 1.0 : (double)pz)));
         int nblk = 0;
         MVSIM_TRY(launch_c2r(ctx, M, Fz, out, tw_m, tw_px, hxp, py * zstride, (int)dim[0], (int)dim[1], (long long)dim[1] * nk, scale,
                              ctx->partials_e.as<double>(), &nblk, fuse ? &fz : nullptr));

@@ -1417,6 +1417,87 @@ def test_hipgraph_replay_of_views(mvs, synth):
             c.dev_free(d)
 
 
+def test_main_loop_iteration_device_resident(mvs, orc, synth):
+    """mvsim_simulate_iteration_dev = one pass through the body of `main`'s view loop (SimulateMultiViewDataset.java:567-613) without
+    leaving HBM: the view, makeIsotropic, and the rotate-backs of the isotropic view, of computeWeightImage and of the PSF -- against
+    the oracle's stage functions chained the same way (noise-free, so that every voxel can be compared: the view's convolution is
+    float32-FFT accurate, everything behind it is bit-exact on identical input)."""
+    nx, ny, nz, inc, deg, back = 40, 44, 36, 3, 60, -45
+    gt = np.ascontiguousarray(synth.sphere_phantom(44)[4:40, :, 2:42])
+    assert gt.shape == (nz, ny, nx)
+    psf = synth.gaussian_psf(7, 7, 9, sigma=(1.2, 1.4, 2.5))
+    want = orc.simulate_view(gt, psf.copy(), deg, inc=inc, snr=-1.0, seed=SEED, stream=0)
+    pn = psf.copy()
+    orc.norm_image(pn)
+    nzo = orc.extract_nz(nz, inc)
+    niso = (nzo - 1) * inc + 1
+    with mvs.Context(0) as c:
+        d_gt = _dev_volume(c, gt)
+        bufs = {k: c.dev_alloc(n * 4) for k, n in (("acq", nx * ny * nzo), ("iso", nx * ny * niso), ("view", nx * ny * niso),
+                                                     ("w", nx * ny * nz), ("psf", psf.size))}
+        try:
+            p = c.view_params(degrees=deg, inc=inc, snr=-1.0, seed=SEED, stream=0, conv_method=1)
+            for _ in range(2):                                          # second pass: the cached weight image
+                praw = psf.copy()
+                c.simulate_iteration_dev(d_gt, (nx, ny, nz), praw, p, back, bufs["acq"], iso_dptr=bufs["iso"], view_dptr=bufs["view"],
+                                         view_weights_dptr=bufs["w"], view_psf_dptr=bufs["psf"])
+            acq = c.download(bufs["acq"], (nzo, ny, nx))
+            iso = c.download(bufs["iso"], (niso, ny, nx))
+            view = c.download(bufs["view"], (niso, ny, nx))
+            vw = c.download(bufs["w"], (nz, ny, nx))
+            vpsf = c.download(bufs["psf"], psf.shape)
+            # a view without the optional outputs leaves the same acquisition
+            c.simulate_iteration_dev(d_gt, (nx, ny, nz), psf.copy(), p, back, bufs["acq"], view_dptr=bufs["view"])
+            assert np.array_equal(c.download(bufs["view"], (niso, ny, nx)), view)
+        finally:
+            for d in [d_gt] + list(bufs.values()):
+                c.dev_free(d)
+    assert np.array_equal(praw, pn)                                     # the PSF comes back normalised (Q5)
+    scale = float(np.abs(want["acq"]).max())
+    assert rel_to_max(acq, want["acq"]) <= CONV_TOL
+    # behind the view everything is bit-exact on identical input: feed the oracle what the GPU produced
+    assert np.array_equal(iso, orc.make_isotropic(acq, inc))
+    assert np.array_equal(view, orc.rotate_around_axis(iso, 0, back))
+    assert np.abs(view - orc.rotate_around_axis(orc.make_isotropic(want["acq"], inc), 0, back)).max() <= 2 * CONV_TOL * scale
+    w = orc.compute_weight_image((nz, ny, nx))
+    assert np.abs(vw - orc.rotate_around_axis(w, 0, back)).max() <= 2e-7
+    assert np.array_equal(vpsf, orc.rotate_around_axis(pn, 0, back))
+
+
+@pytest.mark.parametrize("shape,kshape", [((64, 80, 72), (9, 7, 5)), ((100, 128, 96), (31, 15, 11)), ((40, 48, 44), (39, 5, 5)),
+                                          ((200, 96, 64), (63, 9, 7))])
+def test_inline_fft_z_pass(mvs, orc, synth, shape, kshape):
+    """fft_zpass=inline (k_fft_lines<CONVZ>): the z pass as FFT -> product -> inverse FFT on the UNPADDED spectrum -- mirrored halo
+    planes through the index map, the PSF's z spectrum computed per tile and kept in registers, adjustImage's sum from its epilogue.
+    What auto selects for deep PSFs on z lengths whose tiles fit twice per CU (configs[4]: 2048 x 2048 x 512, 63 taps).  Against the
+    oracle's exact direct sum, and the fused view against the direct z pass (same sum, same compact planes)."""
+    nz, ny, nx = shape
+    rng = np.random.default_rng(5)
+    v = synth.sphere_phantom(nx, ny, nz) + 0.01 * rng.random(shape, dtype=np.float32)
+    psf = (synth.gaussian_psf(kshape[2], kshape[1], kshape[0], sigma=(kshape[2] / 6, kshape[1] / 6, kshape[0] / 5)) *
+           (1 + 0.3 * rng.random(kshape, dtype=np.float32))).astype(np.float32)
+    pn = psf.copy()
+    orc.norm_image(pn)
+    out = {}
+    for zp in ("direct", "inline"):
+        with mvs.Context(0) as c:
+            c.set_option("fft_zpass", zp)
+            con = c.convolve(v, psf.copy(), method=1)
+            views = [c.simulate_view(v, psf.copy(), c.view_params(degrees=40, inc=inc, snr=snr, seed=SEED, stream=2, conv_method=1), want=("acq",))
+                     for inc, snr in ((3, -1.0), (1, 25.0))]
+            out[zp] = (con, views)
+    scale = float(np.abs(out["direct"][0]).max())
+    idx = np.unique(np.concatenate([np.arange(300), v.size - 1 - np.arange(300), rng.integers(0, v.size, 1500)]))
+    want = orc.convolve_direct_at(v, pn, idx)
+    for zp in ("direct", "inline"):
+        assert float(np.abs(out[zp][0].ravel()[idx] - want).max()) <= CONV_TOL * scale, zp
+    assert rel_to_max(out["inline"][0], out["direct"][0]) <= CONV_TOL
+    (a0, a1), (b0, b1) = out["direct"][1], out["inline"][1]
+    assert abs(a0["corr"] / b0["corr"] - 1) <= 1e-6                      # the sum from the epilogue of either z pass
+    assert rel_to_max(b0["acq"], a0["acq"]) <= CONV_TOL
+    assert np.mean(a1["acq"] != b1["acq"]) < 5e-3                        # counts: only where 1e-6 of lambda crosses a decision
+
+
 def test_coscheduling_options_keep_the_results(mvs, synth):
     """Round 4's ways of letting the sampler share the chip with the next view's convolution (profiles/r04_coschedule.txt):
     guest waves inside passes B and D (guest_tail, with the trips split several ways), the tail stream joined only in front of pass E

@@ -15,7 +15,7 @@ for nx, ny, nz, inc in cases:
     for kz in depths:
         psf = synth.gaussian_psf(31, 31, kz, sigma=(2.0, 2.2, kz / 5.0))
         row = {}
-        for zp in ("direct", "fft"):
+        for zp in ("direct", "inline", "fft"):
             ctx = mvs.Context(0)
             ctx.set_option("tail_overlap", 0); ctx.set_option("psf_overlap", 0); ctx.set_option("fft_zpass", zp)
             d_gt = ctx.dev_alloc(gt.nbytes); ctx.upload(d_gt, gt)
@@ -33,5 +33,5 @@ for nx, ny, nz, inc in cases:
             print(f"{nx}x{ny}x{nz} Kz={kz:2d} inc={inc} | {zp:6s} | {t['pass_c_ms']:8.3f} | {t['pass_b_ms'] + t['pass_c_ms'] + t['pass_d_ms']:8.3f} | "
                   f"{t['convolve_ms']:8.3f} | {t['total_ms']:8.3f}", flush=True)
             ctx.dev_free(d_gt); ctx.dev_free(d_acq); ctx.close()
-        d, f = row["direct"], row["fft"]
-        print(f"#   Kz={kz}: direct / fft convolve time = {d['convolve_ms'] / f['convolve_ms']:.3f}")
+        d, f, i = row["direct"], row["fft"], row["inline"]
+        print(f"#   Kz={kz}: convolve time direct / fft = {d['convolve_ms'] / f['convolve_ms']:.3f}, inline / direct = {i['convolve_ms'] / d['convolve_ms']:.3f}")
