@@ -1061,17 +1061,6 @@ static bool lines_can_host(int L)
     return false;
 }
 
-template <int L> static constexpr bool two_blocks_of() { return lines_blocks_per_cu<L>() == 2; }
-static bool lines_two_blocks_per_cu(int L)
-{
-    switch (L) {
-#define X(LL, ...) case LL: return two_blocks_of<LL>();
-        MVSIM_FFT_SIZES(X)
-#undef X
-    }
-    return false;
-}
-
 static int pick_size(int64_t need)
 {
     for (int v : kSizes)
@@ -1350,12 +1339,12 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
 
     // the z pass on the unpadded spectrum as FFT -> product -> inverse FFT with the PSF's z spectrum computed per tile (CONVZ): from
     // MVSIM_ZINLINE_MIN_KZ taps up the Kz-tap direct convolution is bound by its FMAs and this form by HBM (profiles/r04_zpass_sweep.txt)
-    // Measured, whole views with 31 x 31 x Kz PSFs: 2048 x 2048 x 512 (padded z length 576, two blocks per CU) -- pass C 8.1 ms whatever
-    // Kz against 8.1 / 9.0 / 10.2 ms for the direct form at Kz = 41 / 51 / 63; 1024^3 (length 1120: one 81 KB tile per CU) -- 5.6 ms
-    // against 3.9 / 4.4 / 4.9 ms: three transforms per tile on eight waves are no longer hidden behind HBM.  Hence auto = deep PSFs on
-    // z lengths whose tiles fit twice per CU.
+    // Measured, whole views with 31 x 31 x Kz PSFs (profiles/r04_zpass_sweep.txt): 2048 x 2048 x 512 (padded z length 576: tiles of 16
+    // lines, 128-byte rows) -- pass C 8.1 ms whatever Kz against 8.1 / 9.0 / 10.2 ms for the direct form at Kz = 41 / 51 / 63; 1024^3
+    // (length 1120: tiles of 8 lines, 64-byte rows, one line per wave) -- 5.6 ms against 3.9 / 4.4 / 4.9 ms.  Hence auto = deep PSFs on
+    // z lengths of 512 .. 576 (the sizes measured to win); everything else keeps the direct form unless asked.
     const bool zinline = zdirect && !is_slab &&
-                         (ctx->opt.zpass == 3 || (ctx->opt.zpass == 0 && kz >= MVSIM_ZINLINE_MIN_KZ && lines_two_blocks_per_cu(pz)));
+                         (ctx->opt.zpass == 3 || (ctx->opt.zpass == 0 && kz >= MVSIM_ZINLINE_MIN_KZ && pz >= 512 && lines_per_tile(pz) == 16));
     const float2 *tw_m, *tw_px, *tw_py, *tw_pz;
     MVSIM_TRY(ensure_twiddles(ctx, M, 0, &tw_m));
     MVSIM_TRY(ensure_twiddles(ctx, px, 1, &tw_px));
