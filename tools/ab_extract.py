@@ -1,3 +1,5 @@
+"""A/B harness: HIP-event stage times of one 512^3 view (serial) for the library under ROOT (a checkout / worktree / copy of the package with its own
+libmvsim.so), so that several builds run on ONE box in one gpurun call:   python tools/ab_extract.py ROOT [dense]"""
 import importlib, os, sys, numpy as np
 root = sys.argv[1]
 sys.path.insert(0, root)
@@ -7,6 +9,8 @@ n = 512
 ctx = mvs.Context(0)
 ctx.set_option("tail_overlap", 0); ctx.set_option("psf_overlap", 0)
 gt = synth.sphere_phantom(n)
+if len(sys.argv) > 2 and sys.argv[2] == "dense":
+    gt = gt + np.float32(1e-6)          # no empty rows: nothing for the zero fast paths of the fused rotate kernel to skip
 psf = synth.gaussian_psf(31, sigma=(2.0, 2.2, 6.0))
 d_gt = ctx.dev_alloc(gt.nbytes); ctx.upload(d_gt, gt)
 d_acq = ctx.dev_alloc(gt.nbytes)
@@ -17,4 +21,4 @@ acc = {}
 for _ in range(16):
     ctx.simulate_view_dev(d_gt, (n, n, n), psf.copy(), p, d_acq)
 t = ctx.timings()
-print(os.path.basename(root) or root, {k: round(v, 4) for k, v in t.items() if k in ("rotate_ms", "convolve_ms", "extract_ms", "total_ms")}, flush=True)
+print(os.path.basename(root) or root, (sys.argv[2] if len(sys.argv) > 2 else "phantom"), {k: round(v, 4) for k, v in t.items() if k in ("rotate_ms", "convolve_ms", "extract_ms", "total_ms")}, flush=True)
