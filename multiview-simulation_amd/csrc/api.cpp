@@ -83,6 +83,7 @@ int parse_option(Options& o, const char* name, const char* value)
     if (n == "tail_cus") { const int k = atoi(v.c_str()); if (k < 0 || k > 1024) return MVSIM_EINVAL; o.tail_cus = k; return MVSIM_OK; }
     if (n == "exp_guest") { o.exp_guest = atoi(v.c_str()); return MVSIM_OK; }
     if (n == "guest_tail") return flag(&o.guest_tail);
+    if (n == "skip_empty") return flag(&o.skip_empty);
     if (n == "tail_prio") { o.tail_prio = atoi(v.c_str()); return MVSIM_OK; }
     if (n == "guest_trips") { int a = -1, b = -1; if (sscanf(v.c_str(), "%d,%d", &a, &b) != 2) return MVSIM_EINVAL; o.guest_trips[0] = a; o.guest_trips[1] = b; return MVSIM_OK; }
     if (n == "kx_panel") { const int k = atoi(v.c_str()); if (k < 0 || k % 16 != 0) return MVSIM_EINVAL; o.kx_panel = k; return MVSIM_OK; }
@@ -440,7 +441,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     view_graphs_release(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0;
+    ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
@@ -448,6 +449,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
             for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(ctx->evr[k][s][0]); (void)hipEventDestroy(ctx->evr[k][s][1]); }
     if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamDestroy(ctx->tail_stream); (void)hipEventDestroy(ctx->ev_tail_fork); (void)hipEventDestroy(ctx->ev_tail); }
     if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
+    if (ctx->empty_hint) (void)hipHostFree(ctx->empty_hint);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MVSIM_OK;
@@ -508,7 +510,7 @@ int mvsim_release_caches(mvsim_ctx* ctx)
     view_graphs_release(ctx);                             // captured launches point into the workspaces released below
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0;
+    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     return MVSIM_OK;
 }
@@ -815,9 +817,10 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     bool fused = false;
     // ... and when the FFT passes follow, their x transform rides in the same kernel: `att` leaves the chip only if asked for
     bool x_done = false;
+    const int* plane_nz = nullptr;
     ev_begin(ctx, ST_ROTATE);
     if (pick_method(p->conv_method, kdim) == 1)
-        MVSIM_TRY(rotate_attenuate_fftx(ctx, gt, rot, o->att, dim, kdim, inv, p->delta, &x_done));
+        MVSIM_TRY(rotate_attenuate_fftx(ctx, gt, rot, o->att, dim, kdim, inv, p->delta, &x_done, &plane_nz));
     fused = x_done;
     if (!x_done) {
         if (!att) { MVSIM_TRY(ctx->vol_b.reserve(vbytes)); att = ctx->vol_b.as<float>(); }
@@ -853,6 +856,7 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     tail.zstride = (!materialise && p->inc > 1 && plane_vox % 4 == 0 && (!noise || ctx->opt.poisson_queue == 1)) ? p->inc : 1;
     tail.corr_n = n; tail.min_value = p->min_value; tail.target_average = p->target_average;
     tail.x_done = x_done;
+    tail.plane_nz = x_done ? plane_nz : nullptr;
     tail.join_before_e = late_join;
     if (method == 1 && ctx->opt.fuse_tail && (!noise || ctx->opt.poisson_queue == 1)) {
         const size_t qb = noise ? fused_tail_queue_bytes(dim, kdim, p->inc, materialise, ctx->opt) : 0;

@@ -138,6 +138,7 @@ struct Options {
     int     tail_cus = 0;              // > 0: the tail stream (extract + Poisson) is confined to that many CUs, see DESIGN 4.5
     int     exp_guest = -1;            // experiment (tools/guest_probe.py): >= 0: passes B and D carry guest waves running that many Philox blocks
     int     guest_trips[2] = {-1, -1}; // experiment: trips of phase 1 that ride in pass B / pass D (-1: half each); the rest runs as a kernel
+    bool    skip_empty = true;         // convolution passes skip planes the fused rotate kernel found empty (exact; option for A/B runs)
     bool    guest_tail = false;        // extract + Poisson of view v as GUEST waves inside passes B and D of view v + 1:
                                        // the sampler is bound by vector issue, the y passes by HBM, and as separate kernels they
                                        // run one after the other.  Applies where tail_overlap would (device views of >= 2^24
@@ -197,6 +198,9 @@ struct mvsim_ctx {
     mvsim::DevBuf fft_work;
     mvsim::DevBuf pqueue;                   // Poisson work queue: [count][items]
     mvsim::DevBuf sphere_list;              // phantom generator: (centre, radius, value) items
+    mvsim::DevBuf plane_flags;              // per-plane non-zero flags of the current view (rotate_fft.hip -> the convolution passes)
+    int*          empty_hint = nullptr;     // page-locked word the device writes: empty planes of the last view that carried flags (-1: none yet)
+    int           views_since_flags = 0;    // views run WITHOUT flags since (a volume without empty planes pays nothing for the bookkeeping)
     mvsim::DevBuf weight_img;               // computeWeightImage of the last volume size (mvsim_simulate_iteration_dev)
     int64_t       weight_dim[3] = {0, 0, 0};
     mvsim::DevBuf host_gt, host_rot, host_att, host_con;   // device twins of the host-buffer simulate_view (grow-only)
@@ -272,7 +276,7 @@ struct mvsim_ctx {
 inline mvsim_ctx::mvsim_ctx()
 {
     for (mvsim::DevBuf* b : {&vol_a, &vol_b, &vol_c, &out_buf, &psf_dev, &stencil_psf, &fft_real, &fft_spec_img, &fft_spec_psf, &fft_work,
-                             &pqueue, &sphere_list, &weight_img, &host_gt, &host_rot, &host_att, &host_con, &partials, &partials_e, &cfft_f, &cfft_g,
+                             &pqueue, &sphere_list, &weight_img, &plane_flags, &host_gt, &host_rot, &host_att, &host_con, &partials, &partials_e, &cfft_f, &cfft_g,
                              &cfft_g1, &cfft_g2, &partials_z, &async_gt[0], &async_gt[1], &async_acq[0], &async_acq[1]})
         b->epoch = &alloc_epoch;
 }
@@ -356,6 +360,9 @@ struct ConvTail {
     // in: a tail of the previous view is still running on the tail stream and reads the volume pass E is about to write:
     // join it (join_tail) in front of pass E
     bool join_before_e = false;
+    // in (with x_done): per-plane flags the fused rotate kernel has set (1 = the attenuated plane holds a non-zero voxel; device
+    // array of dim[2] ints): passes B .. E skip the planes whose inputs are all empty -- exact, their spectra are zero
+    const int* plane_nz = nullptr;
 };
 // true when the hand-written convolution of this geometry runs y passes that can carry the sampler as guest waves
 bool fft_can_host_guest(mvsim_ctx* ctx, const int64_t dim[3], const int64_t kdim[3]);
@@ -371,7 +378,7 @@ size_t fused_tail_queue_bytes(const int64_t dim[3], const int64_t kdim[3], int i
 int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
                            double mul, uint64_t seed, uint32_t stream, long long plane, int idx_inc, uint64_t index_offset);
 int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, float* att_or_null, const int64_t dim[3],
-                          const int64_t kdim[3], const Affine& inv, double delta, bool* done);
+                          const int64_t kdim[3], const Affine& inv, double delta, bool* done, const int** plane_nz = nullptr);
 int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,
                  const int64_t kdim[3], float* out_dev, ConvTail* tail);
 void fft_release(mvsim_ctx* ctx);

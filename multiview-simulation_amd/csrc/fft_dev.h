@@ -416,6 +416,7 @@ struct RotFftArgs {
     int halo_r, halo_l;         // mirrored positions right of the row (kx / 2) and at the end of the padded row (kx - 1 - kx / 2)
     Affine a;
     double delta;
+    int*   plane_nz;         // [nz], zeroed by the caller: set to 1 for every plane that holds a non-zero attenuated voxel (null: not wanted)
 };
 
 bool rot_fftx_has_plan(int M);

@@ -49,6 +49,10 @@ struct LinesArgs {
     long long     src_blk, dst_blk;
     int           src_mirror;       // != 0 (non-SPARSE): position n reads source position map_src(lmap, n) -- the mirrored halo rows
                                     // of the padded image are the rows themselves, read twice instead of transformed twice
+    // planes known to be empty (null: none): a block whose outer index names an empty plane has nothing to read and -- because every
+    // reader of its output asks the same flags -- nothing to write.  Outer index k = plane k * nz_stride of the flag array
+    const int*    nzflags;
+    int           nz_stride;
     // blocked OUTER addressing (0: linear): outer index by sits at (by >> ZBS) * oblk + (by & (ZB - 1)) * outer -- the z-blocked
     // spectrum layout seen from a pass whose lines run along z (CONVZ)
     long long     src_oblk, dst_oblk;
@@ -77,6 +81,16 @@ struct LinesArgs {
 #define MVSIM_ZINLINE_MIN_KZ 48           // measured (profiles/r04_zpass_sweep.txt): see custom_fft_convolve_slab
 #endif
 constexpr int ZBS = MVSIM_ZBS, ZB = 1 << ZBS;        // rows per block of the z-blocked layout
+constexpr int NZ_EXT = 96;                          // mirrored planes the flag bit string holds in front of plane 0 (>= Kz - 1 + tap padding)
+
+__device__ __forceinline__ int mirror_index(int i, int n)
+{
+    if (n == 1) return 0;
+    const int p = 2 * n - 2;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - i;
+}
 
 __device__ __forceinline__ long long line_off(int n, long long es, long long blk)
 {
@@ -148,6 +162,12 @@ void k_fft_lines(LinesArgs p)
 
     // all global loads of the tile are issued before anything waits
     const int by = (int)blockIdx.y >= p.outer_skip_lo ? (int)blockIdx.y + p.outer_skip_len : (int)blockIdx.y;
+    if (GW == 0 && p.nzflags) {
+        // block-uniform (one scalar load): nothing of an empty plane is read, transformed or stored -- its readers skip it on the
+        // same flags.  Pass B: flags of the input planes; pass D: the dilated flags (a plane of the z pass's output is empty iff
+        // every plane its Kz taps reach is), outer index k = plane k * nz_stride
+        if (p.nzflags[by * p.nz_stride] == 0) return;
+    }
     auto outer_off = [&](long long outer, long long oblk) {
         return oblk ? (long long)(by >> ZBS) * oblk + (long long)(by & (ZB - 1)) * outer : (long long)by * outer;
     };
@@ -437,13 +457,20 @@ struct C2RFuse {
     unsigned int  segcap;
 };
 
+// planes of pass E's input known to be empty (pass D has not written them): plane k of this pass is plane k * stride of the
+// dilated flag array (null: none)
+struct C2REmpty {
+    const int* flags;
+    int        stride;
+};
+
 template <class PLAN, bool FUSE>
 __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* __restrict__ srcc,
                                                                  float* __restrict__ out,
                                                                  const float2* __restrict__ twg,
                                                                  const float2* __restrict__ twx, int hxp, int py,
                                                                  int nx, int ny, long long rows, float scale,
-                                                                 double* __restrict__ partial, C2RFuse f)
+                                                                 double* __restrict__ partial, C2RFuse f, C2REmpty em)
 {
     constexpr int M = PLAN::len;
     using C = CfgX<M>;
@@ -478,8 +505,15 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
             const unsigned urow = (unsigned)row;      // rows = Ny*Nz < 2^31
             const int z = (int)(urow / (unsigned)ny), y = (int)(urow - (unsigned)z * (unsigned)ny);
             offs[j] = ((long long)z * py + y) * hxp;
+            // a row of an empty plane is a row of zeros -- not read (nobody wrote it), transformed to zeros
+            if (em.flags && em.flags[__builtin_amdgcn_readfirstlane(z) * em.stride] == 0) offs[j] = -1;   // (a wave's rows are wave-uniform: scalar load)
         }
     }
+    // every row of this wave lies in an empty plane (wave-uniform): nothing to read or transform, its outputs are zeros
+    bool wave_empty = !FUSE && em.flags != nullptr;
+#pragma unroll
+    for (int j = 0; j < LW; ++j) wave_empty = wave_empty && (offs[j] < 0);
+    if (!wave_empty) {
     float4 xa[HIT];
     float2 xb0[HIT], xb1[HIT];
 #pragma unroll
@@ -535,8 +569,9 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
         }
         wbuf[j * LP + k] = zk;
     }
+    }
     __syncthreads();                                  // twiddle table complete (rows are wave-private)
-    PLAN::template run<LW>(wbuf, tw, lane);
+    if (!wave_empty) PLAN::template run<LW>(wbuf, tw, lane);
     // z[n] = conj(buf[n]) = x[2n] + i x[2n+1]; lane q writes x[4q..4q+3]
     if (FUSE) {
         // nx % 4 == 0 and 16-byte aligned outputs are guaranteed by the launcher
@@ -589,6 +624,11 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
         const long long row = row0 + j;
         if (row >= rows) break;
         float* __restrict__ o = out + row * nx;
+        if (wave_empty) {
+            if (vec_out) for (int q = lane; 4 * q < nx; q += 64) *reinterpret_cast<float4*>(o + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else for (int q = lane; q < nx; q += 64) o[q] = 0.f;
+            continue;
+        }
         const float2* __restrict__ zrow = wbuf + j * LP;
         for (int q = lane; 4 * q < nx; q += 64) {
             const float2 z0 = zrow[2 * q];
@@ -613,6 +653,36 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
         double sum = 0.0;
         for (int w = 0; w < NW; ++w) sum += red[w];
         partial[blockIdx.x] = sum;
+    }
+}
+
+// Empty-plane bookkeeping for the convolution passes (one small block per view).  flags[z] = 1 where the fused rotate kernel found a
+// non-zero voxel in plane z.  dil[z] = 1 iff any plane the z pass's Kz taps reach from output plane z -- z + c - t, t = 0 .. kz - 1,
+// mirror-single at the faces -- is non-empty (passes D and E).  bits: bit i = flags[mirror(i - NZ_EXT)] (pass C').
+__global__ __launch_bounds__(1024) void k_plane_flags_finish(const int* __restrict__ flags, int n, int kz, int c, unsigned int* __restrict__ bits,
+                                                             int nwords, int* __restrict__ dil, int* __restrict__ empty_hint)
+{
+    const int t = threadIdx.x;
+    if (empty_hint) {
+        // how many planes are empty: a hint for the host (page-locked), see rotate_attenuate_fftx
+        __shared__ int cnt;
+        if (t == 0) cnt = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int z = t; z < n; z += 1024) mine += flags[z] == 0;
+        if (mine) atomicAdd(&cnt, mine);
+        __syncthreads();
+        if (t == 0) *empty_hint = cnt;
+    }
+    for (int w = t; w < nwords; w += 1024) {
+        unsigned int m = 0u;
+        for (int k = 0; k < 32; ++k) m |= (flags[mirror_index(w * 32 + k - NZ_EXT, n)] != 0 ? 1u : 0u) << k;
+        bits[w] = m;
+    }
+    for (int z = t; z < n; z += 1024) {
+        int any = 0;
+        for (int tt = 0; tt < kz && !any; ++tt) any = flags[mirror_index(z + c - tt, n)] != 0;
+        dil[z] = any;
     }
 }
 
@@ -701,16 +771,12 @@ struct ZConvArgs {
     const double2* wx;
     const double2* wy;
     double*       sum_partial;
+    // planes of the input known to be empty (pass B has not even written them; null: none): their rows are not loaded, and a tile
+    // whose rows are all empty computes and stores nothing (pass D skips its planes on the same flags)
+    // bit i = plane mirror(i - NZ_EXT) is non-empty: the flags as a bit string that already holds the mirrored halo on both sides, so
+    // that the planes a tile reaches are ONE run of bits (k_plane_flags_finish); null: every plane is read
+    const unsigned int* nzbits;
 };
-
-__device__ __forceinline__ int mirror_index(int i, int n)
-{
-    if (n == 1) return 0;
-    const int p = 2 * n - 2;
-    i %= p;
-    if (i < 0) i += p;
-    return i < n ? i : p - i;
-}
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -743,11 +809,61 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     const int hl = p.kz - 1 - p.c;                        // halo below z = 0
     // all global loads of the tile are issued before anything waits
     float4 v[ZNIT], tv[TNIT];
+    // which of the staged rows belong to non-empty planes: ZRPI = 32 rows per staging iteration = one 32-bit word per iteration, cut
+    // out of the flag bit string with scalar loads and shifts (block-uniform; all ones without flags).  Rows of empty planes are not
+    // read -- pass B has not written them --, and a tile without a single non-empty row has nothing to compute or store.
+    static_assert(ZRPI == 32, "one word of plane bits per staging iteration");
+    unsigned int rowbits[ZNIT];
+    unsigned int zbmask = 0xFFFFu;                                   // z blocks of this tile that have anything to compute
+#pragma unroll
+    for (int it = 0; it < ZNIT; ++it) rowbits[it] = 0xFFFFFFFFu;
+    if (p.nzbits) {
+        const int b0 = p.z_out0 + zc0 - hl + NZ_EXT - padf;           // bit of staged row 0 (>= 0: NZ_EXT covers halo and padding)
+        const unsigned int* __restrict__ wp = p.nzbits + (b0 >> 5);
+        const int sh = b0 & 31;
+        unsigned int anyrow = 0u, missing = 0u;                        // any non-empty row / any empty row among the tile's rows
+#pragma unroll
+        for (int it = 0; it < ZNIT; ++it) {
+            const unsigned long long two = ((unsigned long long)wp[it + 1] << 32) | wp[it];
+            unsigned int m = (unsigned int)(two >> sh);
+            // rows below padf are padding, rows from `rows` on do not exist
+            const int lo = padf - it * 32, hi = rows - it * 32;
+            unsigned int valid = ~0u;
+            if (lo > 0) valid &= lo >= 32 ? 0u : ~0u << lo;
+            if (hi < 32) valid &= hi <= 0 ? 0u : ~0u >> (32 - hi);
+            m &= valid;
+            rowbits[it] = m;
+            anyrow |= m;
+            missing |= m ^ valid;
+        }
+        if (anyrow == 0u) {
+            if (p.sum_partial && tid == 0) p.sum_partial[((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 0.0;
+            return;
+        }
+        // the same per z block of ZU = 16 outputs: block zb reads the staged rows [padf + 16 zb, padf + 16 zb + 16 + kz - 1) -- at most
+        // 79 rows from bit padf + 16 (zb & 1) of word zb / 2 on (static word indices: padf < 16) --; a block that reaches nothing but
+        // empty planes computes and stores nothing (pass D asks the dilated flags, which say the same)
+        static_assert(ZU == 16 && ZNIT * 32 >= 256 + 32, "z blocks of 16 outputs, two per word of plane bits");
+        const int len = ZU + p.kz - 1;
+        if (missing != 0u) zbmask = 0u;                               // (a tile without an empty row -- every tile of a dense volume -- skips this)
+#pragma unroll
+        for (int zb = 0; zb < 16 && missing != 0u; ++zb) {
+            const int w0 = zb / 2, off = padf + 16 * (zb & 1);
+            auto word = [&](int i) { return (w0 + i) < ZNIT ? rowbits[(w0 + i) < ZNIT ? (w0 + i) : 0] : 0u; };
+            const unsigned long long lo = ((unsigned long long)word(1) << 32) | word(0), hi = ((unsigned long long)word(3) << 32) | word(2);
+            // bits [off, off + len) of the 128-bit string hi:lo, len <= 79, off < 32
+            const unsigned long long a = (lo >> off) | (off ? hi << (64 - off) : 0ull);
+            const unsigned long long b = off ? hi >> off : hi;
+            const unsigned long long ma = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+            const unsigned long long mb = len > 64 ? ((1ull << (len - 64)) - 1ull) : 0ull;
+            if (((a & ma) | (b & mb)) != 0ull) zbmask |= 1u << zb;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < ZNIT; ++it) {
         const int r = (tid / ZLPR) + it * ZRPI;
         v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r >= padf && r < rows) {
+        if (r >= padf && r < rows && ((rowbits[it] >> (tid / ZLPR)) & 1u)) {
             int z = p.z_out0 + zc0 + (r - padf) - hl;
             if ((unsigned)z >= (unsigned)p.nz_global) z = mirror_index(z, p.nz_global);
             v[it] = *reinterpret_cast<const float4*>(p.src + (long long)(z - p.z_in0) * p.zs + scol + c2);
@@ -777,6 +893,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     const int nzb = (zn + ZU - 1) / ZU;
     double sre = 0.0, sim = 0.0;                          // this lane's sum over z of its line's outputs
     for (int zb = tid / NLZ; zb < nzb; zb += ZT / NLZ) {
+        if (!((zbmask >> zb) & 1u)) continue;
         const int z0 = zb * ZU;
         v2f acc[ZU];
 #pragma unroll
@@ -968,7 +1085,8 @@ static int launch_r2c_t(mvsim_ctx* ctx, const float* src, const SrcMap& map, flo
 
 template <class PLAN>
 static int launch_c2r_t(mvsim_ctx* ctx, const float2* srcc, float* out, const float2* tw, const float2* twx, int hxp,
-                        int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks, const C2RFuse* fuse)
+                        int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks, const C2RFuse* fuse,
+                        const C2REmpty& em = C2REmpty{})
 {
     using C = CfgX<PLAN::len>;
     const long long groups = (rows + C::NL - 1) / C::NL;
@@ -979,11 +1097,11 @@ static int launch_c2r_t(mvsim_ctx* ctx, const float2* srcc, float* out, const fl
         const size_t lds = C::LDS + 32 + (size_t)C::NW * sizeof(P1Scratch);
         MVSIM_TRY(set_lds(ctx, k_fft_x_c2r<PLAN, true>, lds));
         hipLaunchKernelGGL((k_fft_x_c2r<PLAN, true>), dim3((unsigned)blocks), dim3(C::T), lds, s, srcc, out, tw, twx, hxp, py, nx, ny,
-                           rows, scale, partial, *fuse);
+                           rows, scale, partial, *fuse, em);
     } else {
         MVSIM_TRY(set_lds(ctx, k_fft_x_c2r<PLAN, false>, C::LDS));
         hipLaunchKernelGGL((k_fft_x_c2r<PLAN, false>), dim3((unsigned)blocks), dim3(C::T), C::LDS, s, srcc, out, tw, twx, hxp, py, nx, ny,
-                           rows, scale, partial, C2RFuse{});
+                           rows, scale, partial, C2RFuse{}, em);
     }
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
@@ -1027,11 +1145,12 @@ static int launch_r2c(mvsim_ctx* s, int M, const float* src, const SrcMap& map, 
 }
 
 static int launch_c2r(mvsim_ctx* s, int M, const float2* srcc, float* out, const float2* tw, const float2* twx, int hxp,
-                      int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks, const C2RFuse* fuse)
+                      int py, int nx, int ny, long long rows, float scale, double* partial, int* nblocks, const C2RFuse* fuse,
+                        const C2REmpty& em = C2REmpty{})
 {
     switch (M) {
 #define X(LL, ...) \
-    case LL: return launch_c2r_t<Plan<LL, __VA_ARGS__>>(s, srcc, out, tw, twx, hxp, py, nx, ny, rows, scale, partial, nblocks, fuse);
+    case LL: return launch_c2r_t<Plan<LL, __VA_ARGS__>>(s, srcc, out, tw, twx, hxp, py, nx, ny, rows, scale, partial, nblocks, fuse, em);
         MVSIM_FFT_SIZES(X)
 #undef X
     }
@@ -1240,10 +1359,11 @@ bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[
 // separate kernels.  On success the context's spectrum buffer F holds what pass A would have written for `att`, and the
 // convolution is told so through ConvTail::x_done.
 int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, float* att_or_null, const int64_t dim[3],
-                          const int64_t kdim[3], const Affine& inv, double delta, bool* done)
+                          const int64_t kdim[3], const Affine& inv, double delta, bool* done, const int** plane_nz)
 {
     using namespace fft;
     *done = false;
+    if (plane_nz) *plane_nz = nullptr;
     if (ctx->opt.fused_fftx == 0) return MVSIM_OK;
     const bool x_identity = inv.m[0] == 1.0 && inv.m[1] == 0.0 && inv.m[2] == 0.0 && inv.m[3] == 0.0 &&
                             inv.m[4] == 0.0 && inv.m[8] == 0.0;
@@ -1278,6 +1398,26 @@ int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, f
     a.hxp = hxp; a.py = py;
     a.halo_r = kx / 2; a.halo_l = kx - 1 - kx / 2;
     a.a = inv; a.delta = delta;
+    // The flags cost a volume WITHOUT empty planes about 1.5 % of a view (a scalar load in front of every block's tile loads, the bit
+    // strings of the z pass): the last flagged view says how many planes were empty (a page-locked word the device writes, read here
+    // without waiting -- a hint, nothing depends on its being current), and while that was none only every sixteenth view carries
+    // flags, to notice when the data change.  Results are the same with and without flags.
+    bool want_flags = plane_nz && ctx->opt.skip_empty;
+    if (want_flags) {
+        if (!ctx->empty_hint) {
+            MVSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->empty_hint), sizeof(int), hipHostMallocDefault));
+            *ctx->empty_hint = -1;
+        }
+        const int hint = *reinterpret_cast<volatile int*>(ctx->empty_hint);
+        if (hint == 0 && ctx->views_since_flags < 15) { want_flags = false; ctx->views_since_flags += 1; }
+        else ctx->views_since_flags = 0;
+    }
+    if (want_flags) {
+        MVSIM_TRY(ctx->plane_flags.reserve((size_t)(3 * nz + 1024) * sizeof(int)));   // flags, the dilated flags, the flag bit string
+        MVSIM_HIP(hipMemsetAsync(ctx->plane_flags.p, 0, (size_t)nz * sizeof(int), ctx->stream));
+        a.plane_nz = ctx->plane_flags.as<int>();
+        *plane_nz = a.plane_nz;
+    }
     MVSIM_TRY(launch_rot_fftx(ctx, M, a, rot_or_null != nullptr || att_or_null != nullptr));
     *done = true;
     return MVSIM_OK;
@@ -1500,10 +1640,28 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             ev_end(ctx, ST_PASS_B);
         }
         float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
+        const int* em_flags = nullptr;                                // planes passes D and E skip (see pnz below)
         const int nzd = zdirect ? nzo : (int)dim[2];                  // planes z >= Nz are never read
         const int nk = (nzd - 1) / zstride + 1;                       // planes 0, zstride, 2 zstride, ...
         if (pcols > 0) Fz = G;
         else {
+        // planes the fused rotate kernel found empty: B skips them, C' does not load them and skips tiles made of nothing else, D and E
+        // skip the planes whose taps reach nothing but empty planes (exact: their spectra are zero) -- a specimen in empty space
+        const int* pnz = (tail && tail->x_done && tail->plane_nz && zdirect && !zinline && !is_slab && !fuse && !(tail->guest && tail->guest->valid))
+                             ? tail->plane_nz : nullptr;
+        const int* pnz_dil = nullptr;
+        const unsigned int* pnz_bits = nullptr;
+        if (pnz) {
+            // ctx->plane_flags = [flags (nz)][dilated (nz)][bit string (nwords)] (rotate_attenuate_fftx reserves all three)
+            int* base = ctx->plane_flags.as<int>();
+            const int nwords = ((int)dim[2] + 2 * NZ_EXT + 64 + 31) / 32 + ZNIT + 2;
+            hipLaunchKernelGGL(k_plane_flags_finish, dim3(1), dim3(1024), 0, s, pnz, (int)dim[2], kz, kz / 2,
+                               reinterpret_cast<unsigned int*>(base + 2 * dim[2]), nwords, base + dim[2], ctx->empty_hint);
+            MVSIM_HIP(hipGetLastError());
+            pnz_dil = base + dim[2];
+            pnz_bits = reinterpret_cast<const unsigned int*>(base + 2 * dim[2]);
+            b.nzflags = pnz; b.nz_stride = 1;
+        }
         // the previous view's extract + Poisson as guest waves: phase 1 beside pass B, the resolver beside pass D (option guest_tail)
         DeferredTail* guest = (tail && tail->guest && tail->guest->valid && zdirect && !is_slab && !fuse) ? tail->guest : nullptr;
         if (tail && tail->guest && tail->guest->valid && (!guest || !lines_can_host(py))) {
@@ -1577,6 +1735,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             z.taps_blk = (long long)kz * ZB * hxp;
             z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
             z.zc = zconv_chunk(nzo, kz);
+            z.nzbits = pnz_bits;
             const float scale_f = (float)(0.25 / ((double)px * (double)py));
             long long zblocks = 0;
             if (early) {
@@ -1611,9 +1770,12 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         b.src_outer = b.dst_outer = plane * zstride;
         b.dst_blk = 0;
         if (zdirect) { b.src = F; b.src_outer = (long long)ZB * hxp * zstride; b.src_blk = (long long)nzo * ZB * hxp; }
+        b.nzflags = nullptr;
+        if (pnz) { b.nzflags = pnz_dil; b.nz_stride = zstride; em_flags = pnz_dil; }
         ev_begin(ctx, ST_PASS_D);
         MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, nk));
         ev_end(ctx, ST_PASS_D);
+        b.nzflags = nullptr;
         if (guest) {
             if (guest_end < guest_trips) MVSIM_TRY(launch_poisson_phase1(s, guest_p1, gblocks, (int)guest_end, (int)guest_trips, guest_end > 0));
             // the resolver as a kernel of its own: its work items are dependent 32-byte reads, nothing a guest wave can wait for
@@ -1651,7 +1813,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         const float scale = (float)(0.25 / ((double)px * (double)py * ((zdirect && !zinline) ? 1.0 : (double)pz)));
         int nblk = 0;
         MVSIM_TRY(launch_c2r(ctx, M, Fz, out, tw_m, tw_px, hxp, py * zstride, (int)dim[0], (int)dim[1], (long long)dim[1] * nk, scale,
-                             ctx->partials_e.as<double>(), &nblk, fuse ? &fz : nullptr));
+                             ctx->partials_e.as<double>(), &nblk, fuse ? &fz : nullptr,
+                             C2REmpty{em_flags, zstride}));
         if (fuse && nblk != (int)fblocks) { set_error("fused tail: block count mismatch"); return MVSIM_EINVAL; }
         if (!early) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal, 1.0,
                                        corr_n, corr_min, corr_target);

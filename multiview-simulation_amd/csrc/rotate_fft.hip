@@ -122,6 +122,7 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
     };
 
     double n = 1.0;
+    unsigned int plane_any = 0u;                                  // this wave's columns: any non-zero attenuated value in the plane so far
     int buf = 0;
     int fill = 0;                                                 // batches waiting in the current round buffer (block-uniform)
     int ysub[G], nsub[G];                                         // first row (y) and row count of each of them
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
                 for (int u = 0; u < U; ++u)
                     if (__builtin_amdgcn_ballot_w64(active && (__float_as_uint(val[u]) << 1) != 0u) != 0ull) rowmask |= 1u << u;
                 if (lane == 0) wmask[(buf * G + fill) * 16 + wave] = rowmask;
+                plane_any |= rowmask;
             }
             float* __restrict__ rb = reinterpret_cast<float*>(rowbuf + ((size_t)buf * G + fill) * U * LP);
             ysub[fill] = y0;
@@ -325,6 +327,9 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
         }
         if (fill > 0) flush_round();                              // before the geometry table (and with it nothing the round needs) moves on
     }
+    // Planes that stay empty (a specimen in empty space: a third of the planes of the sphere phantom) need no convolution passes at
+    // all: their spectrum is exactly zero.  The passes skip what these flags call empty (custom_fft_convolve_slab, ConvTail::plane_nz).
+    if (p.plane_nz && lane == 0 && plane_any != 0u) p.plane_nz[z] = 1;
     // rows the reference never visits (Ny > Nx): the attenuated image stays zero there; rot still has its values
     for (int yy = ny - 1 - steps; yy >= 0; --yy) {
         if (WRITE_OUT && active) {

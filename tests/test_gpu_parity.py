@@ -1498,6 +1498,41 @@ def test_inline_fft_z_pass(mvs, orc, synth, shape, kshape):
     assert np.mean(a1["acq"] != b1["acq"]) < 5e-3                        # counts: only where 1e-6 of lambda crosses a decision
 
 
+@pytest.mark.parametrize("zrange,kshape,inc", [((100, 180), (31, 15, 15), 1), ((0, 40), (31, 15, 15), 3), ((230, 256), (63, 9, 9), 1),
+                                               ((0, 256), (15, 15, 15), 1), ((128, 129), (15, 31, 31), 4)])
+def test_empty_planes_are_skipped_exactly(mvs, synth, zrange, kshape, inc):
+    """Option skip_empty (default): the fused rotate kernel flags the planes that hold a non-zero attenuated voxel, pass B skips the
+    others, the z pass neither loads them nor computes z blocks that reach nothing else, passes D and E skip the planes whose taps reach
+    only empty planes -- their spectra are exactly zero.  A specimen that occupies a slab of z (at a face, in the middle, a single plane,
+    the whole volume), deep and shallow PSFs, compact planes: acquisition, adjusted volume and factor identical to skip_empty = 0."""
+    nx, ny, nz = 512, 512, 256                                          # 2^26 voxels: the fused kernel runs (rotation about x keeps z slabs thin)
+    rng = np.random.default_rng(9)
+    gt = np.zeros((nz, ny, nx), np.float32)
+    z0, z1 = zrange
+    gt[z0:z1, 200:312, 64:448] = rng.random((z1 - z0, 112, 384), dtype=np.float32)
+    psf = synth.gaussian_psf(kshape[2], kshape[1], kshape[0], sigma=(kshape[2] / 6, kshape[1] / 6, kshape[0] / 5))
+    out = {}
+    for skip in (0, 1):
+        with mvs.Context(0) as c:
+            c.set_option("skip_empty", skip)
+            c.set_option("fft_zpass", "direct")
+            d_gt = _dev_volume(c, gt)
+            nzo = (nz - 1) // inc + 1
+            d_acq, d_con, d_acq2 = c.dev_alloc(nx * ny * nzo * 4), c.dev_alloc(gt.nbytes), c.dev_alloc(nx * ny * nzo * 4)
+            try:
+                p = c.view_params(degrees=3, inc=inc, snr=25.0, seed=SEED, stream=1, conv_method=1)     # 3 degrees: the slab stays a slab
+                corr = c.simulate_view_dev(d_gt, (nx, ny, nz), psf.copy(), p, d_acq, con_dptr=d_con, want_corr=True)
+                c.simulate_view_dev(d_gt, (nx, ny, nz), psf.copy(), p, d_acq2)                         # compact planes when inc > 1
+                out[skip] = (corr, c.download(d_acq, (nzo, ny, nx)), c.download(d_con, gt.shape), c.download(d_acq2, (nzo, ny, nx)))
+            finally:
+                for d in (d_gt, d_acq, d_con, d_acq2):
+                    c.dev_free(d)
+    a, b = out[0], out[1]
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert a[1].max() > 0
+
+
 def test_coscheduling_options_keep_the_results(mvs, synth):
     """Round 4's ways of letting the sampler share the chip with the next view's convolution (profiles/r04_coschedule.txt):
     guest waves inside passes B and D (guest_tail, with the trips split several ways), the tail stream joined only in front of pass E

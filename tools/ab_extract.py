@@ -21,4 +21,4 @@ acc = {}
 for _ in range(16):
     ctx.simulate_view_dev(d_gt, (n, n, n), psf.copy(), p, d_acq)
 t = ctx.timings()
-print(os.path.basename(root) or root, (sys.argv[2] if len(sys.argv) > 2 else "phantom"), {k: round(v, 4) for k, v in t.items() if k in ("rotate_ms", "convolve_ms", "extract_ms", "total_ms")}, flush=True)
+print(os.path.basename(root) or root, (sys.argv[2] if len(sys.argv) > 2 else "phantom"), {k: round(v, 4) for k, v in t.items() if k in ("rotate_ms", "convolve_ms", "extract_ms", "total_ms", "pass_b_ms", "pass_c_ms", "pass_d_ms", "pass_e_ms")}, flush=True)
