@@ -662,26 +662,41 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
 __global__ __launch_bounds__(1024) void k_plane_flags_finish(const int* __restrict__ flags, int n, int kz, int c, unsigned int* __restrict__ bits,
                                                              int nwords, int* __restrict__ dil, int* __restrict__ empty_hint)
 {
+    // the flags once through LDS (volumes of up to 16384 planes; beyond that straight from memory): every thread then reads up to 64 of them
+    __shared__ unsigned char sf[16384];
+    __shared__ int cnt;
     const int t = threadIdx.x;
-    if (empty_hint) {
-        // how many planes are empty: a hint for the host (page-locked), see rotate_attenuate_fftx
-        __shared__ int cnt;
-        if (t == 0) cnt = 0;
-        __syncthreads();
-        int mine = 0;
-        for (int z = t; z < n; z += 1024) mine += flags[z] == 0;
-        if (mine) atomicAdd(&cnt, mine);
-        __syncthreads();
-        if (t == 0) *empty_hint = cnt;
+    const bool in_lds = n <= 16384;
+    if (t == 0) cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int z = t; z < n; z += 1024) {
+        const int f = flags[z] != 0;
+        if (in_lds) sf[z] = (unsigned char)f;
+        mine += !f;
     }
-    for (int w = t; w < nwords; w += 1024) {
-        unsigned int m = 0u;
-        for (int k = 0; k < 32; ++k) m |= (flags[mirror_index(w * 32 + k - NZ_EXT, n)] != 0 ? 1u : 0u) << k;
-        bits[w] = m;
+    if (mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (t == 0 && empty_hint) *empty_hint = cnt;          // how many planes are empty: a hint for the host (page-locked), see rotate_attenuate_fftx
+    auto flag = [&](int z) { return in_lds ? (int)sf[z] : (flags[z] != 0 ? 1 : 0); };
+    // (one reflection covers every index asked for here unless the PSF is deeper than the volume: the general form only then)
+    auto mir = [&](int i) {
+        int j = i < 0 ? -i : i;
+        if (j >= n) j = 2 * n - 2 - j;
+        return (j >= 0 && j < n) ? j : mirror_index(i, n);
+    };
+    // one bit per lane, 64 bits per ballot: two words of the bit string per wave and trip
+    for (int i0 = 0; i0 < nwords * 32; i0 += 1024) {
+        const int i = i0 + t;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(i < nwords * 32 && flag(mir(i - NZ_EXT)) != 0);
+        if ((t & 63) == 0) {
+            if (i / 32 < nwords) bits[i / 32] = (unsigned int)m;
+            if (i / 32 + 1 < nwords) bits[i / 32 + 1] = (unsigned int)(m >> 32);
+        }
     }
     for (int z = t; z < n; z += 1024) {
         int any = 0;
-        for (int tt = 0; tt < kz && !any; ++tt) any = flags[mirror_index(z + c - tt, n)] != 0;
+        for (int tt = 0; tt < kz; ++tt) any |= flag(mir(z + c - tt));
         dil[z] = any;
     }
 }
@@ -1414,7 +1429,6 @@ int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, f
     }
     if (want_flags) {
         MVSIM_TRY(ctx->plane_flags.reserve((size_t)(3 * nz + 1024) * sizeof(int)));   // flags, the dilated flags, the flag bit string
-        MVSIM_HIP(hipMemsetAsync(ctx->plane_flags.p, 0, (size_t)nz * sizeof(int), ctx->stream));
         a.plane_nz = ctx->plane_flags.as<int>();
         *plane_nz = a.plane_nz;
     }

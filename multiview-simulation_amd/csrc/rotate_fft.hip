@@ -329,7 +329,16 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
     }
     // Planes that stay empty (a specimen in empty space: a third of the planes of the sphere phantom) need no convolution passes at
     // all: their spectrum is exactly zero.  The passes skip what these flags call empty (custom_fft_convolve_slab, ConvTail::plane_nz).
-    if (p.plane_nz && lane == 0 && plane_any != 0u) p.plane_nz[z] = 1;
+    // (every block writes its plane's flag, 0 or 1: nothing has to be cleared beforehand)
+    if (p.plane_nz) {
+        unsigned int* blk_any = wmask + 2 * G * 16;
+        __syncthreads();                                          // (also: every round's readers of wmask are done)
+        if (x == 0) *blk_any = 0u;
+        __syncthreads();
+        if (lane == 0 && plane_any != 0u) atomicOr(blk_any, 1u);
+        __syncthreads();
+        if (x == 0) p.plane_nz[z] = (int)*blk_any;
+    }
     // rows the reference never visits (Ny > Nx): the attenuated image stays zero there; rot still has its values
     for (int yy = ny - 1 - steps; yy >= 0; --yy) {
         if (WRITE_OUT && active) {
@@ -368,7 +377,7 @@ static int launch_rot_fftx_t(mvsim_ctx* ctx, const RotFftArgs& a, bool write_out
     const int waves = (a.nx + 63) / 64;
     const int G = waves > 8 ? 2 : 1;
     const size_t lds = (size_t)(2 * G * UF * (M + 1) + M + (M & 1)) * sizeof(float2) + (size_t)geo_chunk_f(G) * sizeof(RowGeoF) +
-                       (size_t)(geo_chunk_f(G) / UF) * sizeof(int) + (size_t)(2 * G * 16) * sizeof(unsigned int);
+                       (size_t)(geo_chunk_f(G) / UF) * sizeof(int) + (size_t)(2 * G * 16 + 4) * sizeof(unsigned int);
     if (lds > 160 * 1024) { set_error("fused rotate + x transform: %zu bytes of LDS", lds); return MVSIM_EINVAL; }
     dim3 grid((unsigned)((a.nz + 7) / 8 * 8)), block((unsigned)(waves * 64));
 #define MVSIM_RF(W_, G_)                                                                                            \
