@@ -829,7 +829,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     // read -- pass B has not written them --, and a tile without a single non-empty row has nothing to compute or store.
     static_assert(ZRPI == 32, "one word of plane bits per staging iteration");
     unsigned int rowbits[ZNIT];
-    unsigned int zbmask = 0xFFFFu;                                   // z blocks of this tile that have anything to compute
+    unsigned int zbmask = 0xFFFFFFFFu;                               // z blocks of this tile that have anything to compute (up to ZNIT * 2 = 18)
 #pragma unroll
     for (int it = 0; it < ZNIT; ++it) rowbits[it] = 0xFFFFFFFFu;
     if (p.nzbits) {
@@ -858,11 +858,11 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
         // the same per z block of ZU = 16 outputs: block zb reads the staged rows [padf + 16 zb, padf + 16 zb + 16 + kz - 1) -- at most
         // 79 rows from bit padf + 16 (zb & 1) of word zb / 2 on (static word indices: padf < 16) --; a block that reaches nothing but
         // empty planes computes and stores nothing (pass D asks the dilated flags, which say the same)
-        static_assert(ZU == 16 && ZNIT * 32 >= 256 + 32, "z blocks of 16 outputs, two per word of plane bits");
+        static_assert(ZU == 16 && ZNIT * 2 <= 32, "z blocks of 16 outputs, two per word of plane bits");
         const int len = ZU + p.kz - 1;
         if (missing != 0u) zbmask = 0u;                               // (a tile without an empty row -- every tile of a dense volume -- skips this)
 #pragma unroll
-        for (int zb = 0; zb < 16 && missing != 0u; ++zb) {
+        for (int zb = 0; zb < ZNIT * 2 && missing != 0u; ++zb) {
             const int w0 = zb / 2, off = padf + 16 * (zb & 1);
             auto word = [&](int i) { return (w0 + i) < ZNIT ? rowbits[(w0 + i) < ZNIT ? (w0 + i) : 0] : 0u; };
             const unsigned long long lo = ((unsigned long long)word(1) << 32) | word(0), hi = ((unsigned long long)word(3) << 32) | word(2);
