@@ -54,6 +54,8 @@ int parse_option(Options& o, const char* name, const char* value)
         return MVSIM_OK;
     }
     if (n == "early_sum") return flag(&o.early_sum);
+    if (n == "zconv_strided") return flag(&o.zconv_strided);
+    if (n == "exp") { o.exp = atoi(v.c_str()); return MVSIM_OK; }
     if (n == "fuse_tail") return flag(&o.fuse_tail);
     if (n == "psf_overlap") return flag(&o.psf_overlap);
     if (n == "fused_fftx") {
@@ -964,8 +966,8 @@ static std::string view_graph_key(mvsim_ctx* ctx, const float* gt, const int64_t
     add(&o->rot, sizeof(o->rot)); add(&o->att, sizeof(o->att)); add(&o->con, sizeof(o->con)); add(&o->acq, sizeof(o->acq));
     add(&ctx->stream, sizeof(ctx->stream));
     const Options& q = ctx->opt;
-    const int oo[9] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, q.psf_overlap ? 1 : 0,
-                       q.attenuate_scan ? 1 : 0, q.fused_fftx};
+    const int oo[10] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, q.psf_overlap ? 1 : 0,
+                        q.attenuate_scan ? 1 : 0, q.fused_fftx, q.zconv_strided ? 1 : 0};
     add(oo, sizeof(oo));
     add(q.fft_pad, sizeof(q.fft_pad));
     return k;

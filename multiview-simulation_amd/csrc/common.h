@@ -114,6 +114,11 @@ struct Options {
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
                                        // resolver, production), 0: one kernel
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
+    int     exp = 0;                   // experiment bits for A/B runs on one box (tools/): 1 = z pass tiles in plain grid order, 2 = k_zconv_strided wherever its
+                                       // geometry allows (without the cost rule of zconv_strided_chunk)
+    bool    zconv_strided = true;      // views that only return the acquisition (compact planes, inc > 1): the direct z pass computes the
+                                       // planes k * inc alone (k_zconv_strided: 1 / inc of the taps' work) and takes adjustImage's sum from
+                                       // its INPUT rows (the sum over all planes is a linear functional of them); 0: every plane, as round 3
     bool    psf_overlap = true;        // PSF spectrum on the context's side stream, concurrent with passes A and B (views of
                                        // >= 2^24 voxels; +1 % views/s at 512^3).  On by default since round 3 (bit-identical, tested);
                                        // overlapped kernels share the chip, so their own durations in a profile no longer add up to

@@ -791,7 +791,28 @@ struct ZConvArgs {
     // bit i = plane mirror(i - NZ_EXT) is non-empty: the flags as a bit string that already holds the mirrored halo on both sides, so
     // that the planes a tile reaches are ONE run of bits (k_plane_flags_finish); null: every plane is read
     const unsigned int* nzbits;
+    // k_zconv_strided only: outputs are the planes k * stride (the compact planes extractSlices reads); LDS rows reserved for the tile
+    int           stride, frows;
+    // tiles: nch chunks along z x nkxb groups of NLZ columns x py rows, on a 1-D grid (zconv_tile)
+    int           nch, nkxb, py, plain_order;
 };
+
+// Which tile a block of the z pass works on.  Workgroups go to the eight XCDs round robin by their linear id, and the chunks of one
+// column group share their halo rows and all of their taps: with the chunk index fastest in the GRID, neighbours landed on different
+// XCDs and both fetched those rows into their own L2 (k_zconv read 0.60 GB where pass B had written 0.48: profiles/r04_g_pmc_hbm_traffic.txt).
+// So every XCD walks a contiguous range of the tile order (chunk fastest, then column group, then ky) instead.
+__device__ __forceinline__ bool zconv_tile(const ZConvArgs& p, int& chunk, int& kxb, int& ky, long long& tile)
+{
+    const long long total = (long long)p.nch * p.nkxb * p.py, per = (total + 7) / 8;
+    const long long l = blockIdx.x;
+    tile = p.plain_order ? l : (l & 7) * per + (l >> 3);
+    if (tile >= total) return false;
+    chunk = (int)(tile % p.nch);
+    const long long col = tile / p.nch;
+    kxb = (int)(col % p.nkxb);
+    ky = (int)(col / p.nkxb);
+    return true;
+}
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -810,14 +831,16 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     extern __shared__ __align__(16) float2 lds[];
     const int kzp = (p.kz + ZJ - 1) / ZJ * ZJ;            // taps padded with zeros to whole chunks
     const int padf = kzp - p.kz;                          // leading zero rows the padded taps may touch
-    const int zc0 = (int)blockIdx.x * p.zc;
+    int chunk, kxb, ky;
+    long long tile;
+    if (!zconv_tile(p, chunk, kxb, ky, tile)) return;
+    const int zc0 = chunk * p.zc;
     const int zn = min(p.zc, p.nz - zc0);                 // outputs of this block
     const int rows = padf + zn + p.kz - 1;                // staged input rows
     float2* f = lds;                                      // [rows][ZPITCH]
     float2* g = lds + zconv_frows(p.zc, p.kz, kzp);      // [kzp][NLZ]
     const int tid = threadIdx.x;
-    const int ky = (int)blockIdx.z;
-    const long long rowb = (long long)(ky & (ZB - 1)) * p.hxp + (long long)blockIdx.y * NLZ;
+    const long long rowb = (long long)(ky & (ZB - 1)) * p.hxp + (long long)kxb * NLZ;
     const long long scol = (long long)(ky >> ZBS) * p.src_blk + rowb, dcol = (long long)(ky >> ZBS) * p.dst_blk + rowb;
     const long long tcol = (long long)(ky >> ZBS) * p.taps_blk + rowb;
     const int c2 = (tid % ZLPR) * 2;                      // staging: ZLPR lanes x 16 B per row
@@ -852,7 +875,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
             missing |= m ^ valid;
         }
         if (anyrow == 0u) {
-            if (p.sum_partial && tid == 0) p.sum_partial[((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 0.0;
+            if (p.sum_partial && tid == 0) p.sum_partial[tile] = 0.0;
             return;
         }
         // the same per z block of ZU = 16 outputs: block zb reads the staged rows [padf + 16 zb, padf + 16 zb + 16 + kz - 1) -- at most
@@ -972,7 +995,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     }
     if (p.sum_partial) {
         __shared__ double red[ZT / 64];
-        const double2 a = p.wx[(int)blockIdx.y * NLZ + line], b = p.wy[blockIdx.z];
+        const double2 a = p.wx[kxb * NLZ + line], b = p.wy[ky];
         const double wr = a.x * b.x - a.y * b.y, wi = a.x * b.y + a.y * b.x;
         double t = sre * wr - sim * wi;                   // Re( s * W )
 #pragma unroll
@@ -982,7 +1005,227 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
         if (tid == 0) {
             double sum = 0.0;
             for (int w = 0; w < ZT / 64; ++w) sum += red[w];
-            p.sum_partial[((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sum;
+            p.sum_partial[tile] = sum;
+        }
+    }
+}
+
+// The z pass of a view that only returns the acquisition (compact planes, inc = S > 1): passes D and E read the planes k * S alone, so
+// only those are convolved -- 1 / S of the taps' work of k_zconv, which at Kz = 63 is what bounds it (configs[3]: 1024^3, inc 4) -- and
+// adjustImage's sum, which is over EVERY plane of the convolved volume, is taken from the tile's input rows instead of its outputs:
+//   SUM_{z in tile} out[z] = SUM_r f[r] * W[r],  W[r] = SUM of the taps t with a_t <= r < a_t + zn  (a_t = padf + Kz - 1 - t),
+// a difference of two prefix sums of the line's taps (interior rows: the sum of all taps); one complex product per staged row, in fp64.
+// Same tile, same staging (empty planes included) as k_zconv.  The outputs in polyphase form: plane z0 + S k needs the rows
+// padf + Kz - 1 - rho + S (k - q) for the taps t = S q + rho -- per phase rho a stride-1 convolution of every S-th row with every S-th tap.
+// Work unit = (phase, chunk of ZJ taps of that phase); the four 16-lane groups of a wave take the units round robin on the SAME 16
+// outputs per lane (register window of ZU + ZJ - 1 rows S apart: 8 packed FMAs per LDS word, as in k_zconv) and add up their partial
+// sums over the lane crossbar (reduce-scatter: xor 32, xor 16), each group storing a quarter of the wave's outputs.  The waves share a
+// trip's (up to) 64 outputs evenly.  The summation order differs from k_zconv's tap-by-tap order: ~1e-7 of the range
+// (test_compact_planes_view_equals_full_view; option zconv_strided=0 keeps the planes of a compact view bit-identical to a full one).
+// LDS rows are NLZ float2 apart here (no padding): the groups of a half wave read rows an odd distance apart -> other 32 banks.
+// a + b after v_permlane32_swap (W = 32: the upper 32 lanes of a against the lower 32 of b) or v_permlane16_swap (W = 16: the odd rows
+// of 16 lanes of a against the even rows of b).  (Scalars first: __builtin_bit_cast on an element of an ext_vector reads element 0.)
+template <int W> __device__ __forceinline__ v2f swap_add(v2f a, v2f b)
+{
+    const float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+    const auto x = W == 32 ? __builtin_amdgcn_permlane32_swap(__float_as_uint(ax), __float_as_uint(bx), false, false)
+                           : __builtin_amdgcn_permlane16_swap(__float_as_uint(ax), __float_as_uint(bx), false, false);
+    const auto y = W == 32 ? __builtin_amdgcn_permlane32_swap(__float_as_uint(ay), __float_as_uint(by), false, false)
+                           : __builtin_amdgcn_permlane16_swap(__float_as_uint(ay), __float_as_uint(by), false, false);
+    const unsigned int x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+    return v2f{__uint_as_float(x0), __uint_as_float(y0)} + v2f{__uint_as_float(x1), __uint_as_float(y1)};
+}
+
+template <int S>
+__global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv_strided(ZConvArgs p)
+{
+    extern __shared__ __align__(16) float2 lds[];
+    constexpr int PITCH = NLZ;
+    const int nq = (p.kz + S - 1) / S;                    // taps of phase 0 (the longest)
+    const int qp = (nq + ZJ - 1) / ZJ * ZJ;               // ... padded to whole chunks
+    const int gr = S * qp;                                // tap rows (zero from Kz on)
+    const int padf = gr - p.kz;                           // leading zero rows the padded taps may touch
+    int chunk, kxb, ky;
+    long long tile;
+    if (!zconv_tile(p, chunk, kxb, ky, tile)) return;
+    const int zc0 = chunk * p.zc;
+    const int zn = min(p.zc, p.nz - zc0);                 // planes of this tile (outputs: every S-th, from the tile's first)
+    const int rows = padf + zn + p.kz - 1;                // staged input rows
+    float2* f = lds;                                      // [frows][PITCH]
+    float2* g = lds + (size_t)p.frows * PITCH;            // [gr][NLZ]
+    float2* gc = g + (size_t)gr * NLZ;                    // [Kz + 1][NLZ] exclusive prefix sums of the taps; [16][NLZ] segment totals behind
+    const int tid = threadIdx.x;
+    const long long rowb = (long long)(ky & (ZB - 1)) * p.hxp + (long long)kxb * NLZ;
+    const long long scol = (long long)(ky >> ZBS) * p.src_blk + rowb, dcol = (long long)(ky >> ZBS) * p.dst_blk + rowb;
+    const long long tcol = (long long)(ky >> ZBS) * p.taps_blk + rowb;
+    const int c2 = (tid % ZLPR) * 2;
+    const int hl = p.kz - 1 - p.c;
+    float4 v[ZNIT], tv[TNIT];
+    static_assert(ZRPI == 32, "one word of plane bits per staging iteration");
+    unsigned int rowbits[ZNIT];
+#pragma unroll
+    for (int it = 0; it < ZNIT; ++it) rowbits[it] = 0xFFFFFFFFu;
+    if (p.nzbits) {
+        const int b0 = p.z_out0 + zc0 - hl + NZ_EXT - padf;           // bit of staged row 0 (>= 0: the host checks hl + padf <= NZ_EXT)
+        const unsigned int* __restrict__ wp = p.nzbits + (b0 >> 5);
+        const int sh = b0 & 31;
+        unsigned int anyrow = 0u;
+#pragma unroll
+        for (int it = 0; it < ZNIT; ++it) {
+            const unsigned long long two = ((unsigned long long)wp[it + 1] << 32) | wp[it];
+            unsigned int m = (unsigned int)(two >> sh);
+            const int lo = padf - it * 32, hi = rows - it * 32;
+            unsigned int valid = ~0u;
+            if (lo > 0) valid &= lo >= 32 ? 0u : ~0u << lo;
+            if (hi < 32) valid &= hi <= 0 ? 0u : ~0u >> (32 - hi);
+            m &= valid;
+            rowbits[it] = m;
+            anyrow |= m;
+        }
+        if (anyrow == 0u) {
+            if (p.sum_partial && tid == 0) p.sum_partial[tile] = 0.0;
+            return;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ZNIT; ++it) {
+        const int r = (tid / ZLPR) + it * ZRPI;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= padf && r < rows && ((rowbits[it] >> (tid / ZLPR)) & 1u)) {
+            int z = p.z_out0 + zc0 + (r - padf) - hl;
+            if ((unsigned)z >= (unsigned)p.nz_global) z = mirror_index(z, p.nz_global);
+            v[it] = *reinterpret_cast<const float4*>(p.src + (long long)(z - p.z_in0) * p.zs + scol + c2);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < TNIT; ++it) {
+        const int r = (tid / ZLPR) + it * ZRPI;
+        tv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < p.kz) tv[it] = *reinterpret_cast<const float4*>(p.taps + (long long)r * p.zs + tcol + c2);
+    }
+#pragma unroll
+    for (int it = 0; it < ZNIT; ++it) {
+        const int r = (tid / ZLPR) + it * ZRPI;
+        if (r < rows) *reinterpret_cast<float4*>(f + r * PITCH + c2) = v[it];
+    }
+#pragma unroll
+    for (int it = 0; it < TNIT; ++it) {
+        const int r = (tid / ZLPR) + it * ZRPI;
+        if (r < gr) *reinterpret_cast<float4*>(g + r * NLZ + c2) = tv[it];
+    }
+    for (int r = TNIT * ZRPI + tid / ZLPR; r < gr; r += ZRPI) *reinterpret_cast<float4*>(g + r * NLZ + c2) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int line = lane & (NLZ - 1), grp = lane >> 4;
+    if (p.sum_partial) {
+        // exclusive prefix sums of every line's taps, gc[t] = g[0] + .. + g[t - 1] (t <= Kz): a thread per (line, four taps), the
+        // sixteen segments' totals through LDS
+        static_assert(ZT / NLZ == 16 && TNIT * ZRPI <= 64, "sixteen segments of four taps cover Kz <= 64");
+        const int ln = tid & (NLZ - 1), seg = tid >> 4;
+        float2* tot = gc + (size_t)(p.kz + 1) * NLZ;
+        v2f loc[4], run = v2f{0.f, 0.f}, last = v2f{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = 4 * seg + i;
+            loc[i] = run;
+            if (t < p.kz) { const float2 x = g[t * NLZ + ln]; last = v2f{x.x, x.y}; run += last; }
+        }
+        tot[seg * NLZ + ln] = make_float2(run.x, run.y);
+        __syncthreads();
+        v2f off = v2f{0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < ZT / NLZ - 1; ++q) {
+            const float2 x = tot[q * NLZ + ln];
+            if (q < seg) off += v2f{x.x, x.y};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = 4 * seg + i;
+            const v2f e = loc[i] + off;
+            if (t < p.kz) gc[t * NLZ + ln] = make_float2(e.x, e.y);
+            if (t == p.kz - 1) { const v2f all = e + last; gc[p.kz * NLZ + ln] = make_float2(all.x, all.y); }
+        }
+    }
+    const int nout = (zn + S - 1) / S;                    // outputs of the tile: planes zc0 + S k
+    const int nunits = S * (qp / ZJ);                     // unit i: phase i % S, taps S (q0 + t) + phase with q0 = (i / S) * ZJ
+    for (int kb = 0; kb < nout; kb += 64) {
+        const int nt = min(64, nout - kb), zu = (nt + 3) >> 2;   // this trip's outputs, dealt evenly over the four waves
+        const int k0 = kb + wave * zu, kend = min(k0 + zu, kb + nt);
+        if (k0 >= kend) continue;
+        v2f acc[ZU];
+#pragma unroll
+        for (int u = 0; u < ZU; ++u) acc[u] = v2f{0.f, 0.f};
+#pragma unroll 1
+        for (int i = grp; i < nunits; i += 4) {
+            const int rho = i % S, q0 = (i / S) * ZJ;
+            // output u, tap q0 + t reads row base + S (u - t); base - S (ZJ - 1) >= 0 (padf), rows beyond the staged ones (outputs past
+            // kend) lie inside the reserved region (p.frows) and feed nothing that is stored
+            const int base = padf + p.kz - 1 - rho + S * (k0 - q0);
+            const float2* __restrict__ fw = f + (base - S * (ZJ - 1)) * PITCH + line;
+            const float2* __restrict__ gw = g + (S * q0 + rho) * NLZ + line;
+            float2 w[ZU + ZJ - 1], gg[ZJ];
+#pragma unroll
+            for (int j = 0; j < ZU + ZJ - 1; ++j) w[j] = fw[j * S * PITCH];
+#pragma unroll
+            for (int t = 0; t < ZJ; ++t) gg[t] = gw[t * S * NLZ];
+#pragma unroll
+            for (int t = 0; t < ZJ; ++t) {
+#pragma unroll
+                for (int u = 0; u < ZU; ++u) {
+                    const float2 x = w[u - t + ZJ - 1];
+                    acc[u] = __builtin_elementwise_fma(v2f{gg[t].x, gg[t].x}, v2f{x.x, x.y}, acc[u]);
+                    acc[u] = __builtin_elementwise_fma(v2f{-gg[t].y, gg[t].y}, v2f{x.y, x.x}, acc[u]);
+                }
+            }
+        }
+        // reduce-scatter over the four groups: group g ends up with the outputs 4 g .. 4 g + 3 of the wave.  v_permlane32_swap
+        // exchanges the upper half of one register with the lower half of another, so a = acc[u], b = acc[8 + u] become (own a | b of
+        // lane - 32) and (a of lane + 32 | own b): their sum is what the lower lanes keep of u and the upper lanes of 8 + u.
+        // v_permlane16_swap does the same with the odd / even rows of 16 lanes.
+        static_assert(ZU == 16, "four groups x four outputs");
+        v2f h8[8], h4[4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) h8[u] = swap_add<32>(acc[u], acc[8 + u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) h4[u] = swap_add<16>(h8[u], h8[4 + u]);
+        float2* d = p.dst + (long long)(zc0 + S * (k0 + 4 * grp)) * p.zs + dcol + line;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + 4 * grp + u < kend) *d = make_float2(h4[u].x, h4[u].y);
+            d += p.zs * S;
+        }
+    }
+    if (p.sum_partial) {
+        __shared__ double red[ZT / 64];
+        __syncthreads();                                  // the taps' prefix sums (wave 0)
+            // a thread's <= 18 rows in single precision (as k_zconv adds its 16 outputs), then double; every row the same three LDS reads
+        // (rows that every tap reaches weigh gc[Kz] - gc[0]), unrolled so that they are all in flight together
+        const int ln = tid & (NLZ - 1);
+        v2f s2 = v2f{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < ZNIT * ZRPI / (ZT / NLZ); ++i) {
+            const int r = padf + (tid >> 4) + i * (ZT / NLZ);
+            const bool in = r < rows;
+            const int tlo = in ? max(0, padf + p.kz - 1 - r) : 0, thi = in ? min(p.kz, padf + p.kz - 1 + zn - r) : 0;   // taps [tlo, thi)
+            float2 x = make_float2(0.f, 0.f);
+            if (in) x = f[r * PITCH + ln];
+            const float2 a = gc[thi * NLZ + ln], b = gc[tlo * NLZ + ln];
+            const float wr = a.x - b.x, wi = a.y - b.y;
+            s2 = __builtin_elementwise_fma(v2f{wr, wr}, v2f{x.x, x.y}, s2);
+            s2 = __builtin_elementwise_fma(v2f{-wi, wi}, v2f{x.y, x.x}, s2);
+        }
+        const double sre = (double)s2.x, sim = (double)s2.y;
+        const double2 a = p.wx[kxb * NLZ + (tid & (NLZ - 1))], b = p.wy[ky];
+        const double wr = a.x * b.x - a.y * b.y, wi = a.x * b.y + a.y * b.x;
+        double t = sre * wr - sim * wi;                   // Re( s * W )
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = t;
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int w = 0; w < ZT / 64; ++w) sum += red[w];
+            p.sum_partial[tile] = sum;
         }
     }
 }
@@ -1034,13 +1277,77 @@ static long long zconv_blocks(const ZConvArgs& a, int py, int cols = 0)
 }
 
 // cols > 0: only that many kx columns from the column the pointers of `a` start at (a kx panel)
-static int launch_zconv(mvsim_ctx* ctx, const ZConvArgs& a, int py, int cols = 0)
+static dim3 zconv_grid(ZConvArgs& a, int py, int cols, int env_exp)
+{
+    a.nch = (a.nz + a.zc - 1) / a.zc; a.nkxb = (cols > 0 ? cols : a.hxp) / NLZ; a.py = py;
+    a.plain_order = (env_exp & 1) ? 1 : 0;
+    const long long total = (long long)a.nch * a.nkxb * a.py;
+    return dim3((unsigned)((total + 7) / 8 * 8));
+}
+
+static int launch_zconv(mvsim_ctx* ctx, const ZConvArgs& args, int py, int cols = 0)
 {
     hipStream_t s = ctx->stream;
+    ZConvArgs a = args;
     const size_t lds = zconv_lds(a.zc, a.kz);
-    dim3 grid((a.nz + a.zc - 1) / a.zc, (cols > 0 ? cols : a.hxp) / NLZ, py);
+    const dim3 grid = zconv_grid(a, py, cols, ctx->opt.exp);
     MVSIM_TRY(set_lds(ctx, k_zconv, lds));
     hipLaunchKernelGGL(k_zconv, grid, dim3(ZT), lds, s, a);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// k_zconv_strided: planes per tile (a multiple of the stride; 0: this geometry keeps k_zconv), the LDS rows to reserve and the bytes
+#ifndef MVSIM_ZLDS_S
+#define MVSIM_ZLDS_S (52 * 1024)
+#endif
+static int zconv_strided_chunk(int nz, int kz, int s, bool force, int* frows_out, size_t* lds_out)
+{
+    if (s < 2 || s > 4 || kz > 64) return 0;
+    const int nq = (kz + s - 1) / s, qp = (nq + ZJ - 1) / ZJ * ZJ, gr = s * qp, padf = gr - kz;
+    if (kz - 1 - kz / 2 + padf > NZ_EXT) return 0;       // the flag bit string holds that many planes in front of plane 0
+    auto geometry = [&](int zc, int* frows, size_t* lds) {
+        // the last output a lane computes (not stores): trips of 64 outputs, four waves with zu each, 16 per lane
+        const int nout = (zc + s - 1) / s;
+        int kmax = 0;
+        for (int kb = 0; kb < nout; kb += 64) {
+            const int nt = std::min(64, nout - kb), zu = (nt + 3) / 4;
+            kmax = std::max(kmax, kb + 3 * zu + ZU - 1);
+        }
+        const int staged = padf + zc + kz - 1;
+        *frows = std::max(staged, padf + kz - 1 + s * kmax + 1);
+        *lds = ((size_t)*frows * NLZ + (size_t)gr * NLZ + (size_t)(kz + 1 + ZT / NLZ) * NLZ) * sizeof(float2);
+        return staged;
+    };
+    int zc = (nz + s - 1) / s * s, frows = 0;
+    size_t lds = 0;
+    while (zc > s && (geometry(zc, &frows, &lds) > ZNIT * ZRPI || lds > (size_t)MVSIM_ZLDS_S)) zc -= s;
+    if (geometry(zc, &frows, &lds) > ZNIT * ZRPI || lds > (size_t)MVSIM_ZLDS_S) return 0;
+    const int nchunks = (nz + zc - 1) / zc;
+    // Both kernels take about the same time per TILE whatever the tile holds (memory latency and the fixed phases: ~15.5 ns here, 13 ns
+    // + 0.17 ns per tap in k_zconv, over the sizes of profiles/r04_zstrided.txt); the padded tap rows of this kernel cost LDS rows, so a
+    // volume can need more chunks here (512 planes, 31 taps, stride 3: three instead of two) -- then the plain kernel is the faster one.
+    if (!force) {
+        const int zc1 = zconv_chunk(nz, kz), nch1 = (nz + zc1 - 1) / zc1;
+        if (nchunks * 15.5 >= nch1 * (13.0 + 0.17 * kz)) return 0;
+    }
+    const int even = ((nz + nchunks - 1) / nchunks + s - 1) / s * s;
+    if (even < zc) { zc = even; geometry(zc, &frows, &lds); }
+    *frows_out = frows; *lds_out = lds;
+    return zc;
+}
+
+static int launch_zconv_strided(mvsim_ctx* ctx, const ZConvArgs& args, int py, size_t lds)
+{
+    hipStream_t s = ctx->stream;
+    ZConvArgs a = args;
+    const dim3 grid = zconv_grid(a, py, 0, ctx->opt.exp);
+    switch (a.stride) {
+    case 2: MVSIM_TRY(set_lds(ctx, k_zconv_strided<2>, lds)); hipLaunchKernelGGL(k_zconv_strided<2>, grid, dim3(ZT), lds, s, a); break;
+    case 3: MVSIM_TRY(set_lds(ctx, k_zconv_strided<3>, lds)); hipLaunchKernelGGL(k_zconv_strided<3>, grid, dim3(ZT), lds, s, a); break;
+    case 4: MVSIM_TRY(set_lds(ctx, k_zconv_strided<4>, lds)); hipLaunchKernelGGL(k_zconv_strided<4>, grid, dim3(ZT), lds, s, a); break;
+    default: set_error("k_zconv_strided: stride %d", a.stride); return MVSIM_EINVAL;
+    }
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
@@ -1497,7 +1804,12 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     // lines, 128-byte rows) -- pass C 8.1 ms whatever Kz against 8.1 / 9.0 / 10.2 ms for the direct form at Kz = 41 / 51 / 63; 1024^3
     // (length 1120: tiles of 8 lines, 64-byte rows, one line per wave) -- 5.6 ms against 3.9 / 4.4 / 4.9 ms.  Hence auto = deep PSFs on
     // z lengths of 512 .. 576 (the sizes measured to win); everything else keeps the direct form unless asked.
-    const bool zinline = zdirect && !is_slab &&
+    // compact planes: the direct form computes 1 / zstride of the planes (k_zconv_strided) and is then ahead of the inline FFT at every depth
+    int zs_frows = 0;
+    size_t zs_lds = 0;
+    const int zs_chunk = (zdirect && zstride > 1 && ctx->opt.zconv_strided && ctx->opt.zpass != 3 && ctx->opt.kx_panel == 0)
+                             ? zconv_strided_chunk(slab.nz_out, kz, zstride, (ctx->opt.exp & 2) != 0, &zs_frows, &zs_lds) : 0;
+    const bool zinline = zdirect && !is_slab && zs_chunk == 0 &&
                          (ctx->opt.zpass == 3 || (ctx->opt.zpass == 0 && kz >= MVSIM_ZINLINE_MIN_KZ && pz >= 512 && lines_per_tile(pz) == 16));
     const float2 *tw_m, *tw_px, *tw_py, *tw_pz;
     MVSIM_TRY(ensure_twiddles(ctx, M, 0, &tw_m));
@@ -1748,7 +2060,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             z.zs = (long long)ZB * hxp; z.src_blk = (long long)nzs * ZB * hxp; z.dst_blk = (long long)nzo * ZB * hxp;
             z.taps_blk = (long long)kz * ZB * hxp;
             z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
-            z.zc = zconv_chunk(nzo, kz);
+            z.zc = zs_chunk > 0 ? zs_chunk : zconv_chunk(nzo, kz);
+            z.stride = zs_chunk > 0 ? zstride : 1; z.frows = zs_frows;
             z.nzbits = pnz_bits;
             const float scale_f = (float)(0.25 / ((double)px * (double)py));
             long long zblocks = 0;
@@ -1759,7 +2072,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
                 MVSIM_TRY(ctx->partials_z.reserve((size_t)zblocks * sizeof(double)));
                 z.sum_partial = ctx->partials_z.as<double>();
             }
-            MVSIM_TRY(launch_zconv(ctx, z, py));
+            if (zs_chunk > 0) MVSIM_TRY(launch_zconv_strided(ctx, z, py, zs_lds));
+            else MVSIM_TRY(launch_zconv(ctx, z, py));
             if (early) {
                 // same factor pass E applies to every voxel (a float), so that the two sums estimate the same quantity
                 hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, z.sum_partial, zblocks, scal, (double)scale_f,

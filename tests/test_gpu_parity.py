@@ -737,7 +737,8 @@ def options(ctx):
             ctx.set_option(k, v)
     yield set_
     for k, v in (("fft_zpass", "auto"), ("fft_backend", "custom"), ("fft_pad", "auto"), ("fused_rotate", 1),
-                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial"), ("psf_overlap", 1), ("tail_overlap", 1)):
+                 ("poisson_queue", 1), ("early_sum", 1), ("fuse_tail", 0), ("graph", 0), ("attenuate", "serial"), ("psf_overlap", 1), ("tail_overlap", 1),
+                 ("zconv_strided", 1), ("exp", 0)):
         ctx.set_option(k, v)
 
 
@@ -1327,10 +1328,12 @@ def test_early_sum_from_the_spectrum_matches_pass_e(ctx, synth, options, shape, 
 @pytest.mark.parametrize("inc", [2, 3, 4, 7])
 def test_compact_planes_view_equals_full_view(ctx, synth, options, inc):
     """With the sum known before the last two passes of the convolution (early sum), a view that does not return the
-    adjusted volume only produces the planes k * inc that extractSlices reads.  The acquisition must equal the one of a
-    view that materialises the whole volume (same planes through the same per-plane transforms, same RNG counters)."""
+    adjusted volume only produces the planes k * inc that extractSlices reads.  With every plane still convolved
+    (zconv_strided=0) the acquisition must equal the one of a view that materialises the whole volume (same planes through
+    the same per-plane transforms, same RNG counters)."""
     gt = synth.sphere_phantom(40)
     psf = synth.gaussian_psf(7, 9, 11, sigma=(1.2, 1.4, 2.2))
+    options(zconv_strided=0)
     for snr in (25.0, -1.0):
         p = ctx.view_params(degrees=35, inc=inc, snr=snr, seed=SEED, stream=4, conv_method=1)
         full = ctx.simulate_view(gt, psf.copy(), p, want=("con", "acq"))          # con requested: every plane is produced
@@ -1340,6 +1343,35 @@ def test_compact_planes_view_equals_full_view(ctx, synth, options, inc):
         assert compact["corr"] == full["corr"]
         if snr < 0:
             assert np.array_equal(compact["acq"], full["con"][::inc])
+
+
+@pytest.mark.parametrize("shape,kshape", [((40, 40, 40), (7, 9, 11)), ((36, 44, 61), (5, 5, 31)), ((48, 48, 130), (9, 9, 63)),
+                                          ((24, 24, 7), (3, 3, 5)), ((32, 32, 300), (3, 5, 64)), ((32, 32, 33), (3, 3, 1))])
+@pytest.mark.parametrize("inc", [2, 3, 4])
+def test_strided_z_pass_of_compact_views(ctx, synth, options, shape, kshape, inc):
+    """Default for compact views (inc 2..4): the direct z pass convolves the planes k * inc alone, in polyphase order, and takes
+    adjustImage's sum over ALL planes from its input rows (k_zconv_strided).  Same taps, other summation order: the adjusted
+    planes agree with a full view's to float rounding, the factor to 1e-6, the counts except where a rounding moves one;
+    and against the oracle's exact direct sum like every other form of the convolution."""
+    nx, ny, nz = shape
+    options(exp=2)                         # the strided kernel wherever its geometry allows, not only where the cost rule picks it
+    rng = np.random.default_rng(nz * 7 + inc)
+    gt = (rng.random((nz, ny, nx), dtype=np.float32) * (rng.random((nz, ny, nx)) < 0.4)).astype(np.float32)
+    psf = (rng.random(kshape[::-1], dtype=np.float32) + 0.05).astype(np.float32)
+    for snr in (-1.0, 25.0):
+        p = ctx.view_params(degrees=20, inc=inc, snr=snr, seed=SEED, stream=3, conv_method=1)
+        full = ctx.simulate_view(gt, psf.copy(), p, want=("con", "acq"))
+        compact = ctx.simulate_view(gt, psf.copy(), p, want=("acq",))
+        assert compact["acq"].shape == ((nz - 1) // inc + 1, ny, nx)
+        assert abs(compact["corr"] - full["corr"]) <= 1e-6 * full["corr"], (compact["corr"], full["corr"])
+        if snr < 0:
+            ref = full["con"][::inc]
+            assert np.max(np.abs(compact["acq"] - ref)) <= 3e-6 * float(ref.max())
+        else:
+            assert (compact["acq"] != full["acq"]).mean() < 2e-3
+    options(zconv_strided=0)
+    old = ctx.simulate_view(gt, psf.copy(), p, want=("acq",))
+    assert np.array_equal(old["acq"], full["acq"])
 
 
 @pytest.mark.parametrize("inc,want_con", [(1, False), (1, True), (3, False), (3, True)])

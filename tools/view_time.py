@@ -1,6 +1,7 @@
 """HIP-event time of one fused view at an arbitrary geometry (device-resident), e.g. the BASELINE configs:
     python tools/view_time.py 1024 1024 1024  15 15 41  4      # configs[3]
     python tools/view_time.py 2048 2048 512   63 63 63  1      # configs[4]
+Further arguments are context options: zconv_strided=0 fft_zpass=inline ...
 """
 import importlib, os, sys
 import numpy as np
@@ -11,6 +12,8 @@ nx, ny, nz, kx, ky, kz, inc = (int(a) for a in sys.argv[1:8])
 rng = np.random.default_rng(1)
 ctx = mvs.Context(0)
 ctx.set_option("tail_overlap", 0); ctx.set_option("psf_overlap", 0)   # one kernel at a time: stage times are the kernels' own
+for kv in sys.argv[8:]:
+    ctx.set_option(*kv.split("=", 1))
 # cheap compactly supported volume built on the host plane by plane
 w = lambda n: np.clip(1 - ((np.arange(n, dtype=np.float32) - (n - 1) / 2) / (0.3 * n)) ** 2, 0, None) ** 2
 gt = (w(nz)[:, None, None] * w(ny)[None, :, None]).astype(np.float32) * w(nx)[None, None, :]
@@ -27,5 +30,5 @@ for _ in range(4):
     ctx.simulate_view_dev(d_gt, (nx, ny, nz), psf.copy(), p, d_acq)
 t = ctx.timings()
 n = nx * ny * nz
-print(f"{nx}x{ny}x{nz}, PSF {kx}x{ky}x{kz}, inc {inc}: {t['total_ms']:.2f} ms/view = {n / t['total_ms'] / 1e6:.1f} Gvoxel/s  "
+print(f"{nx}x{ny}x{nz}, PSF {kx}x{ky}x{kz}, inc {inc}{' ' + ' '.join(sys.argv[8:]) if sys.argv[8:] else ''}: {t['total_ms']:.2f} ms/view = {n / t['total_ms'] / 1e6:.1f} Gvoxel/s  "
       + " ".join(f"{k}={v:.2f}" for k, v in t.items() if k != "total_ms"))
