@@ -913,6 +913,9 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
         tv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < p.kz) tv[it] = *reinterpret_cast<const float4*>(p.taps + (long long)r * p.zs + tcol + c2);
     }
+    // the sum's weights travel with the tile (requested in the epilogue they cost a block 1-4 k cycles of exposed latency: clock stamps)
+    double2 wxa = make_double2(0.0, 0.0), wyb = make_double2(0.0, 0.0);
+    if (p.sum_partial) { wxa = p.wx[kxb * NLZ + (tid & (NLZ - 1))]; wyb = p.wy[ky]; }
 #pragma unroll
     for (int it = 0; it < ZNIT; ++it) {
         const int r = (tid / ZLPR) + it * ZRPI;
@@ -995,8 +998,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
     }
     if (p.sum_partial) {
         __shared__ double red[ZT / 64];
-        const double2 a = p.wx[kxb * NLZ + line], b = p.wy[ky];
-        const double wr = a.x * b.x - a.y * b.y, wi = a.x * b.y + a.y * b.x;
+        const double wr = wxa.x * wyb.x - wxa.y * wyb.y, wi = wxa.x * wyb.y + wxa.y * wyb.x;
         double t = sre * wr - sim * wi;                   // Re( s * W )
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
@@ -1103,6 +1105,9 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv_strided(ZConvArgs 
         tv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < p.kz) tv[it] = *reinterpret_cast<const float4*>(p.taps + (long long)r * p.zs + tcol + c2);
     }
+    // the sum's weights travel with the tile (requested in the epilogue they cost a block 1-4 k cycles of exposed latency: clock stamps)
+    double2 wxa = make_double2(0.0, 0.0), wyb = make_double2(0.0, 0.0);
+    if (p.sum_partial) { wxa = p.wx[kxb * NLZ + (tid & (NLZ - 1))]; wyb = p.wy[ky]; }
 #pragma unroll
     for (int it = 0; it < ZNIT; ++it) {
         const int r = (tid / ZLPR) + it * ZRPI;
@@ -1215,8 +1220,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv_strided(ZConvArgs 
             s2 = __builtin_elementwise_fma(v2f{-wi, wi}, v2f{x.y, x.x}, s2);
         }
         const double sre = (double)s2.x, sim = (double)s2.y;
-        const double2 a = p.wx[kxb * NLZ + (tid & (NLZ - 1))], b = p.wy[ky];
-        const double wr = a.x * b.x - a.y * b.y, wi = a.x * b.y + a.y * b.x;
+        const double wr = wxa.x * wyb.x - wxa.y * wyb.y, wi = wxa.x * wyb.y + wxa.y * wyb.x;
         double t = sre * wr - sim * wi;                   // Re( s * W )
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
@@ -1981,9 +1985,12 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             // ctx->plane_flags = [flags (nz)][dilated (nz)][bit string (nwords)] (rotate_attenuate_fftx reserves all three)
             int* base = ctx->plane_flags.as<int>();
             const int nwords = ((int)dim[2] + 2 * NZ_EXT + 64 + 31) / 32 + ZNIT + 2;
-            hipLaunchKernelGGL(k_plane_flags_finish, dim3(1), dim3(1024), 0, s, pnz, (int)dim[2], kz, kz / 2,
+            // one block, ~9 us: beside pass B on the side stream when there is one (pass B reads the raw flags; the bit string and the
+            // dilated flags are for passes C', D and E, behind the join)
+            hipLaunchKernelGGL(k_plane_flags_finish, dim3(1), dim3(1024), 0, side ? ctx->side_stream : s, pnz, (int)dim[2], kz, kz / 2,
                                reinterpret_cast<unsigned int*>(base + 2 * dim[2]), nwords, base + dim[2], ctx->empty_hint);
             MVSIM_HIP(hipGetLastError());
+            if (side) MVSIM_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
             pnz_dil = base + dim[2];
             pnz_bits = reinterpret_cast<const unsigned int*>(base + 2 * dim[2]);
             b.nzflags = pnz; b.nz_stride = 1;
