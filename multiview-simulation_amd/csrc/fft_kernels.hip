@@ -620,6 +620,7 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     }
     double acc = 0.0;
     const bool vec_out = (nx & 3) == 0;
+    const bool want_sum = partial != nullptr;             // null: adjustImage's sum came from the z pass (early sum)
     for (int j = 0; j < LW; ++j) {
         const long long row = row0 + j;
         if (row >= rows) break;
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
             const float x0 = z0.x * scale, x1 = -z0.y * scale, x2 = z1.x * scale, x3 = -z1.y * scale;
             if (vec_out) {
                 *reinterpret_cast<float4*>(o + 4 * q) = make_float4(x0, x1, x2, x3);
-                acc += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+                if (want_sum) acc += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
             } else {
                 o[4 * q] = x0; acc += (double)x0;
                 if (4 * q + 1 < nx) { o[4 * q + 1] = x1; acc += (double)x1; }
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
             }
         }
     }
+    if (!want_sum) return;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) red[wave] = acc;
@@ -2148,7 +2150,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         const float scale = (float)(0.25 / ((double)px * (double)py * ((zdirect && !zinline) ? 1.0 : (double)pz)));
         int nblk = 0;
         MVSIM_TRY(launch_c2r(ctx, M, Fz, out, tw_m, tw_px, hxp, py * zstride, (int)dim[0], (int)dim[1], (long long)dim[1] * nk, scale,
-                             ctx->partials_e.as<double>(), &nblk, fuse ? &fz : nullptr,
+                             early ? nullptr : ctx->partials_e.as<double>(), &nblk, fuse ? &fz : nullptr,
                              C2REmpty{em_flags, zstride}));
         if (fuse && nblk != (int)fblocks) { set_error("fused tail: block count mismatch"); return MVSIM_EINVAL; }
         if (!early) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_e.as<double>(), (long long)nblk, scal, 1.0,
