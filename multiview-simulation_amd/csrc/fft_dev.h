@@ -385,6 +385,7 @@ struct __attribute__((packed, aligned(8))) Pair16 {
     X(384, 3, 8, 4, 4)     \
     X(448, 7, 8, 8)        \
     X(512, 8, 8, 8)        \
+    X(540, 9, 5, 4, 3)     \
     X(560, 7, 8, 10)       \
     X(576, 9, 8, 8)        \
     X(640, 5, 8, 4, 4)     \
@@ -392,6 +393,7 @@ struct __attribute__((packed, aligned(8))) Pair16 {
     X(768, 3, 8, 8, 4)     \
     X(896, 7, 8, 4, 4)     \
     X(1024, 4, 8, 8, 4)    \
+    X(1080, 9, 8, 5, 3)    \
     X(1120, 7, 8, 5, 4)    \
     X(1152, 9, 8, 4, 4)    \
     X(1280, 5, 8, 8, 4)    \

@@ -80,6 +80,19 @@ def test_convolve_radix5_7_sizes(ctx, orc, shape, kshape):
     assert rel_to_max(got, got2) <= CONV_TOL
 
 
+@pytest.mark.parametrize("shape,kshape,zpass", [((8, 1040, 1040), (3, 15, 15), "auto"),      # x: 2 * 540 (9*5*4*3), y: 1080 (9*8*5*3)
+                                                ((1040, 20, 24), (15, 5, 5), "fft")])         # z: 1080 through the FFT z pass
+def test_convolve_sizes_540_and_1080(ctx, orc, options, shape, kshape, zpass):
+    """The padded lengths a 1024-voxel axis takes with PSFs of up to 57 taps (1024 + 30 = 1054 -> 1080 instead of 1120; configs[3])."""
+    rng = np.random.default_rng(17)
+    v = rng.random(shape, dtype=np.float32)
+    psf = rng.random(kshape, dtype=np.float32) + 0.01
+    options(fft_zpass=zpass)
+    got = ctx.convolve(v, psf.copy(), method=1)
+    want = orc.convolve_fft(v, psf.copy())
+    assert rel_to_max(got, want) <= CONV_TOL
+
+
 @pytest.mark.parametrize("method", [1, 2])
 def test_convolve_delta_shift_kat(ctx, method):
     v = np.random.default_rng(4).random((10, 11, 12), dtype=np.float32)
