@@ -375,12 +375,14 @@ struct __attribute__((packed, aligned(8))) Pair16 {
     X(140, 7, 5, 4)        \
     X(144, 9, 4, 4)        \
     X(160, 5, 8, 4)        \
+    X(180, 9, 5, 4)        \
     X(192, 3, 8, 8)        \
     X(224, 7, 8, 4)        \
     X(256, 4, 8, 8)        \
     X(280, 7, 5, 8)        \
     X(288, 9, 8, 4)        \
     X(320, 5, 8, 8)        \
+    X(350, 7, 10, 5)       \
     X(360, 9, 5, 8)        \
     X(384, 3, 8, 4, 4)     \
     X(448, 7, 8, 8)        \

@@ -81,8 +81,10 @@ def test_convolve_radix5_7_sizes(ctx, orc, shape, kshape):
 
 
 @pytest.mark.parametrize("shape,kshape,zpass", [((8, 1040, 1040), (3, 15, 15), "auto"),      # x: 2 * 540 (9*5*4*3), y: 1080 (9*8*5*3)
-                                                ((1040, 20, 24), (15, 5, 5), "fft")])         # z: 1080 through the FFT z pass
-def test_convolve_sizes_540_and_1080(ctx, orc, options, shape, kshape, zpass):
+                                                ((1040, 20, 24), (15, 5, 5), "fft"),          # z: 1080 through the FFT z pass
+                                                ((300, 20, 24), (51, 5, 5), "fft"),           # z: 350 (7*10*5)
+                                                ((8, 300, 310), (3, 51, 51), "auto")])        # x: 2 * 180 (9*5*4), y: 350
+def test_convolve_sizes_added_in_round_4(ctx, orc, options, shape, kshape, zpass):
     """The padded lengths a 1024-voxel axis takes with PSFs of up to 57 taps (1024 + 30 = 1054 -> 1080 instead of 1120; configs[3])."""
     rng = np.random.default_rng(17)
     v = rng.random(shape, dtype=np.float32)
