@@ -947,7 +947,7 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
         // No clamps on the row index: rows above the staged range (the last z block of a chunk may be partial) lie inside the LDS
         // region all the same (it is sized for zc outputs) and whatever they hold only feeds outputs that are neither stored nor
         // summed; base never goes below 0 (it ends at z0: padf + kz = kzp).  One address register plus immediate offsets instead
-        // of a 64-bit multiply-add per window element (24 v_mad_u64_u32 per z block).
+        // of a 64-bit multiply-add per window element (24 quarter-rate v_mad_u64_u32 per z block).
         const float2* __restrict__ fw = f + base * ZPITCH + line;
 #pragma unroll
         for (int i = 0; i < ZU + ZJ - 1; ++i) w[i] = fw[i * ZPITCH];
