@@ -73,11 +73,7 @@ int  mvsim_join(mvsim_ctx* ctx);
  * extract + Poisson phase 1 in the epilogue of the convolution's last pass), "fused_fftx" = auto|1|0 (per-view pipeline: rotate + attenuate + the x transform of
  * the FFT convolution as one kernel, so that the attenuated volume crosses HBM only when requested; auto = from 131072
  * columns up), "attenuate" = serial|scan (mvsim_attenuate3d
- * as a wavefront-level prefix scan along the illumination axis: parallel in y, not bit-identical to the serial walk),
- * "skip_empty" = 1|0 (planes the rotate kernel finds empty are not convolved: exact), "zconv_strided" = 1|0 (views with inc 2..4 that
- * return only the acquisition convolve along z only the planes extractSlices reads -- same taps in another summation order, ~1e-7 of
- * the range; 0: every plane, bit-identical to a view that also returns the convolved volume), "broadcast" also takes peer_copy.
- * The switches of the co-scheduling experiments (guest_tail, cu_range, tail_cus, kx_panel, exp, ...) are listed in DESIGN.md section 8.
+ * as a wavefront-level prefix scan along the illumination axis: parallel in y, not bit-identical to the serial walk).
  * MVSIM_OPTIONS="name=value;name=value" sets any of them process-wide.  Unknown names or values: MVSIM_EINVAL. */
 int  mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value);
 /* Release cached FFT plans / workspaces / PSF spectra held by the context. */
