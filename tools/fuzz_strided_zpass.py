@@ -8,6 +8,7 @@ mvs = importlib.import_module("multiview-simulation_amd")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = mvs.Context(0)
+ctx.set_option("fused_fftx", 1)                             # the fused rotate kernel (the source of the plane flags) wherever the geometry allows it
 bad = 0
 degenerate = 0
 for case in range(n_cases):
