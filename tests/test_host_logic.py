@@ -363,3 +363,17 @@ def test_java_facade_passes_a_fresh_generation_per_dataset():
     for name in ("rendered.tif", "groundtruth.tif", "rot_view_", "att_view_", "con_view_", "acq_view_", "iso_view_", "aligned_view_",
                  "aligned_view_psf_", "aligned_view_weights", "sum_weights.tif"):
         assert name in facade, name
+
+
+def test_committed_pmc_traffic_belongs_to_this_build():
+    """bench.py prints roofline.traffic only while the SHA of the kernel sources equals the one the PMC record under profiles/ was
+    collected on (tools/profile_all.sh).  A mismatch is not an error of the build -- the record has to be collected again on a GPU box --
+    so it is reported as a skip, with what bench.py will do about it."""
+    import importlib, json
+    build = importlib.import_module("multiview-simulation_amd.build")
+    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    rec = json.load(open(path))
+    if rec["kernel_sha"] != build.source_sha():
+        pytest.skip(f"{os.path.relpath(path, ROOT)} was collected on kernel sources {rec['kernel_sha']}, this tree is {build.source_sha()}: "
+                    "bench.py will print roofline.traffic = null until `bash tools/profile_all.sh TAG` has been run again")
+    assert rec["views_profiled"] >= 1 and rec["per_view_bytes"]["convolve"] > 0
