@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 mvs = importlib.import_module("multiview-simulation_amd")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+EXP = int(sys.argv[3]) if len(sys.argv) > 3 else 2       # experiment bits beside 2 (= the strided kernel wherever its geometry allows)
 ctx = mvs.Context(0)
 ctx.set_option("fused_fftx", 1)                             # the fused rotate kernel (the source of the plane flags) wherever the geometry allows it
 bad = 0
@@ -30,8 +31,8 @@ for case in range(n_cases):
     nzo = (nz - 1) // inc + 1
     d_acq = ctx.dev_alloc(nzo * ny * nx * 4)
     res = {}
-    for name, opts in (("all", dict(zconv_strided=0, exp=0, skip_empty=1)), ("strided", dict(zconv_strided=1, exp=2, skip_empty=1)),
-                       ("strided_noskip", dict(zconv_strided=1, exp=2, skip_empty=0))):
+    for name, opts in (("all", dict(zconv_strided=0, exp=0, skip_empty=1)), ("strided", dict(zconv_strided=1, exp=EXP, skip_empty=1)),
+                       ("strided_noskip", dict(zconv_strided=1, exp=EXP, skip_empty=0))):
         for k, v in opts.items():
             ctx.set_option(k, v)
         for _ in range(2):                                    # twice: the adaptive plane flags take a view to settle
