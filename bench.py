@@ -126,7 +126,8 @@ def self_launch(args) -> int:
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVSIM_BENCH_SELF_LAUNCHED="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVSIM_BENCH_SELF_LAUNCHED="1",
+                   MVSIM_BENCH_LAUNCHER_PID=str(os.getpid()))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -171,7 +172,8 @@ def self_launch(args) -> int:
 def die_with_parent() -> None:
     """A rank started by self_launch: have the kernel send SIGTERM when the launcher dies, however it dies (SIGKILL from a
     caller's timeout included).  prctl(PR_SET_PDEATHSIG) through ctypes, before torch or HIP are touched; if the launcher
-    is gone already, leave now."""
+    is gone already -- this process's parent is no longer the PID the launcher exported (a launcher that IS pid 1, a container's
+    entry point, is a live parent; an orphan adopted by a subreaper has a parent that is neither 1 nor the launcher) -- leave now."""
     import signal
     try:
         libc = C.CDLL(None, use_errno=True)
@@ -179,7 +181,8 @@ def die_with_parent() -> None:
         libc.prctl(PR_SET_PDEATHSIG, int(signal.SIGTERM), 0, 0, 0)
     except Exception:
         return
-    if os.getppid() == 1:
+    launcher = os.environ.get("MVSIM_BENCH_LAUNCHER_PID", "")
+    if launcher.isdigit() and os.getppid() != int(launcher):
         sys.exit(1)
 
 
@@ -633,12 +636,17 @@ def main():
             ranks_seen["mvsim_comm"] = int(one[0].item())
             if ranks_seen["mvsim_comm"] != world:
                 raise SystemExit(f"rank {rank}: all-reduce of 1 over the C ABI's communicator gave {ranks_seen['mvsim_comm']}, expected {world}")
+            if args.broadcast == "peer_copy":
+                # the copy-engine form writes into the peers' buffers through IPC mappings: an explicit, collective registration
+                # of every buffer a broadcast will fill (never a cache keyed by address)
+                for b in gt_bufs:
+                    bc_ctx.comm_register_volume(b.data_ptr(), nvox)
     views_done = [[], []]      # per ground-truth buffer: events after the last views that read it
     bcast_done = [None, None]  # per ground-truth buffer: event after the broadcast that filled it
     step_no = [0]
 
     bc_events = []             # (start, end) timing events around every broadcast of the timed region (on bc_stream)
-    view_events = []           # (start, end) around this rank's views of every timed step (on the first view stream)
+    view_events = []           # per timed step: (starts, ends) around this rank's views, one pair per view stream
     record_diag = [False]
 
     def issue_broadcast(b):
@@ -673,14 +681,20 @@ def main():
                 issue_broadcast(1 - cur)                # next dataset's ground truth, overlapped with these views
         gt_ptr = gt_bufs[cur].data_ptr()
         if multi and record_diag[0] and my_views:
-            v0 = torch.cuda.Event(enable_timing=True)
-            v0.record(view_streams[0])
+            v0 = []
+            for vs in view_streams:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(vs)
+                v0.append(e)
         for i in range(len(my_views)):
             ctxs[i % len(ctxs)].simulate_view_dev(gt_ptr, dims, psfs[i].copy(), params[i], acq[i].data_ptr())
         if multi and record_diag[0] and my_views:
-            ctxs[0].join()                              # a pending tail belongs to this step's views
-            v1 = torch.cuda.Event(enable_timing=True)
-            v1.record(view_streams[0])
+            v1 = []
+            for c, vs in zip(ctxs, view_streams):
+                c.join()                                # a pending tail belongs to this step's views
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(vs)
+                v1.append(e)
             view_events.append((v0, v1))
         if multi:
             views_done[cur] = []
@@ -730,7 +744,7 @@ def main():
         # rank's views on theirs, how much of the broadcast the views hid, and every rank's own wall clock.  Events, read after the
         # timed region; nothing here is inside it but the event records themselves.
         bc_ms = [a.elapsed_time(b) for a, b in bc_events]
-        vw_ms = [a.elapsed_time(b) for a, b in view_events]
+        vw_ms = [max(a.elapsed_time(b) for a, b in zip(v0, v1)) for v0, v1 in view_events]   # the busiest of this rank's view streams
         mine = torch.tensor([own_elapsed / args.steps * 1e3, sum(bc_ms) / max(1, len(bc_ms)), sum(vw_ms) / max(1, len(vw_ms)),
                              float(len(my_views))], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         every = [torch.zeros_like(mine) for _ in range(world)]

@@ -65,7 +65,7 @@ int  mvsim_join(mvsim_ctx* ctx);
  * "fft_backend" = custom|rocfft (MVSIM_FFT_BACKEND), "fft_pad" = "px,py,pz"|auto (MVSIM_FFT_PAD), "fused_rotate" = auto|1|0|2
  * (MVSIM_NO_FUSED_ROTATE; auto = fused from 131072 columns up, separate kernels for small views; 2 = the variant that
  * recomputes the row geometry in every lane), "poisson_queue" = 1|0 (MVSIM_POISSON_NOQUEUE), "early_sum" = 1|0 (MVSIM_NO_EARLY_SUM),
- * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring (MVSIM_BROADCAST), "psf_overlap" = 1|0 (the PSF's spectrum on a side
+ * "graph" = 0|1 (MVSIM_GRAPH), "broadcast" = scatter_allgather|ring|peer_copy (MVSIM_BROADCAST), "psf_overlap" = 1|0 (the PSF's spectrum on a side
  * stream of the context, concurrent with the image passes A and B), "tail_overlap" = 1|0|any (extract + Poisson of a device
  * view concurrent with the next view's rotate+attenuate; 1 = only on the context's own stream, see mvsim_join; both
  * overlaps are on by default -- results are bit-identical to the serial order -- and are switched off for profiles whose
@@ -216,6 +216,16 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
                             float* psf_host, const int64_t kdim[3],
                             const mvsim_view_params* params, const mvsim_view_outputs* out,
                             double* correction);
+/* The view loop of `main` (SimulateMultiViewDataset.java:567-585) for views that cannot fill the chip one at a time -- the
+ * reference's own run is 7 views of a 289^3 volume with 51^3 PSFs (:376-380, :399, :531-548): n_views independent views of ONE
+ * ground truth in one call.  psf_host[v] (normalised in place like everywhere else), params[v] and outs[v] describe view v; all
+ * views share dim and kdim.  The library runs as many of them side by side as pays for their size (option "view_lanes" =
+ * auto|1..32: child contexts of `ctx` on the same device, forked from and joined to ctx's stream, so the call is asynchronous on
+ * that stream like mvsim_simulate_view_dev).  Every output is bit-identical to what n_views sequential mvsim_simulate_view_dev
+ * calls write.  Output buffers must not overlap each other or the ground truth (MVSIM_EINVAL). */
+int mvsim_simulate_views_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* const* psf_host,
+                             const int64_t kdim[3], const mvsim_view_params* params, const mvsim_view_outputs* outs,
+                             int n_views);
 /* One whole iteration of `main`'s view loop (SimulateMultiViewDataset.java:567-613), device-resident: the view above
  * (rotate, attenuate, convolve, adjust, extractSlices + Poisson) followed by what the loop does with its results --
  *   iso          = makeIsotropic(acq, inc)                                    (:588)   Nx*Ny*isotropic_nz
@@ -315,6 +325,14 @@ int mvsim_comm_library_info(char* path, size_t path_capacity, int* version);
  * Default form: scatter (root sends chunk r to rank r, nranks-1 concurrent ncclSend: one per xGMI link) followed by
  * an in-place ncclAllGather, so that all links carry traffic; option "broadcast" = ring selects one ncclBroadcast. */
 int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, int root);
+/* Option "broadcast" = peer_copy moves the chunks of the same scatter + all-gather with the copy engines between the ranks'
+ * buffers (IPC-mapped into each other's processes; no RCCL kernels beside the views).  The buffer a rank broadcasts into must have
+ * been REGISTERED: a collective -- every rank calls it, in the same order as the other collectives of the communicator, each for
+ * its own buffer of >= count floats; it synchronises the context's stream.  A registration is never reused for another buffer:
+ * registering again replaces it, mvsim_comm_unregister_volume (local), mvsim_dev_free of the buffer and mvsim_comm_destroy drop
+ * it.  One process per rank (ranks that share a process use the RCCL forms). */
+int mvsim_comm_register_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count);
+int mvsim_comm_unregister_volume(mvsim_ctx* ctx, const float* vol_dev);
 /* In-place sum over ranks (RCCL all-reduce) of a device float buffer: the per-voxel weight sums of SMVD:625-628
  * when the views live on different GPUs.  Summation order differs from the sequential reference (<= 1 ulp). */
 int mvsim_comm_allreduce_sum(mvsim_ctx* ctx, float* buf_dev, int64_t count);

@@ -464,6 +464,25 @@ class Context:
             C.byref(o), C.byref(corr) if want_corr else None))
         return corr.value if want_corr else None
 
+    def simulate_views_dev(self, gt_dptr: int, dim_xyz, psfs, params, acq_dptrs, con_dptrs=None) -> None:
+        """``len(psfs)`` independent views of one device-resident ground truth in one call (the view loop of `main`,
+        SimulateMultiViewDataset.java:567-585): the library runs as many side by side as pays for their size.  ``psfs[v]`` is
+        normalised in place; ``params[v]``, ``acq_dptrs[v]`` (and ``con_dptrs[v]``) belong to view v.  Asynchronous."""
+        nv = len(psfs)
+        if not (len(params) == len(acq_dptrs) == nv) or (con_dptrs is not None and len(con_dptrs) != nv):
+            raise ValueError("psfs, params and output lists must have the same length")
+        if nv == 0:
+            return
+        for p in psfs:
+            _check_inplace(p, "psf")
+            if p.shape != psfs[0].shape:
+                raise ValueError("all PSFs of one call share their dimensions")
+        pp = (C.c_void_p * nv)(*[p.ctypes.data for p in psfs])
+        pa = (ViewParams * nv)(*params)
+        oo = (ViewOutputs * nv)(*[ViewOutputs(None, None, (con_dptrs[v] or None) if con_dptrs is not None else None, acq_dptrs[v] or None)
+                                  for v in range(nv)])
+        _lib.check(self._L.mvsim_simulate_views_dev(self._h, C.c_void_p(gt_dptr), (C.c_int64 * 3)(*dim_xyz), pp, _dim(psfs[0]), pa, oo, nv))
+
     def simulate_iteration_dev(self, gt_dptr: int, dim_xyz, psf: np.ndarray, params: ViewParams, back_degrees: int, acq_dptr: int,
                                iso_dptr: int = 0, view_dptr: int = 0, view_weights_dptr: int = 0, view_psf_dptr: int = 0,
                                rot_dptr: int = 0, att_dptr: int = 0, con_dptr: int = 0) -> None:
@@ -561,6 +580,13 @@ class Context:
 
     def comm_broadcast_volume(self, dptr: int, count: int, root: int = 0) -> None:
         _lib.check(self._L.mvsim_comm_broadcast_volume(self._h, C.c_void_p(dptr), count, root))
+
+    def comm_register_volume(self, dptr: int, count: int) -> None:
+        """Collective: every rank registers the buffer it will broadcast into with option broadcast=peer_copy."""
+        _lib.check(self._L.mvsim_comm_register_volume(self._h, C.c_void_p(dptr), count))
+
+    def comm_unregister_volume(self, dptr: int) -> None:
+        _lib.check(self._L.mvsim_comm_unregister_volume(self._h, C.c_void_p(dptr)))
 
     def comm_allreduce_sum(self, dptr: int, count: int) -> None:
         _lib.check(self._L.mvsim_comm_allreduce_sum(self._h, C.c_void_p(dptr), count))

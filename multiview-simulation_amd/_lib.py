@@ -107,6 +107,8 @@ SIGNATURES = {
     "mvsim_view_params_default": (None, [C.POINTER(ViewParams)]),
     "mvsim_simulate_view_dev": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams),
                                           C.POINTER(ViewOutputs), C.POINTER(C.c_double)]),
+    "mvsim_simulate_views_dev": (C.c_int, [_vp, _vp, _i64p, C.POINTER(_vp), _i64p, C.POINTER(ViewParams),
+                                           C.POINTER(ViewOutputs), C.c_int]),
     "mvsim_simulate_iteration_dev": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams), C.c_int,
                                                C.POINTER(ViewOutputs), C.POINTER(IterationOutputs)]),
     "mvsim_simulate_view": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams),
@@ -131,6 +133,8 @@ SIGNATURES = {
     "mvsim_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "mvsim_comm_library_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "mvsim_comm_broadcast_volume": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "mvsim_comm_register_volume": (C.c_int, [_vp, _vp, C.c_int64]),
+    "mvsim_comm_unregister_volume": (C.c_int, [_vp, _vp]),
     "mvsim_comm_allreduce_sum": (C.c_int, [_vp, _vp, C.c_int64]),
     "mvsim_comm_allreduce_sum_f64": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "mvsim_slab_range": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

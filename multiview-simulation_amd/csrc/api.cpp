@@ -55,7 +55,11 @@ int parse_option(Options& o, const char* name, const char* value)
     }
     if (n == "early_sum") return flag(&o.early_sum);
     if (n == "zconv_strided") return flag(&o.zconv_strided);
-    if (n == "exp") { o.exp = atoi(v.c_str()); return MVSIM_OK; }
+    if (n == "exp") {                                  // A/B bits of tools/ and the tests (common.h): 0 .. 3
+        if (v.size() != 1 || v[0] < '0' || v[0] > '3') return MVSIM_EINVAL;
+        o.exp = v[0] - '0';
+        return MVSIM_OK;
+    }
     if (n == "fuse_tail") return flag(&o.fuse_tail);
     if (n == "psf_overlap") return flag(&o.psf_overlap);
     if (n == "fused_fftx") {
@@ -65,7 +69,15 @@ int parse_option(Options& o, const char* name, const char* value)
     }
     if (n == "tail_overlap") {
         if (v == "0" || v == "off") o.tail_overlap = 0; else if (v == "1" || v == "on" || v == "own") o.tail_overlap = 1;
-        else if (v == "2" || v == "any") o.tail_overlap = 2; else if (v == "3" || v == "late") o.tail_overlap = 3; else return MVSIM_EINVAL;
+        else if (v == "2" || v == "any") o.tail_overlap = 2; else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
+    if (n == "view_lanes") {
+        if (v == "auto") { o.view_lanes = 0; return MVSIM_OK; }
+        if (v.empty() || v.size() > 2 || v.find_first_not_of("0123456789") != std::string::npos) return MVSIM_EINVAL;
+        const int k = atoi(v.c_str());
+        if (k < 1 || k > MVSIM_MAX_VIEWS) return MVSIM_EINVAL;
+        o.view_lanes = k;
         return MVSIM_OK;
     }
     if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
@@ -76,19 +88,7 @@ int parse_option(Options& o, const char* name, const char* value)
         else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
-    if (n == "cu_range") {
-        int a = 0, b = 0;
-        if (sscanf(v.c_str(), "%d:%d", &a, &b) != 2 || a < 0 || b < a || b > 1024) return MVSIM_EINVAL;
-        o.cu_lo = a; o.cu_hi = b;
-        return MVSIM_OK;
-    }
-    if (n == "tail_cus") { const int k = atoi(v.c_str()); if (k < 0 || k > 1024) return MVSIM_EINVAL; o.tail_cus = k; return MVSIM_OK; }
-    if (n == "exp_guest") { o.exp_guest = atoi(v.c_str()); return MVSIM_OK; }
-    if (n == "guest_tail") return flag(&o.guest_tail);
     if (n == "skip_empty") return flag(&o.skip_empty);
-    if (n == "tail_prio") { o.tail_prio = atoi(v.c_str()); return MVSIM_OK; }
-    if (n == "guest_trips") { int a = -1, b = -1; if (sscanf(v.c_str(), "%d,%d", &a, &b) != 2) return MVSIM_EINVAL; o.guest_trips[0] = a; o.guest_trips[1] = b; return MVSIM_OK; }
-    if (n == "kx_panel") { const int k = atoi(v.c_str()); if (k < 0 || k % 16 != 0) return MVSIM_EINVAL; o.kx_panel = k; return MVSIM_OK; }
     if (n == "fft_pad") {
         long long a = 0, b = 0, c = 0;
         if (v == "auto" || v.empty()) { o.fft_pad[0] = o.fft_pad[1] = o.fft_pad[2] = 0; return MVSIM_OK; }
@@ -255,18 +255,6 @@ static int check_dim(const int64_t dim[3])
 
 static int64_t nvox(const int64_t dim[3]) { return dim[0] * dim[1] * dim[2]; }
 
-// A stream whose kernels may only be placed on the CUs [lo, hi) of the runtime's mask order (hi <= lo: every CU).
-int create_stream_on_cus(hipStream_t* s, int lo, int hi, int num_cu)
-{
-    if (hi <= lo) { MVSIM_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return MVSIM_OK; }
-    if (hi > num_cu) hi = num_cu;
-    std::vector<uint32_t> mask((size_t)(num_cu + 31) / 32, 0u);
-    for (int c = lo; c < hi; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
-    MVSIM_HIP(hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()));
-    return MVSIM_OK;
-}
-
-
 int join_tail(mvsim_ctx* ctx)
 {
     if (ctx && ctx->tail_pending) {
@@ -276,35 +264,13 @@ int join_tail(mvsim_ctx* ctx)
     return MVSIM_OK;
 }
 
-// A view's extract + Poisson that was left to ride in the next view's y passes (option guest_tail) and now has to run before
-// something else: as the two kernels of its own, on the context's stream.
-int flush_tail(mvsim_ctx* ctx)
-{
-    if (!ctx || !ctx->deferred.valid) return MVSIM_OK;
-    const DeferredTail t = ctx->deferred;
-    ctx->deferred.valid = false;
-    const int64_t n_out = t.dim[0] * t.dim[1] * mvsim_extract_nz(t.dim[2], t.inc);
-    MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(n_out, nullptr)));
-    ev_begin(ctx, ST_EXTRACT);
-    MVSIM_TRY(launch_extract(ctx->stream, t.in, t.out, t.dim, t.inc, t.adjust, t.scal, t.min_value, true, t.mul, t.seed, t.stream, 0,
-                             ctx->pqueue.p, 1, t.index_inc));
-    ev_end(ctx, ST_EXTRACT);
-    return MVSIM_OK;
-}
-
-int settle_tail(mvsim_ctx* ctx)
-{
-    MVSIM_TRY(join_tail(ctx));
-    return flush_tail(ctx);
-}
-
 // every entry point starts here: the device, and a pending tail ordered in front of what the call enqueues
 static int set_device(mvsim_ctx* ctx, bool keep_tail = false)
 {
     MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
     ev_rebalance(ctx);
     MVSIM_HIP(hipSetDevice(ctx->device));
-    if (!keep_tail) { MVSIM_TRY(join_tail(ctx)); MVSIM_TRY(flush_tail(ctx)); }
+    if (!keep_tail) MVSIM_TRY(join_tail(ctx));
     return MVSIM_OK;
 }
 
@@ -425,7 +391,7 @@ int mvsim_create(int device, mvsim_ctx** out)
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
     ctx->opt = env_options();
-    if (create_stream_on_cus(&ctx->own_stream, ctx->opt.cu_lo, ctx->opt.cu_hi, ctx->num_cu) != MVSIM_OK) { delete ctx; return MVSIM_EHIP; }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return MVSIM_EHIP; }
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return MVSIM_OK;
@@ -436,8 +402,12 @@ int mvsim_destroy(mvsim_ctx* ctx)
     if (!ctx) return MVSIM_OK;
     (void)hipSetDevice(ctx->device);
     (void)join_tail(ctx);
-    (void)flush_tail(ctx);
     (void)hipStreamSynchronize(ctx->stream);
+    for (mvsim_ctx* l : ctx->lanes) (void)mvsim_destroy(l);
+    ctx->lanes.clear();
+    for (hipEvent_t e : ctx->lane_done) (void)hipEventDestroy(e);
+    ctx->lane_done.clear();
+    if (ctx->ev_lane_fork) { (void)hipEventDestroy(ctx->ev_lane_fork); ctx->ev_lane_fork = nullptr; }
     mvsim_comm_destroy(ctx);
     async_release(ctx);
     view_graphs_release(ctx);
@@ -472,27 +442,9 @@ int mvsim_join(mvsim_ctx* ctx)
 int mvsim_set_option(mvsim_ctx* ctx, const char* name, const char* value)
 {
     MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
-    const int lo = ctx->opt.cu_lo, hi = ctx->opt.cu_hi, tc = ctx->opt.tail_cus + 4096 * ctx->opt.tail_prio;
     if (parse_option(ctx->opt, name, value) != MVSIM_OK) {
         set_error("invalid argument: option %s = %s", name ? name : "(null)", value ? value : "(null)");
         return MVSIM_EINVAL;
-    }
-    if (ctx->opt.cu_lo != lo || ctx->opt.cu_hi != hi) {
-        // the context's own stream moves to the new CU set (a caller's stream is the caller's business)
-        MVSIM_TRY(set_device(ctx));
-        MVSIM_HIP(hipStreamSynchronize(ctx->own_stream));
-        hipStream_t ns = nullptr;
-        MVSIM_TRY(create_stream_on_cus(&ns, ctx->opt.cu_lo, ctx->opt.cu_hi, ctx->num_cu));
-        if (ctx->stream == ctx->own_stream) ctx->stream = ns;
-        (void)hipStreamDestroy(ctx->own_stream);
-        ctx->own_stream = ns;
-        view_graphs_release(ctx);
-    }
-    if (ctx->opt.tail_cus + 4096 * ctx->opt.tail_prio != tc && ctx->tail_stream) {
-        MVSIM_TRY(set_device(ctx));
-        MVSIM_HIP(hipStreamSynchronize(ctx->tail_stream));
-        (void)hipStreamDestroy(ctx->tail_stream); (void)hipEventDestroy(ctx->ev_tail_fork); (void)hipEventDestroy(ctx->ev_tail);
-        ctx->tail_stream = nullptr;
     }
     return MVSIM_OK;
 }
@@ -508,6 +460,8 @@ int mvsim_release_caches(mvsim_ctx* ctx)
 {
     MVSIM_TRY(set_device(ctx));
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    for (mvsim_ctx* l : ctx->lanes) MVSIM_TRY(mvsim_release_caches(l));
+    MVSIM_HIP(hipSetDevice(ctx->device));
     async_release(ctx);
     view_graphs_release(ctx);                             // captured launches point into the workspaces released below
     fft_release(ctx);
@@ -530,6 +484,13 @@ int mvsim_dev_alloc(mvsim_ctx* ctx, size_t bytes, void** dptr)
 int mvsim_dev_free(mvsim_ctx* ctx, void* dptr)
 {
     MVSIM_TRY(set_device(ctx));
+    if (dptr && ctx->peer_copy) {
+        // peers' IPC mappings registered for this allocation must not outlive it (mvsim_comm_register_volume)
+        void* base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, dptr) == hipSuccess) comm_forget_range(ctx, base, size);
+        else comm_forget_range(ctx, dptr, 0);
+    }
     if (dptr) MVSIM_HIP(hipFree(dptr));
     return MVSIM_OK;
 }
@@ -787,20 +748,6 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     float* con = o->con;
     // (the attenuated volume gets its scratch only where a kernel writes it: behind the fused rotate + attenuate + x transform
     // nothing does, and a 512^3 / 1024^3 view keeps 0.5 / 4 GiB of HBM it would never touch)
-    if (ctx->deferred.valid || ctx->tail_pending) ctx->scal_slot ^= 1;          // the deferred tail reads its view's adjust factor until it has run
-    if (ctx->deferred.valid) {
-        // the previous view's extract + Poisson has not run yet (it rides in this view's y passes): nothing this view does before
-        // them may touch what it reads or writes
-        const DeferredTail& d = ctx->deferred;
-        const size_t dout = (size_t)(d.dim[0] * d.dim[1] * mvsim_extract_nz(d.dim[2], d.inc)) * sizeof(float);
-        const char* lo[2] = {reinterpret_cast<const char*>(d.out), reinterpret_cast<const char*>(d.in)};
-        const char* hi[2] = {lo[0] + dout, lo[1] + (size_t)(d.dim[0] * d.dim[1] * d.dim[2]) * sizeof(float)};
-        bool meet = false;
-        for (int r = 0; r < 2; ++r)
-            meet = meet || ranges_meet(gt, vbytes, lo[r], hi[r]) || ranges_meet(rot, vbytes, lo[r], hi[r]) || ranges_meet(o->att, vbytes, lo[r], hi[r]) ||
-                   ranges_meet(o->con, vbytes, lo[r], hi[r]);
-        if (meet) MVSIM_TRY(flush_tail(ctx));
-    }
     if (ctx->tail_pending) {
         // the previous view's tail still writes its acquisition and reads its convolved volume: this view's first stage
         // may run beside it only if it touches neither
@@ -830,15 +777,12 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     }
     if (!fused) {
         MVSIM_TRY(join_tail(ctx));                      // the rotation scratch is the buffer a pending tail reads
-        MVSIM_TRY(flush_tail(ctx));                     // ... and a deferred one (it runs now, as kernels of its own)
         if (!rot) { MVSIM_TRY(ctx->vol_a.reserve(vbytes)); rot = ctx->vol_a.as<float>(); }
         MVSIM_TRY(launch_rotate(ctx->stream, gt, rot, dim, inv));
     }
     ev_end(ctx, ST_ROTATE);
-    // everything below reuses the workspaces of the previous view -- except, behind the fused kernel, up to pass E: the
-    // spectrum buffers are not the tail's, the [sum, factor] slot alternates, and only pass E writes the volume the tail reads
-    const bool late_join = ctx->opt.tail_overlap == 3 && x_done && ctx->tail_pending && !o->con && pick_method(p->conv_method, kdim) == 1;
-    if (!late_join) MVSIM_TRY(join_tail(ctx));
+    // everything below reuses the workspaces of the previous view
+    MVSIM_TRY(join_tail(ctx));
     if (!fused) {
         ev_begin(ctx, ST_ATTENUATE);
         MVSIM_TRY(launch_attenuate(ctx->stream, rot, att, dim, p->delta));
@@ -859,7 +803,6 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     tail.corr_n = n; tail.min_value = p->min_value; tail.target_average = p->target_average;
     tail.x_done = x_done;
     tail.plane_nz = x_done ? plane_nz : nullptr;
-    tail.join_before_e = late_join;
     if (method == 1 && ctx->opt.fuse_tail && (!noise || ctx->opt.poisson_queue == 1)) {
         const size_t qb = noise ? fused_tail_queue_bytes(dim, kdim, p->inc, materialise, ctx->opt) : 0;
         if (!noise || qb > 0) {
@@ -871,13 +814,7 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
             tail.mul = mvsim_poisson_mul((double)p->snr); tail.seed = p->seed; tail.stream = p->stream;
         }
     }
-    if (ctx->deferred.valid) {
-        // the y passes of this view carry the previous view's sampler -- or it runs now, before pass E reuses its input
-        if (method == 1 && !tail.want_fuse && fft_can_host_guest(ctx, dim, kdim) ) tail.guest = &ctx->deferred;
-        else MVSIM_TRY(flush_tail(ctx));
-    }
     MVSIM_TRY(convolve_dev_impl(ctx, att, dim, kdim, method, con, &tail));
-    if (tail.guest && ctx->deferred.valid) { set_error("guest tail: the convolution did not carry the previous view's sampler"); return MVSIM_EHIP; }
     if (tail.fused) return MVSIM_OK;   // pass E adjusted, extracted and sampled (phase 1); the resolver is enqueued behind it
 
     ev_begin(ctx, ST_ADJUST);
@@ -893,31 +830,11 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     // rotate+attenuate leaves most of the chip idle and runs beside it.
     // (not beside the fused rotate + attenuate + x transform of the next view: that kernel is bound by vector issue like the
     // sampler itself, and the two together measured slower than one after the other -- 17.6 against 17.2 ms per 8 views)
-    // ... but INSIDE the next view's y passes -- HBM-bound tile copies that leave half of the vector issue slots idle -- it fits:
-    // the tail is not enqueued at all now; the next view's passes B and D carry it as guest waves (or flush_tail runs it as
-    // kernels of its own when anything else comes first).  Same visibility contract as the stream overlap.
-    const int64_t ndim[3] = {dim[0], dim[1], tail.zstride > 1 ? mvsim_extract_nz(dim[2], p->inc) : dim[2]};
-    if (overlap_ok && ctx->opt.guest_tail && noise && ctx->opt.poisson_queue == 1 && !materialise && method == 1 && !ctx->timing &&
-        plane_vox % 4 == 0 && ((reinterpret_cast<uintptr_t>(con) | reinterpret_cast<uintptr_t>(o->acq)) & 15) == 0 &&
-        fft_can_host_guest(ctx, dim, kdim)) {
-        DeferredTail& d = ctx->deferred;
-        d.valid = true; d.in = con; d.out = o->acq;
-        d.dim[0] = ndim[0]; d.dim[1] = ndim[1]; d.dim[2] = ndim[2];
-        d.inc = tail.zstride > 1 ? 1 : p->inc; d.index_inc = tail.zstride > 1 ? p->inc : 0;
-        d.adjust = true; d.scal = scal; d.min_value = p->min_value; d.mul = mvsim_poisson_mul((double)p->snr);
-        d.seed = p->seed; d.stream = p->stream;
-        return MVSIM_OK;
-    }
-    if (x_done && ctx->opt.tail_overlap != 3) overlap_ok = false;
+    if (x_done) overlap_ok = false;
     hipStream_t tail_on = ctx->stream;
     if (overlap_ok) {
         if (!ctx->tail_stream) {
-            if (ctx->opt.tail_prio != 0 && ctx->opt.tail_cus == 0) {
-                int least = 0, greatest = 0;
-                MVSIM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                MVSIM_HIP(hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, ctx->opt.tail_prio > 0 ? greatest : least));
-            } else
-            MVSIM_TRY(create_stream_on_cus(&ctx->tail_stream, 0, ctx->opt.tail_cus, ctx->num_cu));
+            MVSIM_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
             MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_tail_fork, hipEventDisableTiming));
             MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
         }
@@ -966,8 +883,8 @@ static std::string view_graph_key(mvsim_ctx* ctx, const float* gt, const int64_t
     add(&o->rot, sizeof(o->rot)); add(&o->att, sizeof(o->att)); add(&o->con, sizeof(o->con)); add(&o->acq, sizeof(o->acq));
     add(&ctx->stream, sizeof(ctx->stream));
     const Options& q = ctx->opt;
-    const int oo[10] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, q.psf_overlap ? 1 : 0,
-                        q.attenuate_scan ? 1 : 0, q.fused_fftx, q.zconv_strided ? 1 : 0};
+    const int oo[12] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, q.psf_overlap ? 1 : 0,
+                        q.attenuate_scan ? 1 : 0, q.fused_fftx, q.zconv_strided ? 1 : 0, q.skip_empty ? 1 : 0, q.exp};
     add(oo, sizeof(oo));
     add(q.fft_pad, sizeof(q.fft_pad));
     return k;
@@ -1043,7 +960,7 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     const bool overlap = ctx->opt.tail_overlap != 0 && (ctx->opt.tail_overlap == 2 || ctx->stream == ctx->own_stream) &&
                          !ctx->opt.graph && !correction && dim &&
                          dim[0] > 0 && dim[1] > 0 && dim[2] > 0 && dim[0] * dim[1] * dim[2] >= ((int64_t)1 << 24);
-    if (!overlap) { MVSIM_TRY(join_tail(ctx)); MVSIM_TRY(flush_tail(ctx)); }
+    if (!overlap) MVSIM_TRY(join_tail(ctx));
     MVSIM_TRY(check_dim(dim));
     MVSIM_CHECK_ARG(gt && p && o, "null pointer");
     MVSIM_CHECK_ARG(o->acq != nullptr, "outputs.acq is required");
@@ -1066,6 +983,96 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
         MVSIM_HIP(hipStreamSynchronize(ctx->stream));
     }
     return MVSIM_OK;
+}
+
+// How many views of this size run side by side.  A view is a chain of ~12 dependent launches; below ~2^25 voxels most of them
+// leave CUs idle (128^3: a few hundred blocks per launch; 289^3: the rotate + attenuate kernel is 1 300 serial waves) and what a
+// view costs is the latency of the chain, not its work.  Measured (profiles/r05_small_views.txt): see DESIGN 4.8.
+static int pick_view_lanes(const mvsim_ctx* ctx, const int64_t dim[3], int n_views)
+{
+    int lanes = ctx->opt.view_lanes;
+    if (lanes <= 0) {
+        const int64_t n = dim[0] * dim[1] * dim[2];
+        lanes = n <= ((int64_t)1 << 22) ? 8 : n <= ((int64_t)1 << 25) ? 4 : n < ((int64_t)1 << 27) ? 2 : 1;
+    }
+    return std::max(1, std::min(lanes, n_views));
+}
+
+int mvsim_simulate_views_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* const* psf_host, const int64_t kdim[3],
+                             const mvsim_view_params* params, const mvsim_view_outputs* outs, int n_views)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(gt && psf_host && kdim && params && outs, "null pointer");
+    MVSIM_CHECK_ARG(n_views >= 0 && n_views <= MVSIM_MAX_VIEWS, "n_views must be in [0, MVSIM_MAX_VIEWS]");
+    MVSIM_CHECK_ARG(!ctx->is_lane, "a lane context cannot fan out itself");
+    const int64_t n = nvox(dim);
+    const size_t vbytes = (size_t)n * sizeof(float);
+    for (int v = 0; v < n_views; ++v) {
+        const mvsim_view_params* p = &params[v];
+        MVSIM_CHECK_ARG(psf_host[v] != nullptr, "null PSF");
+        MVSIM_CHECK_ARG(outs[v].acq != nullptr, "outputs.acq is required");
+        MVSIM_CHECK_ARG(p->axis >= 0 && p->axis <= 2, "axis must be 0, 1 or 2");
+        MVSIM_CHECK_ARG(p->inc >= 1, "inc must be >= 1");
+        MVSIM_CHECK_ARG(p->conv_method >= 0 && p->conv_method <= 2, "conv_method must be 0, 1 or 2");
+    }
+    MVSIM_CHECK_ARG(dim[0] <= dim[1], "attenuate3d: Nx > Ny walks outside the interval in the reference");
+    // views that run side by side must not write what another one reads or writes (sequential calls would order them)
+    {
+        struct Range { const char* lo; const char* hi; };
+        std::vector<Range> w;
+        for (int v = 0; v < n_views; ++v) {
+            const size_t abytes = (size_t)(dim[0] * dim[1] * mvsim_extract_nz(dim[2], params[v].inc)) * sizeof(float);
+            const float* ptr[4] = {outs[v].rot, outs[v].att, outs[v].con, outs[v].acq};
+            for (int a = 0; a < 4; ++a)
+                if (ptr[a]) w.push_back(Range{reinterpret_cast<const char*>(ptr[a]), reinterpret_cast<const char*>(ptr[a]) + (a == 3 ? abytes : vbytes)});
+        }
+        bool meet = false;
+        for (size_t i = 0; i < w.size() && !meet; ++i) {
+            meet = ranges_meet(gt, vbytes, w[i].lo, w[i].hi);
+            for (size_t j = i + 1; j < w.size() && !meet; ++j) meet = w[i].lo < w[j].hi && w[j].lo < w[i].hi;
+        }
+        MVSIM_CHECK_ARG(!meet, "simulate_views: output buffers overlap each other or the ground truth");
+    }
+    const int nl = pick_view_lanes(ctx, dim, n_views);
+    if (nl <= 1) {
+        for (int v = 0; v < n_views; ++v) MVSIM_TRY(mvsim_simulate_view_dev(ctx, gt, dim, psf_host[v], kdim, &params[v], &outs[v], nullptr));
+        return MVSIM_OK;
+    }
+    while ((int)ctx->lanes.size() < nl) {
+        mvsim_ctx* lane = nullptr;
+        MVSIM_TRY(mvsim_create(ctx->device, &lane));
+        lane->is_lane = true;
+        ctx->lanes.push_back(lane);
+        hipEvent_t e = nullptr;
+        MVSIM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->lane_done.push_back(e);
+    }
+    if (!ctx->ev_lane_fork) MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming));
+    // fork: nothing a lane enqueues may overtake what this context's stream holds (the ground truth's producer, say)
+    MVSIM_HIP(hipEventRecord(ctx->ev_lane_fork, ctx->stream));
+    for (int l = 0; l < nl; ++l) {
+        mvsim_ctx* lane = ctx->lanes[(size_t)l];
+        lane->opt = ctx->opt;
+        lane->opt.tail_overlap = 0; lane->opt.graph = 0; lane->opt.view_lanes = 1;
+        MVSIM_HIP(hipStreamWaitEvent(lane->stream, ctx->ev_lane_fork, 0));
+    }
+    int rc = MVSIM_OK;
+    for (int v = 0; v < n_views && rc == MVSIM_OK; ++v) {
+        mvsim_ctx* lane = ctx->lanes[(size_t)(v % nl)];
+        rc = psf_prepare(lane, psf_host[v], kdim, dim);
+        if (rc == MVSIM_OK) rc = view_enqueue(lane, gt, dim, kdim, &params[v], &outs[v], false);
+        ev_rebalance(lane);
+    }
+    // join -- also after a failure: whatever was enqueued is ordered in front of this context's next work
+    for (int l = 0; l < nl; ++l) {
+        mvsim_ctx* lane = ctx->lanes[(size_t)l];
+        if (hipEventRecord(ctx->lane_done[(size_t)l], lane->stream) != hipSuccess ||
+            hipStreamWaitEvent(ctx->stream, ctx->lane_done[(size_t)l], 0) != hipSuccess) {
+            if (rc == MVSIM_OK) { set_error("simulate_views: joining lane %d failed", l); rc = MVSIM_EHIP; }
+        }
+    }
+    return rc;
 }
 
 int mvsim_simulate_iteration_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host, const int64_t kdim[3],
@@ -1397,7 +1404,7 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], f
     if (rc == MVSIM_OK) rc = ctx->out_buf.reserve(obytes);
     dev.acq = ctx->out_buf.as<float>();
     if (rc == MVSIM_OK) rc = mvsim_simulate_view_dev(ctx, gt_d.as<float>(), dim, psf_host, kdim, p, &dev, correction);
-    if (rc == MVSIM_OK) rc = settle_tail(ctx);                // the copies below read what the tail writes
+    if (rc == MVSIM_OK) rc = join_tail(ctx);                // the copies below read what the tail writes
     if (rc == MVSIM_OK && o->rot) rc = down(ctx, o->rot, dev.rot, vbytes);
     if (rc == MVSIM_OK && o->att) rc = down(ctx, o->att, dev.att, vbytes);
     if (rc == MVSIM_OK && o->con) rc = down(ctx, o->con, dev.con, vbytes);
@@ -1509,7 +1516,7 @@ int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt, uint64_t gt_gener
             if (ctx->async_inflight[q]) MVSIM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_d2h[q], 0));
     }
     int rc = mvsim_simulate_view_dev(ctx, ctx->async_gt[s].as<float>(), dim, psf_host, kdim, p, &dev, nullptr);
-    if (rc == MVSIM_OK) rc = settle_tail(ctx);                // the copies below read what the tail writes
+    if (rc == MVSIM_OK) rc = join_tail(ctx);                // the copies below read what the tail writes
     if (rc != MVSIM_OK) { ctx->async_gt_src[s] = nullptr; return rc; }
     {
         double *partial, *scal;
@@ -1574,7 +1581,7 @@ int mvsim_simulate_view_zslabs(mvsim_ctx* ctx, const float* const* gt_slabs, con
     }
     mvsim_view_outputs dev = {nullptr, nullptr, nullptr, ctx->out_buf.as<float>()};
     int rc = mvsim_simulate_view_dev(ctx, ctx->host_gt.as<float>(), dim, psf_host, kdim, p, &dev, correction);
-    if (rc == MVSIM_OK) rc = settle_tail(ctx);                // the copies below read what the tail writes
+    if (rc == MVSIM_OK) rc = join_tail(ctx);                // the copies below read what the tail writes
     z = 0;
     for (int j = 0; j < n_acq_slabs && rc == MVSIM_OK; ++j) {
         if (hipMemcpyAsync(acq_slabs[j], dev.acq + plane * z, (size_t)(plane * acq_slab_nz[j]) * sizeof(float), hipMemcpyDeviceToHost,
@@ -1680,7 +1687,7 @@ int mvsim_extract_slices_zslabs(mvsim_ctx* ctx, const float* const* in_slabs, co
     SyncOnExit sync{ctx};
     MVSIM_TRY(slabs_in(ctx, in_slabs, in_slab_nz, n_in, dim, out_slabs, out_slab_nz, n_out, dim ? mvsim_extract_nz(dim[2], inc) : 0, &in, &out));
     MVSIM_TRY(mvsim_extract_slices_dev(ctx, ctx->vol_a.as<float>(), dim, inc, snr, seed, stream, ctx->vol_b.as<float>()));
-    MVSIM_TRY(settle_tail(ctx));
+    MVSIM_TRY(join_tail(ctx));
     return download_slabs(ctx, out, dim[0] * dim[1], ctx->vol_b.as<float>());
 }
 

@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -75,11 +76,16 @@ int mvsim_comm_init(mvsim_ctx* ctx, int nranks, int rank, const unsigned char id
 // ---- broadcast=peer_copy: the same scatter + all-gather as copy-engine transfers ---------------------------------------
 // RCCL's collectives are kernels: they take CUs from the views that run beside the broadcast.  This form moves the
 // chunks with hipMemcpyAsync between the ranks' buffers -- mapped into each other's processes through IPC handles -- so that
-// the SDMA engines carry them; RCCL is left with two 16-byte all-reduces per broadcast that act as the barriers between the
+// the SDMA engines carry them; RCCL is left with three 16-byte all-reduces per broadcast that act as the barriers between the
 // phases (a rank's all-reduce is enqueued behind its copies, so its completion anywhere implies that every rank's copies of
 // the phase before have landed).
+// The peers' mappings belong to a REGISTRATION (mvsim_comm_register_volume): an explicit collective every rank calls for the
+// buffer it will broadcast into, never a cache looked up by address -- an address that comes back from the allocator on one rank
+// and not on another must not send one rank into a collective the others skip, and a mapping must not outlive the buffer it was
+// made for (mvsim_comm_unregister_volume, mvsim_dev_free of the buffer, mvsim_comm_destroy drop it).
 struct PeerMap {
-    const void*        local = nullptr;      // the buffer of this rank the map belongs to
+    const char*        local = nullptr;      // the registered range of this rank's buffer
+    size_t             bytes = 0;
     std::vector<char*> peer;                 // [rank] -> that rank's buffer in this process's address space (null for me)
     std::vector<void*> opened;               // what hipIpcCloseMemHandle must be called on
 };
@@ -90,29 +96,30 @@ struct PeerCopyState {
     hipEvent_t               fork = nullptr;
     float*                   flag = nullptr; // 16 bytes for the barrier all-reduces
     void*                    xch = nullptr;  // exchange buffer for the handles: nranks * 128 bytes
+    ~PeerCopyState()
+    {
+        for (auto& m : maps)
+            for (void* o : m.opened) (void)hipIpcCloseMemHandle(o);
+        for (hipStream_t s : streams) if (s) (void)hipStreamDestroy(s);
+        for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+        if (fork) (void)hipEventDestroy(fork);
+        if (flag) (void)hipFree(flag);
+        if (xch) (void)hipFree(xch);
+    }
 };
 
 static void peer_copy_release(mvsim_ctx* ctx)
 {
-    PeerCopyState* st = reinterpret_cast<PeerCopyState*>(ctx->peer_copy);
-    if (!st) return;
-    for (auto& m : st->maps)
-        for (void* o : m.opened) (void)hipIpcCloseMemHandle(o);
-    for (hipStream_t s : st->streams) if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : st->done) if (e) (void)hipEventDestroy(e);
-    if (st->fork) (void)hipEventDestroy(st->fork);
-    if (st->flag) (void)hipFree(st->flag);
-    if (st->xch) (void)hipFree(st->xch);
-    delete st;
+    delete reinterpret_cast<PeerCopyState*>(ctx->peer_copy);
     ctx->peer_copy = nullptr;
 }
 
+// the state is published to the context only once every stream, event and buffer exists (a failure half way leaves nothing behind)
 static int peer_copy_state(mvsim_ctx* ctx, PeerCopyState** out)
 {
     if (!ctx->peer_copy) {
-        PeerCopyState* st = new (std::nothrow) PeerCopyState();
+        std::unique_ptr<PeerCopyState> st(new (std::nothrow) PeerCopyState());
         if (!st) { mvsim::set_error("out of host memory"); return MVSIM_ENOMEM; }
-        ctx->peer_copy = st;
         st->streams.assign((size_t)ctx->nranks, nullptr);
         st->done.assign((size_t)ctx->nranks, nullptr);
         for (int r = 0; r < ctx->nranks; ++r) {
@@ -124,16 +131,38 @@ static int peer_copy_state(mvsim_ctx* ctx, PeerCopyState** out)
         MVSIM_HIP(hipMalloc(reinterpret_cast<void**>(&st->flag), 16));
         MVSIM_HIP(hipMemset(st->flag, 0, 16));
         MVSIM_HIP(hipMalloc(&st->xch, (size_t)ctx->nranks * 128));
+        ctx->peer_copy = st.release();
     }
     *out = reinterpret_cast<PeerCopyState*>(ctx->peer_copy);
     return MVSIM_OK;
 }
 
+static void peer_map_close(PeerMap& m)
+{
+    for (void* o : m.opened) (void)hipIpcCloseMemHandle(o);
+    m.opened.clear();
+    m.peer.clear();
+}
+
+// local: forget every registration that meets [p, p + bytes) (bytes == 0: that starts at p or contains it)
+static void peer_copy_forget(mvsim_ctx* ctx, const void* p, size_t bytes)
+{
+    PeerCopyState* st = reinterpret_cast<PeerCopyState*>(ctx->peer_copy);
+    if (!st || !p) return;
+    const char* lo = reinterpret_cast<const char*>(p);
+    const char* hi = lo + (bytes ? bytes : 1);
+    for (size_t i = 0; i < st->maps.size();) {
+        PeerMap& m = st->maps[i];
+        if (lo < m.local + m.bytes && m.local < hi) { peer_map_close(m); st->maps.erase(st->maps.begin() + (long)i); }
+        else ++i;
+    }
+}
+
 // every rank's view of `vol` (same call on every rank, collective): IPC handle of the allocation + offset into it, exchanged
 // through the communicator itself
-static int peer_copy_map(mvsim_ctx* ctx, PeerCopyState* st, float* vol, PeerMap** out)
+static int peer_copy_register(mvsim_ctx* ctx, PeerCopyState* st, float* vol, size_t bytes)
 {
-    for (auto& m : st->maps) if (m.local == vol) { *out = &m; return MVSIM_OK; }
+    peer_copy_forget(ctx, vol, bytes);                       // a registration is replaced, never reused
     struct Record { hipIpcMemHandle_t h; unsigned long long offset; int pid; char pad[128 - sizeof(hipIpcMemHandle_t) - 12]; };
     static_assert(sizeof(Record) == 128, "exchange record");
     Record mine;
@@ -142,6 +171,7 @@ static int peer_copy_map(mvsim_ctx* ctx, PeerCopyState* st, float* vol, PeerMap*
     size_t size = 0;
     MVSIM_HIP(hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, vol));
     mine.offset = (unsigned long long)(reinterpret_cast<char*>(vol) - reinterpret_cast<char*>(base));
+    MVSIM_CHECK_ARG(mine.offset + bytes <= size, "register_volume: the range leaves its allocation");
     mine.pid = (int)getpid();
     if (ctx->nranks > 1) MVSIM_HIP(hipIpcGetMemHandle(&mine.h, base));
     std::vector<Record> all((size_t)ctx->nranks);
@@ -151,22 +181,36 @@ static int peer_copy_map(mvsim_ctx* ctx, PeerCopyState* st, float* vol, PeerMap*
     MVSIM_HIP(hipMemcpyAsync(all.data(), st->xch, all.size() * sizeof(Record), hipMemcpyDeviceToHost, ctx->stream));
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
     PeerMap m;
-    m.local = vol;
+    m.local = reinterpret_cast<const char*>(vol);
+    m.bytes = bytes;
     m.peer.assign((size_t)ctx->nranks, nullptr);
     for (int r = 0; r < ctx->nranks; ++r) {
         if (r == ctx->rank) continue;
         if (all[(size_t)r].pid == mine.pid) {
+            peer_map_close(m);
             mvsim::set_error("broadcast=peer_copy needs one process per rank (ranks %d and %d share a process: use the RCCL forms)", ctx->rank, r);
             return MVSIM_EINVAL;
         }
         void* p = nullptr;
-        MVSIM_HIP(hipIpcOpenMemHandle(&p, all[(size_t)r].h, hipIpcMemLazyEnablePeerAccess));
+        const hipError_t e = hipIpcOpenMemHandle(&p, all[(size_t)r].h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            peer_map_close(m);
+            mvsim::set_error("hipIpcOpenMemHandle (rank %d's buffer) failed: %s", r, hipGetErrorString(e));
+            return MVSIM_EHIP;
+        }
         m.opened.push_back(p);
         m.peer[(size_t)r] = reinterpret_cast<char*>(p) + all[(size_t)r].offset;
     }
     st->maps.push_back(std::move(m));
-    *out = &st->maps.back();
     return MVSIM_OK;
+}
+
+static PeerMap* peer_copy_find(PeerCopyState* st, const float* vol, size_t bytes)
+{
+    const char* p = reinterpret_cast<const char*>(vol);
+    for (auto& m : st->maps)
+        if (m.local == p && bytes <= m.bytes) return &m;
+    return nullptr;
 }
 
 static int peer_copy_barrier(mvsim_ctx* ctx, PeerCopyState* st)
@@ -195,8 +239,11 @@ static int bcast_peer_copy(mvsim_ctx* ctx, float* vol, int64_t count, int root)
 {
     PeerCopyState* st = nullptr;
     MVSIM_TRY(peer_copy_state(ctx, &st));
-    PeerMap* m = nullptr;
-    MVSIM_TRY(peer_copy_map(ctx, st, vol, &m));
+    PeerMap* m = peer_copy_find(st, vol, (size_t)count * sizeof(float));
+    if (!m) {
+        mvsim::set_error("broadcast=peer_copy: the volume is not registered on rank %d (mvsim_comm_register_volume, on every rank, first)", ctx->rank);
+        return MVSIM_EINVAL;
+    }
     const int n = ctx->nranks, me = ctx->rank;
     const int64_t chunk = (count / n) & ~(int64_t)15;
     const int64_t tail = count - chunk * n;
@@ -276,10 +323,29 @@ int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, i
     MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
     MVSIM_CHECK_ARG(root >= 0 && root < ctx->nranks, "root out of range");
     MVSIM_HIP(hipSetDevice(ctx->device));
-    MVSIM_TRY(mvsim::settle_tail(ctx));
+    MVSIM_TRY(mvsim::join_tail(ctx));
     if (count == 0) return MVSIM_OK;
     if (ctx->opt.bcast_peer_copy) return bcast_peer_copy(ctx, vol_dev, count, root);
     for (int phase = 0; phase < 3; ++phase) MVSIM_TRY(bcast_phase(ctx, vol_dev, count, root, phase));
+    return MVSIM_OK;
+}
+
+int mvsim_comm_register_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr && vol_dev != nullptr && count >= 1, "null pointer or empty volume");
+    MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
+    MVSIM_HIP(hipSetDevice(ctx->device));
+    MVSIM_TRY(mvsim::join_tail(ctx));
+    PeerCopyState* st = nullptr;
+    MVSIM_TRY(peer_copy_state(ctx, &st));
+    return peer_copy_register(ctx, st, vol_dev, (size_t)count * sizeof(float));
+}
+
+int mvsim_comm_unregister_volume(mvsim_ctx* ctx, const float* vol_dev)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr && vol_dev != nullptr, "null pointer");
+    (void)hipSetDevice(ctx->device);
+    peer_copy_forget(ctx, vol_dev, 0);
     return MVSIM_OK;
 }
 
@@ -288,7 +354,7 @@ int mvsim_comm_allreduce_sum(mvsim_ctx* ctx, float* buf_dev, int64_t count)
     MVSIM_CHECK_ARG(ctx != nullptr && buf_dev != nullptr && count >= 0, "null pointer or negative count");
     MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
     MVSIM_HIP(hipSetDevice(ctx->device));
-    MVSIM_TRY(mvsim::settle_tail(ctx));
+    MVSIM_TRY(mvsim::join_tail(ctx));
     MVSIM_NCCL(ncclAllReduce(buf_dev, buf_dev, (size_t)count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
     return MVSIM_OK;
 }
@@ -298,7 +364,7 @@ int mvsim_comm_allreduce_sum_f64(mvsim_ctx* ctx, double* value_host)
     MVSIM_CHECK_ARG(ctx != nullptr && value_host != nullptr, "null pointer");
     MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
     MVSIM_HIP(hipSetDevice(ctx->device));
-    MVSIM_TRY(mvsim::settle_tail(ctx));
+    MVSIM_TRY(mvsim::join_tail(ctx));
     MVSIM_TRY(ctx->partials.reserve((mvsim::SUM_BLOCKS + 8) * sizeof(double)));
     double* slot = ctx->partials.as<double>() + mvsim::SUM_BLOCKS + 4;        // scratch behind [sum, corr]
     MVSIM_HIP(hipMemcpyAsync(slot, value_host, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -456,7 +522,7 @@ int mvsim_group_simulate_views(mvsim_group* g, float* const* psf_host, const int
         rc = g->acq[(size_t)i].reserve(obytes);                               // stream order makes the reuse per device safe
         mvsim_view_outputs o = {nullptr, nullptr, nullptr, g->acq[(size_t)i].as<float>()};
         if (rc == MVSIM_OK) rc = mvsim_simulate_view_dev(c, g->gt[(size_t)i].as<float>(), g->dim, psf_host[v], kdim, &params[v], &o, nullptr);
-        if (rc == MVSIM_OK) rc = mvsim::settle_tail(c);                     // the download below reads what the tail writes
+        if (rc == MVSIM_OK) rc = mvsim::join_tail(c);                     // the download below reads what the tail writes
         if (rc == MVSIM_OK && hipMemcpyAsync(acq_host[v], o.acq, obytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
             mvsim::set_error("download of view %d failed", v);
             rc = MVSIM_EHIP;
@@ -470,3 +536,7 @@ int mvsim_group_simulate_views(mvsim_group* g, float* const* psf_host, const int
 }
 
 }  // extern "C"
+
+namespace mvsim {
+void comm_forget_range(mvsim_ctx* ctx, const void* p, size_t bytes) { peer_copy_forget(ctx, p, bytes); }
+}  // namespace mvsim

@@ -134,25 +134,11 @@ struct Options {
                                        // vector issue (0.61 ms against 0.25 + 0.36 ms for pass E and the streaming Poisson kernel
                                        // at 512^3): measured neutral to slightly slower, so off by default
     int     graph = 0;                 // replay simulate_view_dev from a captured hipGraph (small, launch-bound volumes)
+    int     view_lanes = 0;            // mvsim_simulate_views_dev: views in flight side by side (0 = auto: from the size of a view)
     bool    bcast_ring = false;        // ground-truth broadcast as one ncclBroadcast instead of scatter + all-gather
     bool    bcast_peer_copy = false;   // ... or as copy-engine transfers between IPC-mapped buffers (comm.cpp: bcast_peer_copy)
     int64_t fft_pad[3] = {0, 0, 0};    // explicit padded sizes on the rocFFT path (0: choose)
-    int     cu_lo = 0, cu_hi = 0;      // cu_range=a:b: the context's own stream may only use the CUs [a, b) of the mask order
-                                       // (hipExtStreamCreateWithCUMask; 0:0 = all).  Experiments on how kernels share the chip.
-    int     tail_prio = 0;             // tail stream priority: 0 default, > 0 greatest, < 0 least
-    int     tail_cus = 0;              // > 0: the tail stream (extract + Poisson) is confined to that many CUs, see DESIGN 4.5
-    int     exp_guest = -1;            // experiment (tools/guest_probe.py): >= 0: passes B and D carry guest waves running that many Philox blocks
-    int     guest_trips[2] = {-1, -1}; // experiment: trips of phase 1 that ride in pass B / pass D (-1: half each); the rest runs as a kernel
     bool    skip_empty = true;         // convolution passes skip planes the fused rotate kernel found empty (exact; option for A/B runs)
-    bool    guest_tail = false;        // extract + Poisson of view v as GUEST waves inside passes B and D of view v + 1:
-                                       // the sampler is bound by vector issue, the y passes by HBM, and as separate kernels they
-                                       // run one after the other.  Applies where tail_overlap would (device views of >= 2^24
-                                       // voxels on the context's own stream, no graph, no host-visible result) and the y pass can
-                                       // host guests; the tail of the LAST view runs as kernels of its own at the next entry point.
-                                       // Bit-identical; measured neutral (+-1 % per 8 views, profiles/r04_coschedule.txt: two guest waves
-                                       // per SIMD are latency-bound), so OFF by default
-    int     kx_panel = 0;              // > 0: passes B, C', D run panel by panel over kx (that many columns, multiple of 16), so
-                                       // that a panel's intermediates are re-read while still in the Infinity Cache (probe)
 };
 const Options& env_options();
 int parse_option(Options& o, const char* name, const char* value);   // MVSIM_OK / MVSIM_EINVAL
@@ -161,24 +147,6 @@ int parse_option(Options& o, const char* name, const char* value);   // MVSIM_OK
 enum Stage { ST_ROTATE = 0, ST_ATTENUATE, ST_PSF, ST_CONVOLVE, ST_ADJUST, ST_EXTRACT, ST_PASS_A, ST_PASS_B, ST_PASS_C, ST_PASS_D,
              ST_PASS_E, ST_COUNT };
 
-}  // namespace mvsim
-
-namespace mvsim {
-// extract + Poisson of a view that has not been enqueued yet (the arguments of launch_extract): it rides as guest waves in
-// the next view's y passes, or runs as kernels of its own when anything else comes first (flush_tail)
-struct DeferredTail {
-    bool         valid = false;
-    const float* in = nullptr;
-    float*       out = nullptr;
-    int64_t      dim[3] = {0, 0, 0};
-    int          inc = 1, index_inc = 0;
-    bool         adjust = false;
-    const double* scal = nullptr;
-    float        min_value = 0.f;
-    double       mul = 0.0;
-    uint64_t     seed = 0;
-    uint32_t     stream = 0;
-};
 }  // namespace mvsim
 
 struct mvsim_ctx {
@@ -246,8 +214,6 @@ struct mvsim_ctx {
     hipStream_t tail_stream = nullptr;
     hipEvent_t  ev_tail_fork = nullptr, ev_tail = nullptr;
     bool        tail_pending = false;
-    mvsim::DeferredTail deferred;             // guest_tail: the previous view's extract + Poisson, still to be enqueued
-    int         scal_slot = 0;                // which of the two [sum, corr] slots the current view uses (a deferred tail keeps reading the other)
     const char *tail_lo[2] = {nullptr, nullptr}, *tail_hi[2] = {nullptr, nullptr};   // byte ranges the pending tail writes / reads
     mvsim::DevBuf async_gt[ASYNC_SLOTS], async_acq[ASYNC_SLOTS];
     hipEvent_t ev_h2d[ASYNC_SLOTS] = {}, ev_compute[ASYNC_SLOTS] = {}, ev_d2h[ASYNC_SLOTS] = {};
@@ -271,6 +237,13 @@ struct mvsim_ctx {
     std::vector<ViewGraph> graphs;
     std::unordered_set<std::string> graph_seen;
     unsigned long long graph_tick = 0, graph_epoch = 0;
+
+    // mvsim_simulate_views_dev: views that cannot fill the chip one at a time run side by side on LANES -- child contexts of this
+    // one (own stream, own workspaces, same device and options), forked from and joined to this context's stream by events
+    std::vector<mvsim_ctx*> lanes;
+    std::vector<hipEvent_t> lane_done;
+    hipEvent_t  ev_lane_fork = nullptr;
+    bool        is_lane = false;
 
     // RCCL
     void* comm = nullptr;
@@ -359,24 +332,10 @@ struct ConvTail {
     // out: corr_done = the factor is in the context's scalar slot, no separate k_adjust_corr needed
     long long corr_n = 0;
     bool      corr_done = false;
-    // in: the previous view's extract + Poisson, to ride as guest waves in passes B (phase 1) and D (resolver); the caller has
-    // checked fft_can_host_guest for this geometry.  out: guest->valid = false once both are enqueued
-    DeferredTail* guest = nullptr;
-    // in: a tail of the previous view is still running on the tail stream and reads the volume pass E is about to write:
-    // join it (join_tail) in front of pass E
-    bool join_before_e = false;
     // in (with x_done): per-plane flags the fused rotate kernel has set (1 = the attenuated plane holds a non-zero voxel; device
     // array of dim[2] ints): passes B .. E skip the planes whose inputs are all empty -- exact, their spectra are zero
     const int* plane_nz = nullptr;
 };
-// true when the hand-written convolution of this geometry runs y passes that can carry the sampler as guest waves
-bool fft_can_host_guest(mvsim_ctx* ctx, const int64_t dim[3], const int64_t kdim[3]);
-// enqueue a deferred tail as kernels of its own on the context's stream (no-op without one)
-int  flush_tail(mvsim_ctx* ctx);
-// join_tail + flush_tail: after it everything the last view produces is ordered on ctx->stream
-int  settle_tail(mvsim_ctx* ctx);
-// bytes of the Poisson work queue when `blocks` blocks share the n_out voxels (blocks <= 0: the stand-alone geometry)
-size_t poisson_queue_bytes_blocks(int64_t n_out, long long blocks);
 // bytes of queue workspace the fused tail needs for this geometry (0: the geometry has no fused tail)
 size_t fused_tail_queue_bytes(const int64_t dim[3], const int64_t kdim[3], int inc, bool con_wanted, const Options& opt);
 // plane / idx_inc / index_offset: how the RNG counter of an output element follows from its position (ResolveJob)
@@ -445,9 +404,11 @@ inline void ev_next(mvsim_ctx* ctx)
     for (int s = 0; s < ST_COUNT; ++s) ctx->ev_used[ctx->ev_cur][s] = false;
 }
 
-// [sum, adjustImage factor] of the current view: two slots behind the block partials, so that a deferred tail (guest_tail) still
-// finds its view's factor after the next view's sum has been reduced
-inline double* scal_of(mvsim_ctx* ctx) { return ctx->partials.as<double>() + SUM_BLOCKS + 2 * ctx->scal_slot; }
+// [sum, adjustImage factor] of the current view, behind the block partials
+inline double* scal_of(mvsim_ctx* ctx) { return ctx->partials.as<double>() + SUM_BLOCKS; }
+
+// comm.cpp: a device range is about to go away -- drop the peer mappings registered for it (broadcast=peer_copy)
+void comm_forget_range(mvsim_ctx* ctx, const void* p, size_t bytes);
 
 void axis_rotation_host(const int64_t dim[3], int axis, int degrees, double m[12]);
 void affine_invert_host(const double m[12], double inv[12]);

@@ -64,14 +64,6 @@ struct LinesArgs {
     const double2* wx;
     const double2* wy;
     double*       sum_partial;
-    // GW > 0 (guest waves, see k_fft_lines): work the block's extra waves do beside the transform
-    struct Guest {
-        int        kind;            // 0: none, 1: phase 1 of the sampler, 2: the resolver, 3: experiment (chain of `nseg` Philox blocks per wave)
-        long long  nseg;            // resolver: queue segments (dealt over the blocks of this launch)
-        int        it0, it1;        // phase 1: the trips [it0, it1) of every block's walk (p1_block_body)
-        P1Job      p1;
-        ResolveJob rs;
-    } guest;
 };
 
 #ifndef MVSIM_ZBS
@@ -100,22 +92,8 @@ __device__ __forceinline__ long long line_off(int n, long long es, long long blk
 // second launch bound: as many blocks as the LDS lets a CU hold (two, or one for the long lines) must stay resident
 // (w = blocks*T/256 waves per SIMD, rounded up) -- the register budget follows from that
 template <int L> constexpr int lines_blocks_per_cu() { return 2 * Cfg<L>::LDS <= 160 * 1024 ? 2 : 1; }
-// guest waves (below): four per block -- one per SIMD; two measured no better than none, because both land on the same two
-// SIMDs of every block -- with their 1.1 KB of sampler scratch each behind the tile.  Only tiles that leave that room with
-// two blocks per CU, and that are large enough for the transform to need the time (eight waves), host guests.
-constexpr int LINES_GW = 4;
-template <int L> constexpr size_t lines_guest_lds() { return ((Cfg<L>::LDS + 15) & ~(size_t)15) + LINES_GW * sizeof(P1Scratch); }
-template <int L> constexpr bool lines_guest_capable()
-{
-    return lines_blocks_per_cu<L>() == 2 && 2 * lines_guest_lds<L>() <= 160 * 1024 && Cfg<L>::NW == 8;
-}
-
-// GW: guest waves per block.  The y passes are tile copies at 85 % of the HBM copy ceiling that leave half of the vector
-// issue slots idle; GW extra waves per block use them for work that needs no HBM bandwidth to speak of -- the
-// Poisson sampler of the PREVIOUS view (vector-issue-bound).  Guests share nothing with the transform but the CU: the
-// transform's two block barriers become waves_barrier over its own NW waves.
-template <class PLAN, int MODE, bool SPARSE, int GW = 0>
-__global__ __launch_bounds__(Cfg<PLAN::len>::T + 64 * GW, (lines_blocks_per_cu<PLAN::len>() * (Cfg<PLAN::len>::T + 64 * GW) + 255) / 256)
+template <class PLAN, int MODE, bool SPARSE>
+__global__ __launch_bounds__(Cfg<PLAN::len>::T, (lines_blocks_per_cu<PLAN::len>() * Cfg<PLAN::len>::T + 255) / 256)
 void k_fft_lines(LinesArgs p)
 {
     constexpr int L = PLAN::len;
@@ -131,38 +109,9 @@ void k_fft_lines(LinesArgs p)
     const int c2 = (tid % LPR) * 2;
     const int r0 = tid / LPR;
     float2* wbuf = buf + wave * LW * LP;    // the lines this wave transforms
-    unsigned int* bar = reinterpret_cast<unsigned int*>(lds + NL * LP + L);   // Cfg::LDS leaves 256 bytes behind the twiddles
-    if (GW > 0) {
-        // bar[0]: the transform waves' barrier counter; bar[1]: the guests'; bar[2..3]: the guests' queue counters / ticket
-        if (tid < 4) bar[tid] = 0u;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (wave >= NW) {
-            __builtin_amdgcn_s_setprio(3);                    // measured: guests at default priority crawl (B + half of phase 1: 0.55 ms; with it 0.52)
-            const int t = tid - T;
-            const long long gb = (long long)blockIdx.y * gridDim.x + blockIdx.x, gn = (long long)gridDim.x * gridDim.y;
-            WavesBarrier gbar{bar + 1, (unsigned int)GW, 0u, lane};
-            P1Scratch* sc = reinterpret_cast<P1Scratch*>(reinterpret_cast<char*>(lds) + ((C::LDS + 15) & ~(size_t)15));
-            if (p.guest.kind == 1) {
-                p1_block_body<true, true>(p.guest.p1, gb, gn, t, sc, bar + 2, gbar, p.guest.it0, p.guest.it1, p.guest.it0 > 0);
-            } else if (p.guest.kind == 2) {
-                for (long long seg = gb; seg < p.guest.nseg; seg += gn) {
-                    resolve_segment_body(p.guest.rs, seg, t, bar + 2, gbar);
-                    gbar();                                   // the ticket is reset for the next segment
-                }
-            } else if (p.guest.kind == 3) {
-                // experiment (tools/guest_probe.py): the sampler's instruction mix without its memory traffic
-                Philox4 r = Philox4{(uint32_t)tid, blockIdx.x, blockIdx.y, 7u};
-                for (long long i = 0; i < p.guest.nseg; ++i) r = philox4x32_10(r.x, r.y, r.z, r.w, 0x1234u + (uint32_t)i, 0x5678u);
-                if ((r.x ^ r.y ^ r.z ^ r.w) == 0x9E3779B9u && p.guest.rs.out) p.guest.rs.out[0] = (float)r.x;
-            }
-            return;
-        }
-    }
-
     // all global loads of the tile are issued before anything waits
     const int by = (int)blockIdx.y >= p.outer_skip_lo ? (int)blockIdx.y + p.outer_skip_len : (int)blockIdx.y;
-    if (GW == 0 && p.nzflags) {
+    if (p.nzflags) {
         // block-uniform (one scalar load): nothing of an empty plane is read, transformed or stored -- its readers skip it on the
         // same flags.  Pass B: flags of the input planes; pass D: the dilated flags (a plane of the z pass's output is empty iff
         // every plane its Kz taps reach is), outer index k = plane k * nz_stride
@@ -228,7 +177,7 @@ void k_fft_lines(LinesArgs p)
             buf[(c2 + 1) * LP + n] = b;
         }
     }
-    if (GW > 0) waves_barrier(bar, NW, lane); else __syncthreads();
+    __syncthreads();
     PLAN::template run<LW>(wbuf, tw, lane);
     if (MODE == CONV) {
         // x PSF spectrum, conjugate, transform again (inverse = conj FFT conj).  The spectrum is stored tile-major
@@ -249,7 +198,7 @@ void k_fft_lines(LinesArgs p)
             }
         return;
     }
-    if (GW > 0) waves_barrier(bar, 2 * NW, lane); else __syncthreads();
+    __syncthreads();
     float2* dbase = p.dst + outer_off(p.dst_outer, p.dst_oblk) + (long long)blockIdx.x * NL + c2;
     const int nstore = p.store_limit > 0 ? p.store_limit : L;
     float2 sa = make_float2(0.f, 0.f), sb = make_float2(0.f, 0.f);       // CONVZ: this thread's share of its two lines' sums over z
@@ -1369,25 +1318,6 @@ static int launch_lines_t(mvsim_ctx* ctx, int mode, bool sparse, const LinesArgs
         MVSIM_TRY(set_lds(ctx, k_fft_lines<PLAN, MODE_, SP_>, C::LDS));                           \
         hipLaunchKernelGGL((k_fft_lines<PLAN, MODE_, SP_>), grid, block, C::LDS, s, a);      \
     } while (0)
-    if (a.guest.kind != 0) {
-        if constexpr (lines_guest_capable<PLAN::len>()) {
-            if (sparse || mode == CONV) { set_error("guest waves ride on the plain y passes only"); return MVSIM_EINVAL; }
-            constexpr size_t glds = lines_guest_lds<PLAN::len>();
-            dim3 gblock(C::T + 64 * LINES_GW);
-            if (mode == FWD) {
-                MVSIM_TRY(set_lds(ctx, k_fft_lines<PLAN, FWD, false, LINES_GW>, glds));
-                hipLaunchKernelGGL((k_fft_lines<PLAN, FWD, false, LINES_GW>), grid, gblock, glds, s, a);
-            } else {
-                MVSIM_TRY(set_lds(ctx, k_fft_lines<PLAN, INV, false, LINES_GW>, glds));
-                hipLaunchKernelGGL((k_fft_lines<PLAN, INV, false, LINES_GW>), grid, gblock, glds, s, a);
-            }
-            MVSIM_HIP(hipGetLastError());
-            return MVSIM_OK;
-        } else {
-            set_error("guest waves: the y pass of length %d cannot host them", PLAN::len);
-            return MVSIM_EINVAL;
-        }
-    }
     if (mode == FWD && sparse) MVSIM_LL(FWD, true);
     else if (mode == FWD) MVSIM_LL(FWD, false);
     else if (mode == INV) MVSIM_LL(INV, false);
@@ -1497,17 +1427,6 @@ static int lines_per_tile(int L)
     return 16;
 }
 
-template <int L> static constexpr bool guest_capable_of() { return lines_guest_capable<L>(); }
-static bool lines_can_host(int L)
-{
-    switch (L) {
-#define X(LL, ...) case LL: return guest_capable_of<LL>();
-        MVSIM_FFT_SIZES(X)
-#undef X
-    }
-    return false;
-}
-
 static int pick_size(int64_t need)
 {
     for (int v : kSizes)
@@ -1534,19 +1453,6 @@ bool custom_fft_sizes(const int64_t dim[3], const int64_t kdim[3], int64_t P[3],
         }
     }
     return true;
-}
-
-bool fft_can_host_guest(mvsim_ctx* ctx, const int64_t dim[3], const int64_t kdim[3])
-{
-    using namespace fft;
-    int64_t P[3];
-    if (!custom_fft_sizes(dim, kdim, P, ctx->opt)) return false;
-    const bool zdirect = ctx->opt.zpass == 2 ? false : kdim[2] <= 64;
-    if (!zdirect || ctx->opt.kx_panel > 0 || ctx->opt.fuse_tail || !lines_can_host((int)P[1])) return false;
-    const int tile_y = lines_per_tile((int)P[1]);
-    const int tw_max = tile_y > NLZ ? tile_y : NLZ;
-    const int hxp = (((int)(P[0] / 2) + 1 + tw_max - 1) / tw_max) * tw_max;
-    return (long long)(hxp / tile_y) * dim[2] <= 256 * 64;        // one queue segment per block of pass B
 }
 
 // kind 0: per-pass transform table of the plan for length L (see wpasses); kind 1: plain exp(-2 pi i k / L),
@@ -1813,7 +1719,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     // compact planes: the direct form computes 1 / zstride of the planes (k_zconv_strided) and is then ahead of the inline FFT at every depth
     int zs_frows = 0;
     size_t zs_lds = 0;
-    const int zs_chunk = (zdirect && zstride > 1 && ctx->opt.zconv_strided && ctx->opt.zpass != 3 && ctx->opt.kx_panel == 0)
+    const int zs_chunk = (zdirect && zstride > 1 && ctx->opt.zconv_strided && ctx->opt.zpass != 3)
                              ? zconv_strided_chunk(slab.nz_out, kz, zstride, (ctx->opt.exp & 2) != 0, &zs_frows, &zs_lds) : 0;
     const bool zinline = zdirect && !is_slab && zs_chunk == 0 &&
                          (ctx->opt.zpass == 3 || (ctx->opt.zpass == 0 && kz >= MVSIM_ZINLINE_MIN_KZ && pz >= 512 && lines_per_tile(pz) == 16));
@@ -1925,61 +1831,14 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
             b.dst = G; b.dst_outer = (long long)ZB * hxp; b.dst_blk = (long long)nzs * ZB * hxp;
         }
-        // kx panels (option kx_panel, probe): passes B, C', D are independent per kx column, so they can run back to back on a
-        // panel of columns whose two intermediates (2 x Nz x Py x cols x 8 B) fit the 256 MiB Infinity Cache
-        const int pcols = (zdirect && !is_slab && ctx->opt.kx_panel > 0 && ctx->opt.kx_panel % tile_y == 0 && ctx->opt.kx_panel % NLZ == 0)
-                              ? ctx->opt.kx_panel : 0;
-        if (pcols > 0) {
-            ev_begin(ctx, ST_PASS_B);
-            if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
-            ZConvArgs z{};
-            z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
-            z.zs = (long long)ZB * hxp; z.src_blk = (long long)nzs * ZB * hxp; z.dst_blk = (long long)nzo * ZB * hxp;
-            z.taps_blk = (long long)kz * ZB * hxp;
-            z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
-            z.zc = zconv_chunk(nzo, kz);
-            const float scale_f = (float)(0.25 / ((double)px * (double)py));
-            const double2 *wx0 = nullptr;
-            long long zblocks = 0;
-            if (early) {
-                MVSIM_TRY(ensure_box_weights(ctx, (int)dim[0], px, hxp, true, &wx0));
-                MVSIM_TRY(ensure_box_weights(ctx, (int)dim[1], py, py, false, &z.wy));
-                zblocks = zconv_blocks(z, py);
-                MVSIM_TRY(ctx->partials_z.reserve((size_t)zblocks * sizeof(double)));
-            }
-            const int nk = (nzo - 1) / zstride + 1;
-            long long sum_off = 0;
-            for (int c0 = 0; c0 < hxp; c0 += pcols) {
-                const int cols = std::min(pcols, hxp - c0);
-                LinesArgs pb = b;
-                pb.src = F + c0; pb.dst = G + c0;
-                MVSIM_TRY(launch_lines(ctx, py, FWD, false, pb, cols / tile_y, nzs));
-                z.src = G + c0; z.dst = F + c0; z.taps = G2 + c0;
-                if (early) { z.wx = wx0 + c0; z.sum_partial = ctx->partials_z.as<double>() + sum_off; sum_off += zconv_blocks(z, py, cols); }
-                MVSIM_TRY(launch_zconv(ctx, z, py, cols));
-                LinesArgs pd = b;
-                pd.lmap = ident_none; pd.src_mirror = 0; pd.gap_lo = pd.gap_hi = 0; pd.outer_skip_lo = 1 << 30; pd.outer_skip_len = 0;
-                pd.tw = tw_py; pd.store_limit = (int)dim[1];
-                pd.src = F + c0; pd.src_outer = (long long)ZB * hxp * zstride; pd.src_blk = (long long)nzo * ZB * hxp;
-                pd.dst = G + c0; pd.dst_outer = plane * zstride; pd.dst_blk = 0;
-                MVSIM_TRY(launch_lines(ctx, py, INV, false, pd, cols / tile_y, nk));
-            }
-            if (early) {
-                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, ctx->partials_z.as<double>(), zblocks, scal, (double)scale_f,
-                                   corr_n, corr_min, corr_target);
-                MVSIM_HIP(hipGetLastError());
-            }
-            ev_end(ctx, ST_PASS_B);
-        }
         float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
         const int* em_flags = nullptr;                                // planes passes D and E skip (see pnz below)
         const int nzd = zdirect ? nzo : (int)dim[2];                  // planes z >= Nz are never read
         const int nk = (nzd - 1) / zstride + 1;                       // planes 0, zstride, 2 zstride, ...
-        if (pcols > 0) Fz = G;
-        else {
+        {
         // planes the fused rotate kernel found empty: B skips them, C' does not load them and skips tiles made of nothing else, D and E
         // skip the planes whose taps reach nothing but empty planes (exact: their spectra are zero) -- a specimen in empty space
-        const int* pnz = (tail && tail->x_done && tail->plane_nz && zdirect && !zinline && !is_slab && !fuse && !(tail->guest && tail->guest->valid))
+        const int* pnz = (tail && tail->x_done && tail->plane_nz && zdirect && !zinline && !is_slab && !fuse)
                              ? tail->plane_nz : nullptr;
         const int* pnz_dil = nullptr;
         const unsigned int* pnz_bits = nullptr;
@@ -1997,42 +1856,10 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             pnz_bits = reinterpret_cast<const unsigned int*>(base + 2 * dim[2]);
             b.nzflags = pnz; b.nz_stride = 1;
         }
-        // the previous view's extract + Poisson as guest waves: phase 1 beside pass B, the resolver beside pass D (option guest_tail)
-        DeferredTail* guest = (tail && tail->guest && tail->guest->valid && zdirect && !is_slab && !fuse) ? tail->guest : nullptr;
-        if (tail && tail->guest && tail->guest->valid && (!guest || !lines_can_host(py))) {
-            set_error("guest tail: this convolution cannot carry the previous view's sampler (the caller must flush it first)");
-            return MVSIM_EINVAL;
-        }
-        const long long gblocks = (long long)(hxp / tile_y) * nzs;
-        ResolveJob guest_rs{};
-        long long guest_trips = 0, guest_split = 0, guest_end = 0;
-        P1Job guest_p1{};
-        if (guest) {
-            const int64_t n_out = guest->dim[0] * guest->dim[1] * ((guest->dim[2] - 1) / guest->inc + 1);
-            MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_blocks(n_out, gblocks)));
-            b.guest.kind = 1;
-            if (!poisson_make_jobs(*guest, gblocks, ctx->pqueue.p, &b.guest.p1, &guest_rs)) {
-                set_error("guest tail: the deferred extract + Poisson cannot take the vector path");
-                return MVSIM_EINVAL;
-            }
-            // phase 1 is dealt over the two y passes (half of every block's trips each) when pass D runs the same grid
-            guest_trips = (long long)(b.guest.p1.segcap / 1024u);
-            guest_split = (nzo == nzs && zstride == 1) ? (guest_trips + 1) / 2 : guest_trips;
-            guest_end = guest_trips;
-            if (ctx->opt.guest_trips[0] >= 0) {
-                guest_split = std::min<long long>(ctx->opt.guest_trips[0], guest_trips);
-                guest_end = (nzo == nzs && zstride == 1) ? std::min<long long>(guest_split + std::max(ctx->opt.guest_trips[1], 0), guest_trips) : guest_split;
-            }
-            b.guest.it0 = 0; b.guest.it1 = (int)guest_split;
-            if (guest_split == 0) b.guest.kind = 0;
-        } else if (ctx->opt.exp_guest >= 0 && zdirect && !is_slab && lines_can_host(py)) {
-            b.guest.kind = 3; b.guest.nseg = ctx->opt.exp_guest;
-        }
         ev_begin(ctx, ST_PASS_B);
         MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
         ev_end(ctx, ST_PASS_B);
         b.lmap = ident_none; b.src_mirror = 0;
-        if (guest) { guest_p1 = b.guest.p1; b.guest.kind = guest_split < guest_end ? 1 : 0; b.guest.it0 = (int)guest_split; b.guest.it1 = (int)guest_end; }
         if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));    // the z pass reads the PSF spectrum
         ev_begin(ctx, ST_PASS_C);
         b.gap_lo = b.gap_hi = 0; b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
@@ -2113,14 +1940,6 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         MVSIM_TRY(launch_lines(ctx, py, INV, false, b, hxp / tile_y, nk));
         ev_end(ctx, ST_PASS_D);
         b.nzflags = nullptr;
-        if (guest) {
-            if (guest_end < guest_trips) MVSIM_TRY(launch_poisson_phase1(s, guest_p1, gblocks, (int)guest_end, (int)guest_trips, guest_end > 0));
-            // the resolver as a kernel of its own: its work items are dependent 32-byte reads, nothing a guest wave can wait for
-            MVSIM_TRY(launch_poisson_resolve(s, guest_rs.out, const_cast<PItem*>(guest_rs.queue), guest_rs.qcount, (int)gblocks, guest_rs.segcap,
-                                             guest_rs.mul, guest->seed, guest_rs.stream, guest_rs.plane, (int)guest_rs.idx_inc, 0));
-            guest->valid = false;                                     // all of it is enqueued
-        }
-        b.guest.kind = 0;
         }
         C2RFuse fz{};
         if (fuse) {
@@ -2144,7 +1963,6 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
                 fz.segcap = fsegcap;
             }
         }
-        if (tail && tail->join_before_e) MVSIM_TRY(join_tail(ctx));
         ev_begin(ctx, ST_PASS_E);
         // both half spectra carry the factor 2 left in by pass A (see k_fft_x_r2c): 2 * 2 = 4
         const float scale = (float)(0.25 / ((double)px * (double)py * ((zdirect && !zinline) ? 1.0 : (double)pz)));

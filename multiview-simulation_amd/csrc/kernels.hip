@@ -833,30 +833,12 @@ __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict
     }
 }
 
-// the same phase 1 restricted to the trips [it0, it1) of every block's walk, continuing a segment (what guest waves left over)
-__global__ __launch_bounds__(256) void k_extract4_noise2_part(P1Job job, int it0, int it1, int resume)
-{
-    __shared__ unsigned int ctr[2];
-    __shared__ P1Scratch scratch[4];
-    BlockBarrier bar;
-    p1_block_body<true, false>(job, (long long)blockIdx.x, (long long)gridDim.x, (int)threadIdx.x, scratch, ctr, bar, it0, it1, resume != 0);
-}
-
-// the trips [it0, it1) of phase 1 as a kernel of its own over `blocks` blocks (what guest waves left over: resume = 1)
-int launch_poisson_phase1(hipStream_t s, const P1Job& job, long long blocks, int it0, int it1, bool resume)
-{
-    hipLaunchKernelGGL(k_extract4_noise2_part, dim3((unsigned)blocks), dim3(256), 0, s, job, it0, it1, resume ? 1 : 0);
-    MVSIM_HIP(hipGetLastError());
-    return MVSIM_OK;
-}
-
 // One block per queue segment (same grid as k_extract4_noise2; the grid-stride walk of that kernel spreads the
 // bright voxels evenly over the segments).
 __global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job)
 {
     __shared__ unsigned int ticket;
-    BlockBarrier bar;
-    resolve_segment_body(job, (long long)blockIdx.x, (int)threadIdx.x, &ticket, bar);
+    resolve_segment_body(job, (long long)blockIdx.x, (int)threadIdx.x, &ticket);
 }
 
 int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
@@ -888,40 +870,6 @@ size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)
     poisson_geometry(n_out, &blocks, &segcap);
     if (capacity) *capacity = (unsigned long long)blocks * segcap;
     return (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);   // [counts][segments]
-}
-
-static unsigned int segcap_for_blocks(int64_t n_out, long long blocks)
-{
-    const long long iters = (n_out / 4 + blocks * 256 - 1) / (blocks * 256);
-    return (unsigned int)(iters * 1024);
-}
-
-size_t poisson_queue_bytes_blocks(int64_t n_out, long long blocks)
-{
-    if (blocks <= 0) return poisson_queue_bytes(n_out, nullptr);
-    return (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap_for_blocks(n_out, blocks) * sizeof(PItem);
-}
-
-static bool extract_vec_ok(const float* in, const float* out, long long plane, uint64_t index_offset)
-{
-    return (plane % 4 == 0) && (index_offset % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
-}
-
-bool poisson_make_jobs(const DeferredTail& t, long long blocks, void* queue_ws, P1Job* p1, ResolveJob* rs)
-{
-    const int index_inc = t.index_inc > 0 ? t.index_inc : t.inc;
-    const long long plane = (long long)t.dim[0] * t.dim[1];
-    const long long nzo = (t.dim[2] - 1) / t.inc + 1;
-    if (!extract_vec_ok(t.in, t.out, plane, 0) || blocks < 1 || blocks > POISSON_MAX_BLOCKS || !queue_ws ||
-        (long long)(index_inc - 1) * plane >= (1ll << 31) || plane * nzo >= (1ll << 32))
-        return false;
-    const unsigned int segcap = segcap_for_blocks(plane * nzo, blocks);
-    unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
-    PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int));
-    const uint32_t k0 = (uint32_t)t.seed, k1 = (uint32_t)(t.seed >> 32);
-    *p1 = P1Job{t.in, t.out, plane / 4, nzo, t.inc, index_inc, t.scal, t.min_value, t.mul, k0, k1, t.stream, 0ull, queue, qcount, segcap};
-    *rs = ResolveJob{t.out, queue, qcount, segcap, t.mul, k0, k1, t.stream, (unsigned int)plane, (unsigned int)index_inc, 0ull};
-    return true;
 }
 
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,

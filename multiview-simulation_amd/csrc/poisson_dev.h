@@ -601,120 +601,10 @@ __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, un
 }
 
 
-// ------------------------------------------------------------------------------------------------------------
-// The two production sampler kernels as BLOCK BODIES: 256 lanes that share a queue segment.  They run as kernels of their
-// own (k_extract4_noise2, k_poisson_resolve: kernels.hip) and as GUEST waves inside the convolution's y passes of the next
-// view (k_fft_lines<.., GW>: fft_kernels.hip), where the vector-issue-bound sampler fills the issue slots an HBM-bound tile
-// copy leaves idle.  The only thing that differs is the barrier: a kernel's own __syncthreads, or a counter barrier over
-// the guest waves alone.
-// ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float adjust_one(float v, double corr, float min_value)
 {
     const float t = (float)((double)v * corr);  // pass 1, Tools.java:150-151
     return t + min_value;                       // pass 2, Tools.java:154-155 (second rounding, Q6)
-}
-
-// Barrier among `n` waves of a block through a monotonic LDS counter (the block's other waves never take part, so they may
-// run for as long as they like).  LDS operations of a wave execute in issue order: the add lands behind the wave's earlier
-// LDS writes, the reads behind the poll that saw every add.
-__device__ __forceinline__ void waves_barrier(unsigned int* cnt, unsigned int target, int lane)
-{
-    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-}
-
-struct BlockBarrier {
-    __device__ __forceinline__ void operator()() { __syncthreads(); }
-};
-struct WavesBarrier {                 // `nwaves` waves meet on *cnt (zeroed before the first use)
-    unsigned int* cnt;
-    unsigned int  nwaves, target;
-    int           lane;
-    __device__ __forceinline__ void operator()() { target += nwaves; waves_barrier(cnt, target, lane); }
-};
-
-// Phase 1 over a volume: `nblocks` blocks of 256 lanes x 4 voxels walk the extracted planes with a grid stride
-// (SimulateMultiViewDataset.java:195-251, Tools.java:73-86 with adjustImage folded in when `scal` is given).
-struct P1Job {
-    const float*  in;
-    float*        out;
-    long long     plane4, nzo;        // float4 groups per plane, extracted planes
-    int           inc, idx_inc;       // plane stride of the reads / of the RNG counter
-    const double* scal;               // scal[1] = adjustImage's factor (ADJUST)
-    float         min_value;
-    double        mul;
-    uint32_t      k0, k1, stream;
-    unsigned long long index_offset;
-    PItem*        queue;
-    unsigned int* qcount;
-    unsigned int  segcap;
-};
-
-// it0, it1: the block's trips [it0, it1) of the grid-stride walk (a trip = one 1024-voxel slot per wave); resume: the
-// segment already holds the items of earlier trips (counters from qcount).  PREFETCH: the next trip's voxels are requested
-// before this trip's are worked on -- for guest waves, which have no other wave to hide the load behind.
-template <bool ADJUST, bool PREFETCH, class BAR>
-__device__ __forceinline__ void p1_block_body(const P1Job& j, long long block, long long nblocks, int t, P1Scratch* scratch4,
-                                              unsigned int* ctr, BAR& bar, int it0, int it1, bool resume)
-{
-    if (t == 0) { ctr[0] = resume ? j.qcount[2 * block] : 0u; ctr[1] = resume ? j.qcount[2 * block + 1] : 0u; }
-    bar();
-    const int lane = t & 63, wave = t >> 6;
-    P1Args pa;
-    pa.mul = j.mul; pa.mulf = (float)j.mul; pa.k0 = j.k0; pa.k1 = j.k1; pa.stream = j.stream;
-    pa.seg = j.queue + (unsigned long long)block * j.segcap; pa.segcap = j.segcap; pa.nq = &ctr[0]; pa.nqs = &ctr[1];
-    double corr = 1.0;
-    if (ADJUST) corr = j.scal[1];
-    const long long total4 = j.plane4 * j.nzo;
-    const long long nthreads = nblocks * 256;
-    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(j.in);
-    float4* __restrict__ out4 = reinterpret_cast<float4*>(j.out);
-    const bool small32 = total4 < (1ll << 32);
-    const bool strided = j.inc != 1 || j.idx_inc != 1;
-    // the trip count is uniform per wave (lanes past the end carry invalid voxels): ballots need every lane
-    // (it1 never exceeds the block's trip count segcap / 1024, so it1 * nthreads stays within a trip of total4: no overflow, no division)
-    const long long wave_first = block * 256 + wave * 64 + (long long)it0 * nthreads;
-    const long long wave_end = total4 < (long long)it1 * nthreads ? total4 : (long long)it1 * nthreads;
-    auto source = [&](long long o, long long& idx4) {
-        long long src4 = o; idx4 = o;                 // where the voxels are read / what the RNG counter says they are
-        if (strided) {
-            const long long k = small32 ? (long long)((unsigned)o / (unsigned)j.plane4) : o / j.plane4;
-            src4 = k * j.inc * j.plane4 + (o - k * j.plane4);
-            idx4 = k * j.idx_inc * j.plane4 + (o - k * j.plane4);
-        }
-        return src4;
-    };
-    float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
-    long long inext = 0;
-    if (PREFETCH && wave_first < wave_end && wave_first + lane < total4) vnext = in4[source(wave_first + lane, inext)];
-    for (long long o0 = wave_first; o0 < wave_end; o0 += nthreads) {
-        const long long o = o0 + lane;
-        const bool valid = o < total4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        long long idx4 = o;
-        if (PREFETCH) {
-            v = vnext; idx4 = inext;
-            const long long on = o + nthreads;
-            if (o0 + nthreads < wave_end && on < total4) vnext = in4[source(on, inext)];
-        } else if (valid) {
-            v = in4[source(o, idx4)];
-        }
-        if (valid && ADJUST) {
-            v.x = adjust_one(v.x, corr, j.min_value);
-            v.y = adjust_one(v.y, corr, j.min_value);
-            v.z = adjust_one(v.z, corr, j.min_value);
-            v.w = adjust_one(v.w, corr, j.min_value);
-        }
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        float ov[4];
-        poisson_phase1(vv, valid, j.index_offset + 4ull * (unsigned long long)idx4, 4ull * (unsigned long long)o, pa, &scratch4[wave], lane, ov);
-        if (valid) out4[o] = make_float4(ov[0], ov[1], ov[2], ov[3]);
-    }
-    bar();
-    if (t == 0) {
-        j.qcount[2 * block] = ctr[0];
-        j.qcount[2 * block + 1] = ctr[1];
-    }
 }
 
 struct ResolveJob {
@@ -730,9 +620,8 @@ struct ResolveJob {
     unsigned long long  index_offset;
 };
 
-// One queue segment resolved by 256 lanes.
-template <class BAR>
-__device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long long segment, int t, unsigned int* ticket, BAR& bar)
+// One queue segment resolved by the 256 lanes of a block (k_poisson_resolve: kernels.hip).
+__device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long long segment, int t, unsigned int* ticket)
 {
     const unsigned int n = j.qcount[2 * segment], ns = j.qcount[2 * segment + 1];
     const PItem* __restrict__ seg = j.queue + (unsigned long long)segment * j.segcap;
@@ -746,7 +635,7 @@ __device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long l
     // item -- retries come in geometrically distributed numbers -- has been accepted.  The loop ends when the tickets run
     // out: each attempt succeeds with probability > 0.8 and the attempt count is capped, so every lane gets there.
     if (t == 0) *ticket = 256u;
-    bar();
+    __syncthreads();
     unsigned int i = (unsigned int)t;
     PItem it;
     it.out = 0u; it.v = 0.f; it.w0 = 0u; it.w1 = 0u;
@@ -782,11 +671,5 @@ __device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long l
         }
     }
 }
-
-// host: the two jobs of a deferred tail when `blocks` blocks (of 256 lanes) share its voxels; queue_ws holds
-// poisson_queue_bytes_blocks(n_out, blocks) bytes.  False when the tail cannot take the vector path (unaligned, odd plane).
-struct DeferredTail;
-bool poisson_make_jobs(const DeferredTail& t, long long blocks, void* queue_ws, P1Job* p1, ResolveJob* rs);
-int  launch_poisson_phase1(hipStream_t s, const P1Job& job, long long blocks, int it0, int it1, bool resume);
 
 }  // namespace mvsim

@@ -34,6 +34,8 @@ def main():
         d = c.dev_alloc(n * 4)
         for form in ("scatter_allgather", "ring", "peer_copy", "peer_copy"):
             c.set_option("broadcast", form)
+            if form == "peer_copy":
+                c.comm_register_volume(d, n)            # collective; the second round replaces the first registration
             c.upload(d, truth if rank == 0 else np.full(n, -1.0, np.float32))
             c.comm_broadcast_volume(d, n, 0)
             c.synchronize()

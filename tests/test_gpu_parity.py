@@ -1143,10 +1143,24 @@ def test_rccl_entry_points_single_rank(mvs, synth):
             c.set_option("broadcast", "ring")
             c.comm_broadcast_volume(d, vol.size, 0)
             c.set_option("broadcast", "peer_copy")                        # copy-engine form: with one rank its barriers and the map
+            with pytest.raises(ValueError, match="not registered"):
+                c.comm_broadcast_volume(d, vol.size, 0)                   # never an implicit registration keyed by address
+            c.comm_register_volume(d, vol.size)                           # the explicit collective
             c.comm_broadcast_volume(d, vol.size, 0)
-            c.comm_broadcast_volume(d, vol.size, 0)                       # (second call: the cached map)
+            c.comm_register_volume(d, vol.size)                           # registering again replaces the mapping
+            c.comm_broadcast_volume(d, vol.size, 0)
             c.synchronize()
             assert np.array_equal(c.download(d, vol.shape), vol)
+            c.comm_unregister_volume(d)
+            with pytest.raises(ValueError, match="not registered"):
+                c.comm_broadcast_volume(d, vol.size, 0)
+            d2 = c.dev_alloc(vol.nbytes)
+            c.comm_register_volume(d2, vol.size)
+            c.dev_free(d2)                                                # freeing the buffer drops its registration
+            d3 = c.dev_alloc(vol.nbytes)                                  # (the allocator may hand the same address back)
+            with pytest.raises(ValueError, match="not registered"):
+                c.comm_broadcast_volume(d3, vol.size, 0)
+            c.dev_free(d3)
             c.set_option("broadcast", "scatter_allgather")
             c.comm_allreduce_sum(d, vol.size)
             c.synchronize()
@@ -1580,13 +1594,13 @@ def test_empty_planes_are_skipped_exactly(mvs, synth, zrange, kshape, inc):
     assert a[1].max() > 0
 
 
-def test_coscheduling_options_keep_the_results(mvs, synth):
-    """Round 4's ways of letting the sampler share the chip with the next view's convolution (profiles/r04_coschedule.txt):
-    guest waves inside passes B and D (guest_tail, with the trips split several ways), the tail stream joined only in front of pass E
-    (tail_overlap=late), CU-masked streams (cu_range, tail_cus) and kx panels (kx_panel).  None is faster than the serial order, all must
-    give its voxels: back-to-back views into distinct and shared outputs, a view that reads the previous view's output, a stage
-    operator and a download right behind a view, a view whose requested `att` is the pending tail's output."""
-    nx, ny, nz = 512, 512, 64                                           # 2^24 voxels, padded y length 560: the y passes can host guests
+def test_overlap_options_keep_the_results(mvs, synth):
+    """The library's two overlaps (psf_overlap, tail_overlap: DESIGN 4.5) against the serial order, with and without the fused rotate
+    kernel: back-to-back views into distinct and shared outputs, a view that reads the previous view's output, a stage operator and
+    a download right behind a view, a view whose requested `att` is the pending tail's output.  (Round 4's other co-scheduling forms
+    -- guest waves, CU masks, a late-joined tail, kx panels -- were measured neutral or slower, profiles/r04_coschedule.txt, and left
+    the library in round 5; the code is in the history at b8f3482.)"""
+    nx, ny, nz = 512, 512, 64                                           # 2^24 voxels: the size from which the overlaps act
     gt = np.ascontiguousarray(synth.sphere_phantom(512)[224:288])
     psfs = [synth.gaussian_psf(15, sigma=(1.5, 1.7, 3.0 + 0.2 * v)) for v in range(4)]
     dim = (nx, ny, nz)
@@ -1617,19 +1631,14 @@ def test_coscheduling_options_keep_the_results(mvs, synth):
 
     with mvs.Context(0) as c:
         c.set_option("tail_overlap", 0)
-        c.set_option("guest_tail", 0)
+        c.set_option("psf_overlap", 0)
         want = run(c)
     assert want[0].mean() > 1.0
     variants = [
-        {"guest_tail": 1, "tail_overlap": 1},                                        # separate rotate kernel: the deferred tail is flushed
-        {"guest_tail": 1, "tail_overlap": 1, "fused_fftx": 1},                       # fused kernel: it rides in passes B and D
-        {"guest_tail": 1, "tail_overlap": 1, "fused_fftx": 1, "guest_trips": "1,1"},
-        {"guest_tail": 1, "tail_overlap": 1, "fused_fftx": 1, "guest_trips": "8,0"},
-        {"guest_tail": 1, "tail_overlap": 1, "fused_fftx": 1, "guest_trips": "0,0"},
-        {"guest_tail": 0, "tail_overlap": "late", "fused_fftx": 1},
-        {"guest_tail": 0, "tail_overlap": "late", "fused_fftx": 1, "tail_prio": 1},
-        {"guest_tail": 0, "tail_overlap": 1, "cu_range": "32:256", "tail_cus": 32, "fused_fftx": 0},
-        {"guest_tail": 0, "tail_overlap": 0, "kx_panel": 64},
+        {"tail_overlap": 1, "psf_overlap": 1},                                       # defaults: fused kernel from 131072 columns up
+        {"tail_overlap": 1, "psf_overlap": 1, "fused_fftx": 0},                      # separate rotate kernel: the tail runs beside it
+        {"tail_overlap": "any", "psf_overlap": 0, "fused_fftx": 0},
+        {"tail_overlap": 1, "psf_overlap": 1, "fused_fftx": 1, "skip_empty": 0},
     ]
     for opts in variants:
         with mvs.Context(0) as c:
