@@ -90,6 +90,8 @@ def parse_args():
                     help="launcher / rendezvous check only: every rank joins the process group, all-reduces a 1 and rank 0 prints "
                          "{n_gpus, ranks_seen}; no GPU, no libmvsim (what the CPU test of the self-launcher runs with --backend gloo)")
     ap.add_argument("--no-size-1024", action="store_true", help="skip the 1024^3 sub-record")
+    ap.add_argument("--no-tiled-1024", action="store_true",
+                    help="N > 1 data path only: skip the `tiled_1024` sub-record (BASELINE configs[3]: every 1024^3 view cut into N z slabs)")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the `no_empty_space` sub-record (N = 1 only)")
     ap.add_argument("--no-main-iteration", action="store_true",
                     help="skip the `main_iteration` sub-record (N = 1 only): whole iterations of the reference's view loop, device-resident")
@@ -503,6 +505,314 @@ def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.nd
             "first_plane_mean_count": mean_count, "roofline": rl}
 
 
+class Env:
+    """What every leg of a run shares: the modules, this rank's device, the process group's geometry and -- for the N > 1 data path --
+    the broadcast stream and the context that holds the C ABI's own RCCL communicator."""
+
+
+class ShardedRun:
+    """The view loop of `main` (SimulateMultiViewDataset.java:567) sharded over the ranks: a STEP is one dataset of `total_views` views of
+    one n^3 ground truth, view v on rank v % world.  With env.multi every step also contains one broadcast of a ground truth from rank 0
+    (mvsim_comm_broadcast_volume on env.bc_ctx, or torch.distributed for the gloo rehearsals), issued one dataset ahead into the second of
+    two buffers on env.bc_stream unless serial_broadcast.  Used for the main line (512^3) and for the `size_1024` leg of N > 1."""
+
+    def __init__(self, env, n, kdim, sigma, inc, snr, conv_method, total_views, streams, serial, serial_broadcast, fill_gt):
+        torch, mvs, synth = env.torch, env.mvs, env.synth
+        self.env, self.n, self.inc, self.total_views = env, n, inc, total_views
+        self.serial, self.serial_broadcast = serial, serial_broadcast
+        self.dims, self.nvox = (n, n, n), n ** 3
+        self.nzo = (n - 1) // inc + 1
+        self.my_views = mvs.shard_views(total_views, env.world, env.rank)
+        self.angles = [15 + (360 * v) // total_views for v in range(total_views)]      # 8 views: 45-degree steps (configs[2])
+        # N > 1 keeps two ground-truth buffers so that the broadcast of the next dataset runs (RCCL, own stream) while the views of
+        # the current one are being computed
+        self.gt_bufs = [torch.empty(self.nvox, dtype=torch.float32, device=env.dev) for _ in range(2 if env.multi else 1)]
+        if env.rank == 0:
+            for b in self.gt_bufs:
+                fill_gt(b)
+        # one PSF per view (the reference loads Angle<k>.tif per view, SMVD:579): vary sigma_z slightly so no spectrum can be shared
+        self.psfs = [synth.gaussian_psf(*kdim, sigma=(sigma[0], sigma[1], sigma[2] + 0.05 * (v % 8))) for v in self.my_views]
+        self.acq = [torch.empty(n * n * self.nzo, dtype=torch.float32, device=env.dev) for _ in self.my_views]
+        # one context (own HIP stream + workspaces) per concurrent view pipeline
+        self.ctxs = [mvs.Context(env.dev_index) for _ in range(max(1, streams))]
+        self.params = [self.ctxs[0].view_params(degrees=self.angles[v], inc=inc, snr=snr, seed=464232194, stream=v, conv_method=conv_method)
+                       for v in self.my_views]
+        self.set_overlap(not serial)
+        self.view_streams = []
+        self.registered = []
+        if env.multi:
+            # the view pipelines run on torch-owned HIP streams so that torch events can order them against the broadcast stream
+            # without blocking the host
+            self.view_streams = [torch.cuda.Stream(device=env.dev) for _ in self.ctxs]
+            for c, vs in zip(self.ctxs, self.view_streams):
+                c.set_stream(vs.cuda_stream)
+            if env.bc_ctx is not None and env.broadcast == "peer_copy":
+                # the copy-engine form writes into the peers' buffers through IPC mappings: an explicit, collective registration of
+                # every buffer a broadcast will fill (never a cache keyed by address)
+                for b in self.gt_bufs:
+                    env.bc_ctx.comm_register_volume(b.data_ptr(), self.nvox)
+                    self.registered.append(b.data_ptr())
+        self.views_done = [[], []]      # per ground-truth buffer: events after the last views that read it
+        self.bcast_done = [None, None]  # per ground-truth buffer: event after the broadcast that filled it
+        self.step_no = 0
+        self.bc_events = []             # (start, end) timing events around every broadcast of a timed region (on bc_stream)
+        self.view_events = []           # per timed step: (starts, ends) around this rank's views, one pair per view stream
+        self.record_diag = False
+
+    def set_overlap(self, on: bool):
+        for c in self.ctxs:
+            # on a caller's stream (N > 1) the tail overlap needs the explicit opt-in ("any"): nothing here reads a view's output from
+            # another stream before the final device-wide synchronisation, and the events that gate the next broadcast only protect
+            # the ground truth, which the tail does not read
+            c.set_option("tail_overlap", ("any" if self.env.multi else 1) if on else 0)
+            c.set_option("psf_overlap", 1 if on else 0)
+
+    def issue_broadcast(self, b):
+        env, torch = self.env, self.env.torch
+        with torch.cuda.stream(env.bc_stream):
+            for e in self.views_done[b]:
+                env.bc_stream.wait_event(e)             # readers of the previous contents have finished
+            if self.record_diag:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(env.bc_stream)
+            if env.bc_ctx is not None:
+                env.bc_ctx.comm_broadcast_volume(self.gt_bufs[b].data_ptr(), self.nvox, 0)      # enqueued on bc_stream
+            else:
+                work = env.dist.broadcast(self.gt_bufs[b], src=0, async_op=True)
+                work.wait()                             # nccl: bc_stream waits for the collective; gloo: host waits
+            e = torch.cuda.Event(enable_timing=self.record_diag)
+            e.record(env.bc_stream)
+            self.bcast_done[b] = e
+            if self.record_diag:
+                self.bc_events.append((e0, e))
+
+    def step(self):
+        env, torch = self.env, self.env.torch
+        cur = 0
+        if env.multi:
+            cur = self.step_no % 2
+            if self.serial_broadcast or self.bcast_done[cur] is None:
+                self.issue_broadcast(cur)               # this dataset's ground truth (prologue / serial mode)
+            for vs in self.view_streams:
+                vs.wait_event(self.bcast_done[cur])     # ground truth has landed before the views read it
+            if not self.serial_broadcast:
+                self.issue_broadcast(1 - cur)           # next dataset's ground truth, overlapped with these views
+        gt_ptr = self.gt_bufs[cur].data_ptr()
+        diag = env.multi and self.record_diag and self.my_views
+        if diag:
+            v0 = []
+            for vs in self.view_streams:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(vs)
+                v0.append(e)
+        for i in range(len(self.my_views)):
+            self.ctxs[i % len(self.ctxs)].simulate_view_dev(gt_ptr, self.dims, self.psfs[i].copy(), self.params[i], self.acq[i].data_ptr())
+        if diag:
+            v1 = []
+            for c, vs in zip(self.ctxs, self.view_streams):
+                c.join()                                # a pending tail belongs to this step's views
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(vs)
+                v1.append(e)
+            self.view_events.append((v0, v1))
+        if env.multi:
+            self.views_done[cur] = []
+            for vs in self.view_streams:
+                e = torch.cuda.Event()
+                e.record(vs)
+                self.views_done[cur].append(e)
+            self.step_no += 1
+
+    def sync(self):
+        self.env.torch.cuda.synchronize()
+        if self.env.world > 1:
+            self.env.dist.barrier()
+        self.env.torch.cuda.synchronize()
+
+    def check_broadcast(self):
+        """Outside any timed region: every rank must hold rank 0's ground truth in each buffer a broadcast has filled."""
+        torch, dist = self.env.torch, self.env.dist
+        for b_i, done in enumerate(self.bcast_done):
+            if done is None:
+                continue
+            chk = torch.stack([self.gt_bufs[b_i].double().sum(), self.gt_bufs[b_i].double().abs().max()])
+            if self.env.backend != "nccl":
+                chk = chk.cpu()
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi) or float(hi[1]) == 0.0:
+                raise SystemExit(f"rank {self.env.rank}: ground-truth buffer {b_i} differs between ranks after the broadcast")
+        self.sync()
+
+    def timed(self, steps):
+        """Exactly `steps` steps between two barrier + synchronise pairs.  Returns (seconds: MAX over ranks, multi_gpu diagnostics or None)."""
+        env, torch, dist = self.env, self.env.torch, self.env.dist
+        self.bc_events, self.view_events = [], []
+        self.record_diag = env.multi
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        own = time.perf_counter() - t0
+        self.record_diag = False
+        diag = None
+        if env.multi:
+            # What a scaling run needs to be attributable: per step, the broadcast's own duration on its stream, this rank's views on
+            # theirs, how much of the broadcast the views hid, and every rank's own wall clock.  Events, read after the timed region;
+            # nothing here is inside it but the event records themselves.
+            bc_ms = [a.elapsed_time(b) for a, b in self.bc_events]
+            vw_ms = [max(a.elapsed_time(b) for a, b in zip(v0, v1)) for v0, v1 in self.view_events]   # the busiest of this rank's view streams
+            mine = torch.tensor([own / steps * 1e3, sum(bc_ms) / max(1, len(bc_ms)), sum(vw_ms) / max(1, len(vw_ms)),
+                                 float(len(self.my_views))], dtype=torch.float64, device=env.dev if env.backend == "nccl" else "cpu")
+            every = [torch.zeros_like(mine) for _ in range(env.world)]
+            if env.world > 1:
+                dist.all_gather(every, mine)
+            else:
+                every = [mine]
+            rows = [[float(x) for x in t.tolist()] for t in every]
+            step_ms = [r[0] for r in rows]
+            b_ms = max(r[1] for r in rows)                 # the collective ends when its slowest rank does
+            v_ms = max(r[2] for r in rows)
+            exposed = min(max(max(step_ms) - v_ms, 0.0), b_ms) if b_ms > 0 else 0.0
+            diag = {"broadcast_ms": round(b_ms, 4), "views_ms": round(v_ms, 4),
+                    "broadcast_hidden_frac": round(1.0 - exposed / b_ms, 4) if b_ms > 0 else None,
+                    "broadcast_GBps_per_rank": round(4 * self.nvox / (b_ms * 1e-3) / 1e9, 2) if b_ms > 0 else None,
+                    "ms_per_step_min": round(min(step_ms), 4), "ms_per_step_max": round(max(step_ms), 4),
+                    "per_rank": [{"rank": i, "ms_per_step": round(r[0], 4), "broadcast_ms": round(r[1], 4), "views_ms": round(r[2], 4),
+                                  "views": int(r[3])} for i, r in enumerate(rows)],
+                    "note": "per step: broadcast_ms = scatter + all-gather of the next dataset's ground truth on its own stream (HIP events, "
+                            "slowest rank); views_ms = this dataset's views on the busiest rank; broadcast_hidden_frac = share of the broadcast "
+                            "that did not extend the step beyond the views (1 = fully hidden); broadcast_GBps_per_rank = volume bytes / "
+                            "broadcast_ms (what every rank received); expected from link rates: DESIGN.md section 6"}
+        elapsed = own
+        if env.world > 1:
+            tt = torch.tensor([own], dtype=torch.float64, device=env.dev if env.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, diag
+
+    def close(self):
+        self.sync()
+        for p in self.registered:
+            self.env.bc_ctx.comm_unregister_volume(p)
+        self.registered = []
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+        self.acq.clear()
+        self.gt_bufs.clear()
+        self.env.torch.cuda.empty_cache()
+
+
+def upsample2x(torch, g512, n):
+    """The 512^3 phantom up-sampled 2x on the device (spheres of twice the radius: the character of the phantom at that size,
+    SimulateMultiViewDataset.java:436-522 scales the radii with the canvas)."""
+    g = g512.view(n, n, n)
+    return g.repeat_interleave(2, dim=0).repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous().view(-1)
+
+
+def sharded_2x_leg(env, gt_dev, n_half, psf_edge, inc, snr, total_views, steps, serial_broadcast):
+    """north_star's second size on the N > 1 data path (n_half = 512: `total_views` views of a 1024^3 ground truth sharded v % N, one
+    4.3 GB broadcast per step; same machinery and diagnostics as the main line).  Returns (record, the ground truth every rank now holds)."""
+    torch = env.torch
+    n = 2 * n_half
+
+    def fill(buf):
+        buf.copy_(upsample2x(torch, gt_dev, n_half))
+    run = ShardedRun(env, n, (psf_edge,) * 3, (2.0, 2.2, 6.0), inc, snr, 1, total_views, 1, serial=False, serial_broadcast=serial_broadcast,
+                     fill_gt=fill)
+    try:
+        run.step()
+        run.sync()
+        if env.world > 1:
+            run.check_broadcast()
+        elapsed, diag = run.timed(steps)
+        mean_count = float(run.acq[0][: n * n].double().mean().item()) if run.acq else None
+        gt_keep = run.gt_bufs[0]                       # every rank holds the 1024^3 ground truth now: the tiled leg reuses it
+        run.gt_bufs = run.gt_bufs[1:]
+    finally:
+        run.close()
+    rec = {"workload": f"{n}^3 float volume x {total_views} views per dataset (view v on GPU v % N), {psf_edge}^3 PSF, inc={inc}, SNR {snr:g}, "
+                       f"device-resident, one broadcast of the {4 * n ** 3 / 1e9:.1f} GB ground truth per step",
+           "steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": total_views * steps / elapsed * n ** 3 / 1e6, "unit": "Mvoxel/s",
+           "views_per_s": total_views * steps / elapsed, "first_plane_mean_count": mean_count, "multi_gpu": diag}
+    return rec, gt_keep
+
+
+def tiled_leg(env, gt_dev, n, steps) -> dict:
+    """BASELINE configs[3] as stated (n = 1024): 1024^3 volume, 6 views, anisotropic 31 x 31 x 63 PSF (sigma 2 / 2.2 / 12), 4x axial
+    downsample, EVERY view cut into N z slabs -- one per rank -- through mvsim_view_slab_convolve_dev / _finish_dev
+    (multiview-simulation_amd/tiling.py).  The halo planes are recomputed from the broadcast ground truth, the only exchange per view is
+    the one double of adjustImage's sum, reduced by the C ABI's own mvsim_comm_allreduce_sum_f64 (torch.distributed only where RCCL
+    cannot run: gloo ranks sharing a GPU)."""
+    torch, dist, mvs, synth = env.torch, env.dist, env.mvs, env.synth
+    tiling = importlib.import_module("multiview-simulation_amd.tiling")
+    inc, views = 4, 6
+    dims = (n, n, n)
+    psfs = [synth.gaussian_psf(31, 31, 63, sigma=(2.0, 2.2, 12.0 + 0.05 * v)) for v in range(views)]
+    reduce_fn, reduce_name = None, "mvsim_comm_allreduce_sum_f64 (C ABI, RCCL)"
+    if env.bc_ctx is None:
+        def reduce_fn(x):
+            t = torch.tensor([x], dtype=torch.float64)
+            if env.world > 1:
+                dist.all_reduce(t)
+            return float(t.item())
+        reduce_name = f"torch.distributed.all_reduce ({env.backend}: rehearsal, RCCL cannot place two ranks on one device)"
+    with mvs.Context(env.dev_index) as ctx:
+        tv = tiling.TiledView(ctx, env.rank, env.world, comm_ctx=env.bc_ctx, allreduce_f64=reduce_fn)
+        planes = tv.acq_planes(n, inc)
+        acq = torch.empty(max(1, planes) * n * n, dtype=torch.float32, device=env.dev)
+        params = [ctx.view_params(degrees=15 + 60 * v, inc=inc, snr=25.0, seed=464232194, stream=v, conv_method=1) for v in range(views)]
+        info = []
+
+        def step(record):
+            for v in range(views):
+                r = tv.run(gt_dev.data_ptr(), dims, psfs[v].copy(), params[v], acq.data_ptr())
+                t0 = time.perf_counter()
+                ctx.synchronize()                       # the next view reuses the slab workspace and `acq`
+                r["finish_ms"] = (time.perf_counter() - t0) * 1e3
+                if record:
+                    info.append(r)
+
+        def sync():
+            torch.cuda.synchronize()
+            if env.world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+        step(False)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        sync()
+        own = time.perf_counter() - t0
+        mean_count = float(acq[: n * n].double().mean().item()) if planes else None
+    elapsed = own
+    mine = torch.tensor([own / steps * 1e3, sum(r["convolve_ms"] for r in info) / len(info), sum(r["allreduce_ms"] for r in info) / len(info),
+                         sum(r["finish_ms"] for r in info) / len(info), float(info[0]["planes_owned"]), float(info[0]["planes_rotated"])],
+                        dtype=torch.float64, device=env.dev if env.backend == "nccl" else "cpu")
+    every = [mine]
+    if env.world > 1:
+        tt = torch.tensor([own], dtype=torch.float64, device=mine.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        every = [torch.zeros_like(mine) for _ in range(env.world)]
+        dist.all_gather(every, mine)
+    rows = [[float(x) for x in t.tolist()] for t in every]
+    return {"workload": f"BASELINE configs[3]: {n}^3 float volume, {views} views at 60-degree steps, 31x31x63 PSF, inc={inc} (4x axial downsample), "
+                        f"SNR 25, every view tiled into {env.world} z slab(s), one per rank; device-resident, ground truth already broadcast",
+            "steps": steps, "ms_per_step": elapsed / steps * 1e3, "ms_per_view": elapsed / (steps * views) * 1e3,
+            "value": views * steps / elapsed * n ** 3 / 1e6, "unit": "Mvoxel/s", "first_plane_mean_count": mean_count,
+            "reduction": reduce_name,
+            "per_rank": [{"rank": i, "ms_per_step": round(r[0], 4), "slab_convolve_ms_per_view": round(r[1], 4), "allreduce_ms_per_view": round(r[2], 4),
+                          "finish_ms_per_view": round(r[3], 4), "planes_owned": int(r[4]), "planes_rotated": int(r[5]),
+                          "halo_recompute_share": round(1.0 - r[4] / r[5], 4) if r[5] > 0 else None} for i, r in enumerate(rows)],
+            "note": "slab_convolve = rotate + attenuate of the slab and its halo planes, the convolution of the slab, the slab sum to the host; "
+                    "allreduce = the one double of Tools.adjustImage's sum over the ranks (host clock around the call); finish = adjust, extract, "
+                    "Poisson of the rank's acquired planes; halo_recompute_share = planes rotated beyond the rank's own / planes rotated"}
+
+
 def dry_run_launch(args, world: int, rank: int) -> None:
     """Launcher / rendezvous check: no GPU, no libmvsim (tests/test_host_logic.py runs it with --backend gloo)."""
     import torch
@@ -566,12 +876,16 @@ def main():
     synth = importlib.import_module("multiview-simulation_amd.synthetic")
     build = importlib.import_module("multiview-simulation_amd.build")
 
+    env = Env()
+    env.torch, env.dist, env.mvs, env.synth = torch, dist, mvs, synth
+    env.dev, env.dev_index, env.world, env.rank = dev, dev_index, world, rank
+    env.multi, env.collective, env.backend, env.broadcast = multi, collective, args.backend, args.broadcast
+    env.bc_ctx, env.bc_stream = None, None
+
     n = args.size
     dims = (n, n, n)
     nvox = n ** 3
     total_views = args.views_total if args.scaling == "strong" else args.views_per_gpu * world
-    my_views = mvs.shard_views(total_views, world, rank)
-    angles = [15 + (360 * v) // total_views for v in range(total_views)]      # 8 views: 45-degree steps (configs[2])
     nzo = (n - 1) // args.inc + 1
 
     # every rank really is there: one all-reduce of a 1 through torch.distributed, and (below) one through the C ABI's own
@@ -583,192 +897,49 @@ def main():
         ranks_seen["torch"] = int(t.item())
         if ranks_seen["torch"] != world:
             raise SystemExit(f"rank {rank}: all-reduce of 1 over the process group gave {ranks_seen['torch']}, expected {world}")
-
-    # synthetic inputs (rank 0 owns the ground truth; other ranks receive it by broadcast, once per step = dataset).
-    # N > 1 keeps two ground-truth buffers so that the broadcast of the next dataset runs (RCCL, own stream) while
-    # the views of the current one are being computed.
-    gt_bufs = [torch.empty(nvox, dtype=torch.float32, device=dev) for _ in range(2 if multi else 1)]
-    gt_host = None
-    if rank == 0:
-        gt_host = synth.sphere_phantom(n)
-        for b in gt_bufs:
-            b.copy_(torch.from_numpy(gt_host.reshape(-1)))
-    psf_raw = synth.gaussian_psf(args.psf, sigma=(2.0, 2.2, 6.0))
-    # one PSF per view (the reference loads Angle<k>.tif per view, SMVD:579): vary sigma_z slightly so no
-    # spectrum can be shared between views
-    psfs = [synth.gaussian_psf(args.psf, sigma=(2.0, 2.2, 6.0 + 0.05 * (v % 8))) for v in my_views]
-    acq = [torch.empty(n * n * nzo, dtype=torch.float32, device=dev) for _ in my_views]
-
-    # one context (own HIP stream + workspaces) per concurrent view pipeline
-    ctxs = [mvs.Context(dev_index) for _ in range(max(1, args.streams))]
-    ctx = ctxs[0]
-
-    def set_overlap(on: bool):
-        for c in ctxs:
-            # on a caller's stream (N > 1 below) the tail overlap needs the explicit opt-in ("any"): nothing here reads a view's
-            # output from another stream before the final device-wide synchronisation, and the events that gate the next
-            # broadcast only protect the ground truth, which the tail does not read
-            c.set_option("tail_overlap", ("any" if multi else 1) if on else 0)
-            c.set_option("psf_overlap", 1 if on else 0)
-    set_overlap(not args.serial)
-    view_streams = []
-    bc_ctx = None
     if multi:
-        # the view pipelines run on torch-owned HIP streams so that torch events can order them against the
-        # broadcast stream without blocking the host
-        view_streams = [torch.cuda.Stream(device=dev) for _ in ctxs]
-        for c, vs in zip(ctxs, view_streams):
-            c.set_stream(vs.cuda_stream)
-        bc_stream = torch.cuda.Stream(device=dev)
+        env.bc_stream = torch.cuda.Stream(device=dev)
         if collective == "mvsim":
             # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed is only the messenger
             box = [mvs.Context.comm_unique_id() if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(box, src=0)
-            bc_ctx = mvs.Context(dev_index)
-            bc_ctx.set_stream(bc_stream.cuda_stream)
-            bc_ctx.set_option("broadcast", args.broadcast)
-            bc_ctx.comm_init(world, rank, box[0])
+            env.bc_ctx = mvs.Context(dev_index)
+            env.bc_ctx.set_stream(env.bc_stream.cuda_stream)
+            env.bc_ctx.set_option("broadcast", args.broadcast)
+            env.bc_ctx.comm_init(world, rank, box[0])
             one = torch.ones(16, dtype=torch.float32, device=dev)
-            with torch.cuda.stream(bc_stream):
-                bc_ctx.comm_allreduce_sum(one.data_ptr(), 16)
-            bc_stream.synchronize()
+            with torch.cuda.stream(env.bc_stream):
+                env.bc_ctx.comm_allreduce_sum(one.data_ptr(), 16)
+            env.bc_stream.synchronize()
             ranks_seen["mvsim_comm"] = int(one[0].item())
             if ranks_seen["mvsim_comm"] != world:
                 raise SystemExit(f"rank {rank}: all-reduce of 1 over the C ABI's communicator gave {ranks_seen['mvsim_comm']}, expected {world}")
-            if args.broadcast == "peer_copy":
-                # the copy-engine form writes into the peers' buffers through IPC mappings: an explicit, collective registration
-                # of every buffer a broadcast will fill (never a cache keyed by address)
-                for b in gt_bufs:
-                    bc_ctx.comm_register_volume(b.data_ptr(), nvox)
-    views_done = [[], []]      # per ground-truth buffer: events after the last views that read it
-    bcast_done = [None, None]  # per ground-truth buffer: event after the broadcast that filled it
-    step_no = [0]
+    bc_ctx = env.bc_ctx
 
-    bc_events = []             # (start, end) timing events around every broadcast of the timed region (on bc_stream)
-    view_events = []           # per timed step: (starts, ends) around this rank's views, one pair per view stream
-    record_diag = [False]
+    # synthetic inputs (rank 0 owns the ground truth; other ranks receive it by broadcast, once per step = dataset)
+    gt_host = synth.sphere_phantom(n) if rank == 0 else None
+    psf_raw = synth.gaussian_psf(args.psf, sigma=(2.0, 2.2, 6.0))
 
-    def issue_broadcast(b):
-        with torch.cuda.stream(bc_stream):
-            for e in views_done[b]:
-                bc_stream.wait_event(e)             # readers of the previous contents have finished
-            if record_diag[0]:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e0.record(bc_stream)
-            if bc_ctx is not None:
-                bc_ctx.comm_broadcast_volume(gt_bufs[b].data_ptr(), nvox, 0)      # enqueued on bc_stream
-            else:
-                work = dist.broadcast(gt_bufs[b], src=0, async_op=True)
-                work.wait()                         # nccl: bc_stream waits for the collective; gloo: host waits
-            e = torch.cuda.Event(enable_timing=record_diag[0])
-            e.record(bc_stream)
-            bcast_done[b] = e
-            if record_diag[0]:
-                bc_events.append((e0, e))
-    params = [ctx.view_params(degrees=angles[v], inc=args.inc, snr=args.snr, seed=464232194, stream=v,
-                              conv_method=args.conv_method) for v in my_views]
-
-    def step():
-        cur = 0
-        if multi:
-            cur = step_no[0] % 2
-            if args.serial_broadcast or bcast_done[cur] is None:
-                issue_broadcast(cur)                    # this dataset's ground truth (prologue / serial mode)
-            for vs in view_streams:
-                vs.wait_event(bcast_done[cur])          # ground truth has landed before the views read it
-            if not args.serial_broadcast:
-                issue_broadcast(1 - cur)                # next dataset's ground truth, overlapped with these views
-        gt_ptr = gt_bufs[cur].data_ptr()
-        if multi and record_diag[0] and my_views:
-            v0 = []
-            for vs in view_streams:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record(vs)
-                v0.append(e)
-        for i in range(len(my_views)):
-            ctxs[i % len(ctxs)].simulate_view_dev(gt_ptr, dims, psfs[i].copy(), params[i], acq[i].data_ptr())
-        if multi and record_diag[0] and my_views:
-            v1 = []
-            for c, vs in zip(ctxs, view_streams):
-                c.join()                                # a pending tail belongs to this step's views
-                e = torch.cuda.Event(enable_timing=True)
-                e.record(vs)
-                v1.append(e)
-            view_events.append((v0, v1))
-        if multi:
-            views_done[cur] = []
-            for vs in view_streams:
-                e = torch.cuda.Event()
-                e.record(vs)
-                views_done[cur].append(e)
-            step_no[0] += 1
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def fill_gt(buf):
+        buf.copy_(torch.from_numpy(gt_host.reshape(-1)))
+    run = ShardedRun(env, n, (args.psf,) * 3, (2.0, 2.2, 6.0), args.inc, args.snr, args.conv_method, total_views, args.streams,
+                     serial=args.serial, serial_broadcast=args.serial_broadcast, fill_gt=fill_gt)
+    my_views, angles, ctxs, gt_bufs, acq, psfs, params = run.my_views, run.angles, run.ctxs, run.gt_bufs, run.acq, run.psfs, run.params
+    ctx = ctxs[0]
+    step, sync, set_overlap = run.step, run.sync, run.set_overlap
 
     for _ in range(args.warmup):
         step()
     sync()
     if world > 1 and args.warmup > 0:
-        # outside the timed region: every rank must hold rank 0's ground truth in each buffer a broadcast has filled
-        for b_i, done in enumerate(bcast_done):
-            if done is None:
-                continue
-            chk = torch.stack([gt_bufs[b_i].double().sum(), gt_bufs[b_i].double().abs().max()])
-            lo, hi = chk.clone(), chk.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            if not torch.equal(lo, hi) or float(hi[1]) == 0.0:
-                raise SystemExit(f"rank {rank}: ground-truth buffer {b_i} differs between ranks after the broadcast")
-        sync()
+        run.check_broadcast()                     # outside the timed region: every rank holds rank 0's ground truth
     # ---- the timed region: exactly K steps between two barrier + synchronise pairs; MAX over ranks below
     timed_with_events = args.serial or multi      # serial main line: its stage events ARE the roofline's source
     if timed_with_events:
         for c in ctxs:
             c.enable_timing(True)
-    record_diag[0] = multi
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    record_diag[0] = False
-    own_elapsed = elapsed
-    multi_diag = None
-    if multi:
-        # What a scaling run needs to be attributable: per step, the broadcast's own duration on its stream, this
-        # rank's views on theirs, how much of the broadcast the views hid, and every rank's own wall clock.  Events, read after the
-        # timed region; nothing here is inside it but the event records themselves.
-        bc_ms = [a.elapsed_time(b) for a, b in bc_events]
-        vw_ms = [max(a.elapsed_time(b) for a, b in zip(v0, v1)) for v0, v1 in view_events]   # the busiest of this rank's view streams
-        mine = torch.tensor([own_elapsed / args.steps * 1e3, sum(bc_ms) / max(1, len(bc_ms)), sum(vw_ms) / max(1, len(vw_ms)),
-                             float(len(my_views))], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        if world > 1:
-            dist.all_gather(every, mine)
-        else:
-            every = [mine]
-        rows = [[float(x) for x in t.tolist()] for t in every]
-        step_ms = [r[0] for r in rows]
-        b_ms = max(r[1] for r in rows)                 # the collective ends when its slowest rank does
-        v_ms = max(r[2] for r in rows)
-        exposed = min(max(max(step_ms) - v_ms, 0.0), b_ms) if b_ms > 0 else 0.0
-        multi_diag = {"broadcast_ms": round(b_ms, 4), "views_ms": round(v_ms, 4),
-                      "broadcast_hidden_frac": round(1.0 - exposed / b_ms, 4) if b_ms > 0 else None,
-                      "ms_per_step_min": round(min(step_ms), 4), "ms_per_step_max": round(max(step_ms), 4),
-                      "per_rank": [{"rank": i, "ms_per_step": round(r[0], 4), "broadcast_ms": round(r[1], 4), "views_ms": round(r[2], 4),
-                                    "views": int(r[3])} for i, r in enumerate(rows)],
-                      "note": "per step: broadcast_ms = scatter + all-gather of the next dataset's ground truth on its own stream (HIP events, "
-                              "slowest rank); views_ms = this dataset's views on the busiest rank; broadcast_hidden_frac = share of the broadcast "
-                              "that did not extend the step beyond the views (1 = fully hidden); expected from link rates: DESIGN.md section 6"}
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, multi_diag = run.timed(args.steps)
 
     def read_stage():
         acc = {}
@@ -845,6 +1016,10 @@ def main():
         out = {
             "metric": "simulated Mvoxel/s (views x input voxels / s), 512^3 volume x 8 views",
             "value": mvox_s, "unit": "Mvoxel/s", "views_per_s": views_s,
+            # `value` is measured on the sphere phantom -- a specimen in empty space, like the reference's own drawSpheres volume
+            # (SimulateMultiViewDataset.java:436-522) -- whose empty rows and planes the kernels skip exactly; `value_dense` is the
+            # same workload without a single empty voxel (phantom + 1e-6; serial leg, see `no_empty_space`).  Read them side by side.
+            "value_dense": (no_empty["value"] if no_empty else None),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             **({"rehearsal": "N > 1 data path on one GPU (--rehearse-multi): a control-flow check, not a result"} if args.rehearse_multi else {}),
@@ -930,11 +1105,48 @@ def main():
                                       note="views alternate between two contexts of the same GPU; same workload and timed-region rules as `value`")
         except Exception as e:
             out["two_streams"] = {"failed": repr(e)}
-    for c in ctxs:
-        c.close()
+    gt512 = gt_bufs[0]                                     # rank 0's phantom (every rank's after a broadcast): the 1024^3 legs up-sample it
+    run.close()
+    legs = {}
+    if multi and args.conv_method == 1 and n <= 512:
+        # the other sizes north_star names, on the N > 1 data path: 1024^3 views sharded v % N (`size_1024`) and BASELINE configs[3] as
+        # stated -- every 1024^3 view cut into N z slabs (`tiled_1024`).  Every rank takes part; rank 0 reports.  (The legs run at twice
+        # the main line's edge: 1024 for the 512^3 line of record, 512 for the tests' 256^3 rehearsals.)
+        leg_steps = max(1, min(args.steps, 3))
+        n2 = 2 * n
+        gt2 = None
+        try:
+            if not args.no_size_1024:
+                legs[f"size_{n2}"], gt2 = sharded_2x_leg(env, gt512, n, args.psf, args.inc, args.snr, total_views, leg_steps, args.serial_broadcast)
+            if not args.no_tiled_1024:
+                if gt2 is None:
+                    gt2 = torch.empty(n2 ** 3, dtype=torch.float32, device=dev)
+                    if rank == 0:
+                        gt2.copy_(upsample2x(torch, gt512, n))
+                    if world > 1:
+                        if bc_ctx is not None:
+                            if args.broadcast == "peer_copy":
+                                bc_ctx.comm_register_volume(gt2.data_ptr(), n2 ** 3)
+                            with torch.cuda.stream(env.bc_stream):
+                                bc_ctx.comm_broadcast_volume(gt2.data_ptr(), n2 ** 3, 0)
+                            env.bc_stream.synchronize()
+                            if args.broadcast == "peer_copy":
+                                bc_ctx.comm_unregister_volume(gt2.data_ptr())
+                        else:
+                            dist.broadcast(gt2, src=0)
+                    torch.cuda.synchronize()
+                legs[f"tiled_{n2}"] = tiled_leg(env, gt2, n2, leg_steps)
+        except Exception as e:
+            if world > 1:
+                raise                                      # a rank that drops out of a collective must end the job, not hang it
+            legs.setdefault(f"size_{n2}", {"failed": repr(e)})
+        del gt2
+    del gt512
+    torch.cuda.empty_cache()
     if bc_ctx is not None:
         bc_ctx.close()
-
+    if rank == 0:
+        out.update(legs)
     if rank == 0:
         if not multi and not args.no_end_to_end and args.conv_method == 1:
             try:
@@ -943,9 +1155,9 @@ def main():
                 out["end_to_end"] = {"failed": repr(e)}
         if not multi and not args.no_size_1024 and n == 512 and args.conv_method == 1:
             try:
-                acq.clear()
-                torch.cuda.empty_cache()
-                out["size_1024"] = size_1024_record(mvs, torch, dev, dev_index, gt_bufs[0], psf_raw, args.inc, args.snr)
+                g512 = torch.from_numpy(gt_host.reshape(-1)).to(dev)
+                out["size_1024"] = size_1024_record(mvs, torch, dev, dev_index, g512, psf_raw, args.inc, args.snr)
+                del g512
             except Exception as e:
                 out["size_1024"] = {"failed": repr(e)}
         if not args.no_cpu_baseline and world == 1:

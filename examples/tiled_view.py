@@ -6,8 +6,8 @@ z-slab tiling ... on 8 GPUs").  One process per GPU:
         examples/tiled_view.py --size 1024 --psf 15 15 41 --inc 4
 
 Rank 0 owns the ground truth and broadcasts it (RCCL); every rank rotates+attenuates its slab and the halo planes the
-PSF reaches, convolves the slab, the ranks all-reduce ONE double (the sum adjustImage divides by), and every rank
-extracts and noises its acquired planes.  `--check` gathers the slabs on rank 0 and compares them with the untiled
+PSF reaches, convolves the slab, the ranks all-reduce ONE double (the sum adjustImage divides by) through the C ABI's own
+communicator, and every rank extracts and noises its acquired planes (multiview-simulation_amd/tiling.py: TiledView).  `--check` gathers the slabs on rank 0 and compares them with the untiled
 view computed there.  `--backend gloo` lets several ranks share one GPU to rehearse the control flow.
 """
 import argparse
@@ -45,6 +45,7 @@ def main():
 
     mvs = importlib.import_module("multiview-simulation_amd")
     synth = importlib.import_module("multiview-simulation_amd.synthetic")
+    tiling = importlib.import_module("multiview-simulation_amd.tiling")
     n = a.size
     dims = (n, n, n)
     gt = torch.empty(n ** 3, dtype=torch.float32, device=dev)
@@ -59,18 +60,26 @@ def main():
 
     ctx = mvs.Context(local)
     p = ctx.view_params(degrees=a.degrees, delta=0.01, inc=a.inc, snr=25.0, seed=464232194, stream=0, conv_method=1)
-    z0, z1 = ctx.slab_range(n, world, rank)
-    slab_sum = ctx.view_slab_convolve_dev(gt.data_ptr(), dims, psf.copy(), p, z0, z1)
-    t = torch.tensor([slab_sum], dtype=torch.float64, device=dev)
-    dist.all_reduce(t)                                           # the only exchange of the view itself: one double
-    total = float(t.item())
-    k0, k1 = (z0 + a.inc - 1) // a.inc, (z1 + a.inc - 1) // a.inc
-    acq = torch.empty(max(1, k1 - k0) * n * n, dtype=torch.float32, device=dev)
-    got = ctx.view_slab_finish_dev(dims, p, z0, z1, total, acq.data_ptr())
+    # the one double of adjustImage's sum travels through the C ABI's own communicator (mvsim_comm_allreduce_sum_f64) -- except where
+    # RCCL cannot run: gloo ranks that share a GPU reduce it through torch.distributed
+    reduce_fn = None
+    if a.backend == "nccl":
+        box = [mvs.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(world, rank, box[0])
+    else:
+        def reduce_fn(x):
+            t = torch.tensor([x], dtype=torch.float64)
+            dist.all_reduce(t)
+            return float(t.item())
+    tv = tiling.TiledView(ctx, rank, world, allreduce_f64=reduce_fn)
+    got = tv.acq_planes(n, a.inc)
+    acq = torch.empty(max(1, got) * n * n, dtype=torch.float32, device=dev)
+    info = tv.run(gt.data_ptr(), dims, psf.copy(), p, acq.data_ptr())
     ctx.synchronize()
-    assert got == k1 - k0
-    print(f"rank {rank}: planes [{z0},{z1}) -> acquired planes [{k0},{k1}), slab sum {slab_sum:.6g}, "
-          f"mean count {float(acq[: got * n * n].mean()) if got else float('nan'):.3f}", flush=True)
+    z0, z1, k0, k1 = info["z0"], info["z1"], info["k0"], info["k1"]
+    print(f"rank {rank}: planes [{z0},{z1}) -> acquired planes [{k0},{k1}), rotated {info['planes_rotated']} planes for {info['planes_owned']} owned, "
+          f"slab sum {info['slab_sum']:.6g}, mean count {float(acq[: got * n * n].mean()) if got else float('nan'):.3f}", flush=True)
 
     if a.check:
         parts = [None] * world

@@ -47,6 +47,32 @@ def main():
         assert c.comm_allreduce_sum_f64(0.5 + rank) == sum(0.5 + r for r in range(nranks))
         assert mvs.shard_views(8, nranks, rank) == list(range(rank, 8, nranks))
         c.dev_free(d)
+        # BASELINE configs[3]'s rank-level path through the C ABI alone: every rank its z slab of ONE view, the one double of
+        # adjustImage's sum through mvsim_comm_allreduce_sum_f64, the stitched acquisition against the untiled view (rank 0)
+        import importlib
+        tiling = importlib.import_module("multiview-simulation_amd.tiling")
+        synth = importlib.import_module("multiview-simulation_amd.synthetic")
+        m, inc = 96, 4
+        gt = synth.sphere_phantom(m)
+        psf = synth.gaussian_psf(7, 9, 21, sigma=(1.3, 1.5, 4.0))
+        d_gt = c.dev_alloc(gt.nbytes)
+        c.upload(d_gt, gt if rank == 0 else np.zeros_like(gt))
+        c.set_option("broadcast", "scatter_allgather")
+        c.comm_broadcast_volume(d_gt, gt.size, 0)
+        p = c.view_params(degrees=50, delta=0.01, inc=inc, snr=25.0, seed=464232194, stream=5, conv_method=1)
+        tv = tiling.TiledView(c, rank, nranks)
+        planes = tv.acq_planes(m, inc)
+        d_acq = c.dev_alloc(max(1, planes) * m * m * 4)
+        info = tv.run(d_gt, (m, m, m), psf.copy(), p, d_acq)
+        part = c.download(d_acq, (planes, m, m))
+        np.save(uid_file + f".slab{rank}.npy", part)
+        c.comm_allreduce_sum_f64(0.0)                       # barrier: every rank's slab is on disk
+        if rank == 0:
+            tiled = np.concatenate([np.load(uid_file + f".slab{r}.npy") for r in range(nranks)], axis=0)
+            whole = c.simulate_view(gt, psf.copy(), p, want=("acq",))["acq"]
+            assert tiled.shape == whole.shape and (tiled != whole).mean() < 5e-3, (tiled.shape, whole.shape)
+        assert info["planes_rotated"] > info["planes_owned"]
+        c.dev_free(d_acq); c.dev_free(d_gt)
         c.comm_destroy()
     print(f"rank {rank} ok", flush=True)
 

@@ -1735,6 +1735,12 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
         # what makes a scaling run attributable: per-step broadcast / view times and every rank's own clock
         mg = d["multi_gpu"]
         assert mg["broadcast_ms"] >= 0 and mg["views_ms"] > 0 and len(mg["per_rank"]) == 1 and mg["ms_per_step_max"] >= mg["ms_per_step_min"] > 0
+        # the other legs of the N > 1 data path, at twice the edge (1024^3 for the line of record, 512^3 here): views sharded v % N
+        # with their own broadcast, and BASELINE configs[3] -- every view cut into N z slabs, the sum reduced by the C ABI's collective
+        big, tiled = d["size_512"], d["tiled_512"]
+        assert big["value"] > 0 and big["multi_gpu"]["views_ms"] > 0 and "512^3" in big["workload"]
+        assert tiled["value"] > 0 and "mvsim_comm_allreduce_sum_f64" in tiled["reduction"] and "31x31x63" in tiled["workload"]
+        assert len(tiled["per_rank"]) == 1 and tiled["per_rank"][0]["planes_owned"] == 512 and tiled["per_rank"][0]["slab_convolve_ms_per_view"] > 0
 
 
 @pytest.mark.parametrize("shape,kshape,degrees,inc", [((40, 64, 64), (9, 5, 7), 33, 1),       # one wave per row batch
@@ -1820,6 +1826,83 @@ def test_bench_launches_its_own_ranks():
     assert d["config"]["launcher"].startswith("self-launched") and d["config"]["views_this_gpu"] == 4
     assert "torch.distributed.broadcast (gloo)" in d["config"]["collective"]
     assert d["roofline"]["stages"]["convolve"]["ms"] > 0
+    # configs[3]'s tiled leg with two real ranks: each owns half of the planes and recomputes the PSF's halo beside them
+    tiled = d["tiled_512"]
+    assert len(tiled["per_rank"]) == 2 and all(r["planes_owned"] == 256 and r["planes_rotated"] > 256 for r in tiled["per_rank"])
+    assert 0 < tiled["per_rank"][0]["halo_recompute_share"] < 0.2 and "torch.distributed.all_reduce" in tiled["reduction"]
+    assert len(d["size_512"]["multi_gpu"]["per_rank"]) == 2 and d["size_512"]["value"] > 0
+
+
+def test_tiled_view_two_gloo_ranks_on_one_gpu():
+    """BASELINE configs[3]'s rank-level path (multiview-simulation_amd/tiling.py through examples/tiled_view.py) with two real
+    processes sharing this box's GPU: each rank rotates, attenuates and convolves its z slab of a 256^3 view (31 x 31 x 63 taps would
+    not leave two slabs their halo at this size: 15 x 15 x 41), the one double of adjustImage's sum is all-reduced between them, and
+    the stitched acquisition equals the untiled view (the script's own --check).  On gloo the double travels through
+    torch.distributed; with the default backend (one rank per GPU) it goes through mvsim_comm_allreduce_sum_f64."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29546", os.path.join(ROOT, "examples", "tiled_view.py"), "--size", "256", "--psf", "15", "15", "41",
+                        "--inc", "4", "--backend", "gloo", "--check"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "rank 0: planes [0,128)" in r.stdout and "rank 1: planes [128,256)" in r.stdout and "of the counts differ" in r.stdout
+
+
+def test_example_simulate_dataset_runs(tmp_path):
+    """examples/simulate_dataset.py -- the whole driver of SimulateMultiViewDataset.main (:524-663) on the GPU path through the
+    package's mirror of the reference's static methods -- runs and writes every image `main` writes."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "simulate_dataset.py"), "--size", "48", "--views", "3", "--psf", "9",
+                        "--out", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    z = np.load(tmp_path / "dataset.npz")
+    for name in ("rendered", "groundtruth", "rot_view_0", "att_view_0", "con_view_0", "acq_view_0", "iso_view_0", "aligned_view_0",
+                 "aligned_view_psf_0", "aligned_view_weights0", "sum_weights"):
+        assert name in z.files, name
+    assert z["acq_view_0"].shape == (16, 48, 48) and z["acq_view_0"].max() > 0 and np.all(z["acq_view_0"] == np.round(z["acq_view_0"]))
+    assert z["sum_weights"].max() <= 3.0 + 1e-5 and z["iso_view_0"].shape == (46, 48, 48)
+
+
+def test_simulate_views_dev_equals_sequential_views(mvs, synth):
+    """mvsim_simulate_views_dev (the view loop of `main`, SimulateMultiViewDataset.java:567-585, for views that cannot fill the chip
+    one at a time): V views of one ground truth in one call, `view_lanes` of them side by side -- every acquisition and every
+    requested adjusted volume bit-identical to V sequential mvsim_simulate_view_dev calls; more views than lanes; overlapping
+    outputs rejected."""
+    for (n, k, inc, nv) in ((64, 9, 1, 8), (97, 11, 3, 7), (128, 15, 2, 5)):
+        gt = synth.sphere_phantom(n)
+        nzo = (n - 1) // inc + 1
+        psfs = [synth.gaussian_psf(k, sigma=(1.2, 1.4, 2.0 + 0.1 * v)) for v in range(nv)]
+        with mvs.Context(0) as c:
+            d_gt = _dev_volume(c, gt)
+            acq = [c.dev_alloc(nzo * n * n * 4) for _ in range(nv)]
+            con = [c.dev_alloc(gt.nbytes) for _ in range(nv)]
+            params = [c.view_params(degrees=15 + 50 * v, inc=inc, snr=25.0, seed=SEED, stream=v, conv_method=1) for v in range(nv)]
+            try:
+                for v in range(nv):
+                    c.simulate_view_dev(d_gt, (n, n, n), psfs[v].copy(), params[v], acq[v], con_dptr=con[v] if v % 2 else 0)
+                want = [c.download(a, (nzo, n, n)) for a in acq]
+                want_con = [c.download(x, gt.shape) for x in con]
+                assert want[0].max() > 0
+                for lanes in ("auto", 1, 2, 3, 8):
+                    for a in acq:
+                        c.upload(a, np.full((nzo, n, n), -1.0, np.float32))
+                    c.set_option("view_lanes", lanes)
+                    mine = [p.copy() for p in psfs]
+                    c.simulate_views_dev(d_gt, (n, n, n), mine, params, acq, con_dptrs=[con[v] if v % 2 else 0 for v in range(nv)])
+                    for v in range(nv):
+                        assert np.array_equal(c.download(acq[v], (nzo, n, n)), want[v]), (n, lanes, v)
+                        if v % 2:
+                            assert np.array_equal(c.download(con[v], gt.shape), want_con[v]), (n, lanes, v)
+                        assert abs(float(mine[v].astype(np.float64).sum()) - 1.0) < 1e-6      # normalised in place (Q5)
+                with pytest.raises(ValueError, match="overlap"):
+                    c.simulate_views_dev(d_gt, (n, n, n), [p.copy() for p in psfs[:2]], params[:2], [acq[0], acq[0]])
+                with pytest.raises(ValueError, match="overlap"):
+                    c.simulate_views_dev(d_gt, (n, n, n), [p.copy() for p in psfs[:2]], params[:2], [acq[0], d_gt])
+            finally:
+                for d in [d_gt] + acq + con:
+                    c.dev_free(d)
 
 
 @pytest.mark.parametrize("seed", range(12))

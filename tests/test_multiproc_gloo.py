@@ -32,3 +32,24 @@ def test_two_rank_sharding_and_broadcast(tmp_path):
     assert res["tmax"] == 2.0
     angs = sorted(a for d in g for a in d["angles"])
     assert angs == [15 + (360 * v) // 16 for v in range(16)]
+
+
+def test_two_rank_tiled_view_through_the_package(tmp_path):
+    """BASELINE configs[3]'s rank-level path (multiview-simulation_amd/tiling.py: TiledView) with two real gloo ranks: slab ranges from
+    the library, the one double of adjustImage's sum all-reduced between the processes, the acquired planes of each slab stitched --
+    equal to the untiled view.  No GPU here: the two slab entry points are stood in for by the oracle (tests/_tiled_gloo_worker.py);
+    the same worker logic runs on the GPU box with real contexts (tests/test_gpu_parity.py::test_tiled_view_two_gloo_ranks_on_one_gpu)."""
+    out = tmp_path / "tiled.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29537",
+           os.path.join(ROOT, "tests", "_tiled_gloo_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.load(open(out))
+    assert res["shape"] == res["want_shape"] == [5, 14, 14]                       # (14 - 1) // 3 + 1 planes
+    assert res["slabs"][0][:2] == [0, 7] and res["slabs"][1][:2] == [7, 14]
+    assert res["slabs"][0][2:4] == [0, 3] and res["slabs"][1][2:4] == [3, 5]       # planes k with z0 <= 3 k < z1
+    assert res["slabs"][0][4] == 9 and res["slabs"][1][4] == 9                     # 7 owned + 2 halo planes of the 5-deep PSF
+    assert res["totals"][0] == res["totals"][1] == res["sum_of_slab_sums"]         # the all-reduce delivered the same total to both
+    assert res["differing"] < 5e-3 and abs(res["mean"] / res["want_mean"] - 1) < 1e-3
