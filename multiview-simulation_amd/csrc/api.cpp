@@ -72,6 +72,11 @@ int parse_option(Options& o, const char* name, const char* value)
         else if (v == "2" || v == "any") o.tail_overlap = 2; else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
+    if (n == "view_batch") {
+        if (v == "auto") o.view_batch = 2; else if (v == "1" || v == "on") o.view_batch = 1; else if (v == "0" || v == "off") o.view_batch = 0;
+        else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
     if (n == "view_lanes") {
         if (v == "auto") { o.view_lanes = 0; return MVSIM_OK; }
         if (v.empty() || v.size() > 2 || v.find_first_not_of("0123456789") != std::string::npos) return MVSIM_EINVAL;
@@ -274,14 +279,9 @@ static int set_device(mvsim_ctx* ctx, bool keep_tail = false)
     return MVSIM_OK;
 }
 
-// Normalise the PSF on the host exactly as Tools.normImage does (double sum, (float)(v/sum)),
-// in place (Q5), then place it in device memory.
-static int psf_prepare(mvsim_ctx* ctx, float* psf_host, const int64_t kdim[3], const int64_t dim[3])
+// Tools.normImage on the host (Tools.java:112-132), in place (Q5): double sum, (float)(v / sum).
+static void psf_normalise_host(float* psf_host, int64_t n)
 {
-    MVSIM_CHECK_ARG(psf_host != nullptr && kdim != nullptr, "psf is null");
-    MVSIM_CHECK_ARG(kdim[0] >= 1 && kdim[1] >= 1 && kdim[2] >= 1, "psf dimensions must be >= 1");
-    (void)dim;
-    const int64_t n = kdim[0] * kdim[1] * kdim[2];
     // pairwise (cascade) double summation: same order of magnitude of error as mpicbg RealSum.  A binary counter of
     // partial sums (level l holds the sum of 2^l consecutive elements); aligned blocks of 16 enter it at level 4 with
     // their balanced tree written out -- the same additions in the same association as 16 single pushes (IEEE addition is
@@ -306,6 +306,16 @@ static int psf_prepare(mvsim_ctx* ctx, float* psf_host, const int64_t kdim[3], c
     double sum = 0.0;
     for (int l = 0; l < 64; ++l) if (used[l]) sum += lvl[l];
     for (int64_t i = 0; i < n; ++i) psf_host[i] = (float)((double)psf_host[i] / sum);
+}
+
+// Normalise the PSF on the host exactly as Tools.normImage does, in place (Q5), then place it in device memory.
+static int psf_prepare(mvsim_ctx* ctx, float* psf_host, const int64_t kdim[3], const int64_t dim[3])
+{
+    MVSIM_CHECK_ARG(psf_host != nullptr && kdim != nullptr, "psf is null");
+    MVSIM_CHECK_ARG(kdim[0] >= 1 && kdim[1] >= 1 && kdim[2] >= 1, "psf dimensions must be >= 1");
+    (void)dim;
+    const int64_t n = kdim[0] * kdim[1] * kdim[2];
+    psf_normalise_host(psf_host, n);
     MVSIM_TRY(ctx->psf_dev.reserve((size_t)n * sizeof(float)));
     int slot = 0;
     MVSIM_TRY(ctx->pinned.acquire((size_t)n * sizeof(float), &slot));
@@ -341,7 +351,7 @@ static int convolve_dev_impl(mvsim_ctx* ctx, const float* img, const int64_t dim
 
 static int scal_ptr(mvsim_ctx* ctx, double** partial, double** scal)
 {
-    MVSIM_TRY(ctx->partials.reserve((SUM_BLOCKS + 8) * sizeof(double)));
+    MVSIM_TRY(ctx->partials.reserve(PARTIALS_BYTES));
     *partial = ctx->partials.as<double>();
     *scal = scal_of(ctx);
     return MVSIM_OK;
@@ -413,7 +423,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     view_graphs_release(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
+    ctx->psf_dev.release(); ctx->view_tab.release(); ctx->stencil_psf.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
@@ -466,7 +476,7 @@ int mvsim_release_caches(mvsim_ctx* ctx)
     view_graphs_release(ctx);                             // captured launches point into the workspaces released below
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->stencil_psf.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
+    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->view_tab.release(); ctx->stencil_psf.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     return MVSIM_OK;
 }
@@ -998,6 +1008,117 @@ static int pick_view_lanes(const mvsim_ctx* ctx, const int64_t dim[3], int n_vie
     return std::max(1, std::min(lanes, n_views));
 }
 
+// ---- stacked views: ONE launch per stage for all V views ------------------------------------------------------------------
+// A view below ~2^26 voxels is a chain of a dozen dependent launches that each leave most of the chip idle (128^3: a few hundred
+// blocks per launch and ~10 us per link of the chain; 289^3: the rotate + attenuate kernel is 1 300 waves of serial latency), and the
+// host needs ~5 us per launch on top.  The views of `main`'s loop are independent and alike (SimulateMultiViewDataset.java:567-585:
+// same volume, same PSF size, same spacing), so their kernels take the view as one more grid dimension: the attenuated volumes, the
+// spectra, the PSFs' taps and the convolved planes of the V views lie back to back in the workspaces, the passes that work on planes
+// or rows (A, B, D, E, the PSF's own) simply see V times as many, and the kernels with per-view operands -- rotate + attenuate (the
+// view's inverse model), the z pass (its taps, its sum), extract + Poisson (its acquisition, RNG key, adjustImage factor) -- read them
+// from small device tables.  Every voxel goes through the same arithmetic in the same order as in a single view: bit-identical.
+static bool views_batchable(const mvsim_ctx* ctx, const int64_t dim[3], const int64_t kdim[3], const mvsim_view_params* params,
+                            const mvsim_view_outputs* outs, int n_views)
+{
+    if (n_views < 2 || ctx->opt.view_batch == 0 || ctx->opt.graph || ctx->opt.rocfft) return false;
+    const int64_t n = nvox(dim);
+    if (ctx->opt.view_batch == 2 && n > ((int64_t)1 << 26)) return false;            // auto: views that fill the chip by themselves stay single
+    if ((size_t)n * n_views * sizeof(float) > ((size_t)24 << 30)) return false;      // the stacked workspaces are ~6 x this
+    const mvsim_view_params& p0 = params[0];
+    if (pick_method(p0.conv_method, kdim) != 1 || !custom_fft_batchable(ctx, dim, kdim)) return false;
+    const bool noise = p0.snr >= 0.0f;
+    if (noise && ctx->opt.poisson_queue != 1) return false;
+    for (int v = 0; v < n_views; ++v) {
+        const mvsim_view_params& p = params[v];
+        if (p.axis != 0 || p.delta != p0.delta || p.inc != p0.inc || p.snr != p0.snr || p.min_value != p0.min_value ||
+            p.target_average != p0.target_average || pick_method(p.conv_method, kdim) != 1)
+            return false;
+        if (outs[v].rot || outs[v].att || outs[v].con) return false;                   // intermediates on request: the single-view path
+        double m[12];
+        Affine inv;
+        axis_rotation_host(dim, 0, p.degrees, m);
+        affine_invert_host(m, inv.m);
+        if (!(inv.m[0] == 1.0 && inv.m[1] == 0.0 && inv.m[2] == 0.0 && inv.m[3] == 0.0 && inv.m[4] == 0.0 && inv.m[8] == 0.0)) return false;
+    }
+    return true;
+}
+
+static int views_enqueue_batched(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* const* psf_host, const int64_t kdim[3],
+                                 const mvsim_view_params* params, const mvsim_view_outputs* outs, int V)
+{
+    const int64_t n = nvox(dim), k3 = kdim[0] * kdim[1] * kdim[2];
+    const mvsim_view_params& p0 = params[0];
+    const bool noise = p0.snr >= 0.0f;
+    const int64_t nzo = mvsim_extract_nz(dim[2], p0.inc), plane_vox = dim[0] * dim[1];
+    const int64_t n_out = plane_vox * nzo;
+    ev_next(ctx);
+    // one upload for everything the views bring: [V inverse models][V extract tables][V normalised PSFs]
+    const size_t tab_a = (size_t)V * sizeof(Affine), tab_e = (size_t)V * sizeof(ExtractView);
+    const size_t off_e = (tab_a + 255) & ~(size_t)255, off_p = (off_e + tab_e + 255) & ~(size_t)255;
+    const size_t up_bytes = off_p + (size_t)V * k3 * sizeof(float);
+    MVSIM_TRY(ctx->view_tab.reserve(up_bytes));
+    MVSIM_TRY(ctx->vol_b.reserve((size_t)V * n * sizeof(float)));                       // att[v]
+    const int zstride = (p0.inc > 1 && plane_vox % 4 == 0) ? p0.inc : 1;                // (as view_enqueue: compact planes when the sampler takes 16-byte rows)
+    const int64_t con_planes = zstride > 1 ? nzo : dim[2];
+    MVSIM_TRY(ctx->vol_a.reserve((size_t)V * plane_vox * con_planes * sizeof(float)));  // con[v]
+    const size_t qbytes = noise ? ((poisson_queue_bytes(n_out, nullptr) + 255) & ~(size_t)255) : 0;
+    if (noise) MVSIM_TRY(ctx->pqueue.reserve(qbytes * V));
+    double *partial, *scal0;
+    MVSIM_TRY(scal_ptr(ctx, &partial, &scal0));
+    int slot = 0;
+    MVSIM_TRY(ctx->pinned.acquire(up_bytes, &slot));
+    char* hp = reinterpret_cast<char*>(ctx->pinned.p[slot]);
+    char* dp = ctx->view_tab.as<char>();
+    Affine* atab = reinterpret_cast<Affine*>(hp);
+    ExtractView* etab = reinterpret_cast<ExtractView*>(hp + off_e);
+    float* con = ctx->vol_a.as<float>();
+    bool vec_all = true;
+    for (int v = 0; v < V; ++v) {
+        double m[12];
+        axis_rotation_host(dim, 0, params[v].degrees, m);
+        affine_invert_host(m, atab[v].m);
+        ExtractView& e = etab[v];
+        e.in = con + (size_t)v * plane_vox * con_planes;
+        e.out = outs[v].acq;
+        e.scal = scal_of(ctx, v);
+        e.queue = nullptr; e.qcount = nullptr;
+        if (noise) poisson_queue_split(ctx->pqueue.as<char>() + (size_t)v * qbytes, &e.queue, &e.qcount);
+        e.k0 = (uint32_t)params[v].seed; e.k1 = (uint32_t)(params[v].seed >> 32); e.stream = params[v].stream; e.pad = 0;
+        vec_all = vec_all && ((reinterpret_cast<uintptr_t>(e.in) | reinterpret_cast<uintptr_t>(e.out)) % 16 == 0);
+        psf_normalise_host(psf_host[v], k3);
+        std::memcpy(hp + off_p + (size_t)v * k3 * sizeof(float), psf_host[v], (size_t)k3 * sizeof(float));
+    }
+    MVSIM_HIP(hipMemcpyAsync(dp, hp, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+    MVSIM_HIP(hipEventRecord(ctx->pinned.ev[slot], ctx->stream));
+    ctx->pinned.busy[slot] = true;
+
+    ev_begin(ctx, ST_ROTATE);
+    MVSIM_TRY(launch_rotate_attenuate_views(ctx->stream, gt, ctx->vol_b.as<float>(), dim, reinterpret_cast<const Affine*>(dp), V, p0.delta));
+    ev_end(ctx, ST_ROTATE);
+
+    ConvTail tail;
+    tail.views = V;
+    tail.zstride = zstride;
+    tail.corr_n = n; tail.min_value = p0.min_value; tail.target_average = p0.target_average;
+    int64_t P[3];
+    if (!custom_fft_sizes(dim, kdim, P, ctx->opt)) { set_error("stacked views: no hand-written FFT size"); return MVSIM_EINVAL; }
+    MVSIM_TRY(custom_fft_convolve(ctx, ctx->vol_b.as<float>(), dim, reinterpret_cast<const float*>(dp + off_p), kdim, P, con, &tail));
+    if (!tail.corr_done || tail.zstride != zstride) { set_error("stacked views: the convolution did not deliver the factors / planes asked for"); return MVSIM_EHIP; }
+
+    ev_begin(ctx, ST_EXTRACT);
+    const ExtractView* evt = reinterpret_cast<const ExtractView*>(dp + off_e);
+    if (zstride > 1) {
+        const int64_t cdim[3] = {dim[0], dim[1], nzo};                                  // `con` holds the acquired planes only
+        MVSIM_TRY(launch_extract_views(ctx->stream, cdim, 1, true, p0.min_value, noise, mvsim_poisson_mul((double)p0.snr), ctx->opt.poisson_queue,
+                                       p0.inc, V, evt, vec_all));
+    } else {
+        MVSIM_TRY(launch_extract_views(ctx->stream, dim, p0.inc, true, p0.min_value, noise, mvsim_poisson_mul((double)p0.snr), ctx->opt.poisson_queue,
+                                       0, V, evt, vec_all));
+    }
+    ev_end(ctx, ST_EXTRACT);
+    return MVSIM_OK;
+}
+
 int mvsim_simulate_views_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* const* psf_host, const int64_t kdim[3],
                              const mvsim_view_params* params, const mvsim_view_outputs* outs, int n_views)
 {
@@ -1033,6 +1154,11 @@ int mvsim_simulate_views_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[
             for (size_t j = i + 1; j < w.size() && !meet; ++j) meet = w[i].lo < w[j].hi && w[j].lo < w[i].hi;
         }
         MVSIM_CHECK_ARG(!meet, "simulate_views: output buffers overlap each other or the ground truth");
+    }
+    if (views_batchable(ctx, dim, kdim, params, outs, n_views)) {
+        const int rc = views_enqueue_batched(ctx, gt, dim, psf_host, kdim, params, outs, n_views);
+        ev_rebalance(ctx);
+        return rc;
     }
     const int nl = pick_view_lanes(ctx, dim, n_views);
     if (nl <= 1) {

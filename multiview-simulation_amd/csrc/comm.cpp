@@ -365,8 +365,8 @@ int mvsim_comm_allreduce_sum_f64(mvsim_ctx* ctx, double* value_host)
     MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
     MVSIM_HIP(hipSetDevice(ctx->device));
     MVSIM_TRY(mvsim::join_tail(ctx));
-    MVSIM_TRY(ctx->partials.reserve((mvsim::SUM_BLOCKS + 8) * sizeof(double)));
-    double* slot = ctx->partials.as<double>() + mvsim::SUM_BLOCKS + 4;        // scratch behind [sum, corr]
+    MVSIM_TRY(ctx->partials.reserve(mvsim::PARTIALS_BYTES));
+    double* slot = ctx->partials.as<double>() + mvsim::SUM_BLOCKS + mvsim::SCAL_DOUBLES + 4;   // scratch behind the [sum, corr] pairs
     MVSIM_HIP(hipMemcpyAsync(slot, value_host, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MVSIM_NCCL(ncclAllReduce(slot, slot, 1, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
     MVSIM_HIP(hipMemcpyAsync(value_host, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

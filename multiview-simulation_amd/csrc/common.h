@@ -135,6 +135,8 @@ struct Options {
                                        // at 512^3): measured neutral to slightly slower, so off by default
     int     graph = 0;                 // replay simulate_view_dev from a captured hipGraph (small, launch-bound volumes)
     int     view_lanes = 0;            // mvsim_simulate_views_dev: views in flight side by side (0 = auto: from the size of a view)
+    int     view_batch = 2;            // mvsim_simulate_views_dev: the views STACKED -- one launch per stage for all of them (api.cpp:
+                                       // views_enqueue_batched): 0 never, 1 whenever the views allow it, 2 auto (views of <= 2^26 voxels)
     bool    bcast_ring = false;        // ground-truth broadcast as one ncclBroadcast instead of scatter + all-gather
     bool    bcast_peer_copy = false;   // ... or as copy-engine transfers between IPC-mapped buffers (comm.cpp: bcast_peer_copy)
     int64_t fft_pad[3] = {0, 0, 0};    // explicit padded sizes on the rocFFT path (0: choose)
@@ -164,6 +166,7 @@ struct mvsim_ctx {
     mvsim::DevBuf vol_a, vol_b, vol_c;      // N-sized float staging for host entry points / fused path
     mvsim::DevBuf out_buf;                  // extract output staging
     mvsim::DevBuf psf_dev;                  // K^3 floats
+    mvsim::DevBuf view_tab;                 // stacked views: [inverse models][extract tables][PSFs] of the current batch
     mvsim::DevBuf stencil_psf;              // direct stencil: PSF reversed along x, rows zero-padded to 4 taps
     mvsim::PinnedRing pinned;
     mvsim::DevBuf fft_real;                 // P^3 floats
@@ -254,7 +257,7 @@ struct mvsim_ctx {
 inline mvsim_ctx::mvsim_ctx()
 {
     for (mvsim::DevBuf* b : {&vol_a, &vol_b, &vol_c, &out_buf, &psf_dev, &stencil_psf, &fft_real, &fft_spec_img, &fft_spec_psf, &fft_work,
-                             &pqueue, &sphere_list, &weight_img, &plane_flags, &host_gt, &host_rot, &host_att, &host_con, &partials, &partials_e, &cfft_f, &cfft_g,
+                             &pqueue, &view_tab, &sphere_list, &weight_img, &plane_flags, &host_gt, &host_rot, &host_att, &host_con, &partials, &partials_e, &cfft_f, &cfft_g,
                              &cfft_g1, &cfft_g2, &partials_z, &async_gt[0], &async_gt[1], &async_acq[0], &async_acq[1]})
         b->epoch = &alloc_epoch;
 }
@@ -282,6 +285,19 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
                    uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc = 0);
 // bytes of the Poisson work queue (HBM) for n_out output voxels
 size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity);
+// ---- stacked views (mvsim_simulate_views_dev): one launch per stage for V views of one ground truth; blockIdx.y / .z = view
+struct ExtractView {              // per-view operands of the extract + Poisson kernels (device table)
+    const float*  in;             // the view's convolved planes
+    float*        out;            // its acquisition
+    const double* scal;           // its [sum, adjustImage factor]
+    void*         queue;          // its Poisson work-queue segments (PItem) ...
+    unsigned int* qcount;         // ... and their counters
+    uint32_t      k0, k1, stream, pad;
+};
+int launch_rotate_attenuate_views(hipStream_t s, const float* in, float* att, const int64_t dim[3], const Affine* atab_dev, int nviews, double delta);
+void poisson_queue_split(void* queue_ws, void** queue_items, unsigned int** qcount);
+int launch_extract_views(hipStream_t s, const int64_t dim[3], int inc, bool adjust, float min_value, bool noise, double mul,
+                         int queue_mode, int index_inc, int nviews, const ExtractView* vt_dev, bool vec_all);
 int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc);
 // phantom generator (phantom.hip)
 int launch_downsample2x(hipStream_t s, const float* in, const int64_t dim[3], float* out);
@@ -309,6 +325,9 @@ int ensure_lds_attr(mvsim_ctx* ctx, const void* kernel, size_t bytes);
 // What the caller would like the tail of the convolution to do beyond "write the convolved volume"; every request is
 // optional for the implementation, which reports back what it did.
 struct ConvTail {
+    // in: `img` / `psf` / `out` hold this many views stacked back to back (mvsim_simulate_views_dev; the caller has checked
+    // custom_fft_batchable): one launch per pass for all of them, sums and factors in the context's scalar pairs 0 .. views-1
+    int views = 1;
     // in: produce only the planes k * zstride (the planes extractSlices will read) into a COMPACT out[nk][Ny][Nx].
     // Possible when adjustImage's sum comes from the spectrum side (early sum); out: the stride actually applied (1 = full).
     int zstride = 1;
@@ -364,6 +383,9 @@ int  custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t di
                               const int64_t kdim[3], const int64_t P[3], const SlabRange& slab, float* out, ConvTail* tail);
 void custom_fft_release(mvsim_ctx* ctx);
 bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[5], const Options& opt);
+// true when views of this geometry can run stacked through the hand-written passes (ConvTail::views > 1): direct z pass, early sum,
+// pass B reading the mirrored y halo from its mirror images, no inline-FFT z pass, no fused tail
+bool custom_fft_batchable(const mvsim_ctx* ctx, const int64_t dim[3], const int64_t kdim[3]);
 
 // stage markers: a roctx range per stage (what rocprofv3 --marker-trace / a timeline shows around the launches; the reference
 // prints a time stamp per stage, SimulateMultiViewDataset.java:553-590) and, when timing is on, HIP events recorded on the
@@ -404,8 +426,11 @@ inline void ev_next(mvsim_ctx* ctx)
     for (int s = 0; s < ST_COUNT; ++s) ctx->ev_used[ctx->ev_cur][s] = false;
 }
 
-// [sum, adjustImage factor] of the current view, behind the block partials
-inline double* scal_of(mvsim_ctx* ctx) { return ctx->partials.as<double>() + SUM_BLOCKS; }
+// [sum, adjustImage factor] of the current view, behind the block partials; stacked views: one pair per view.  The doubles behind
+// the pairs are scratch of the one-double all-reduce (comm.cpp)
+constexpr int SCAL_DOUBLES = 2 * MVSIM_MAX_VIEWS;
+constexpr size_t PARTIALS_BYTES = (size_t)(SUM_BLOCKS + SCAL_DOUBLES + 8) * sizeof(double);
+inline double* scal_of(mvsim_ctx* ctx, int view = 0) { return ctx->partials.as<double>() + SUM_BLOCKS + 2 * view; }
 
 // comm.cpp: a device range is about to go away -- drop the peer mappings registered for it (broadcast=peer_copy)
 void comm_forget_range(mvsim_ctx* ctx, const void* p, size_t bytes);

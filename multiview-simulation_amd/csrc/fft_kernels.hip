@@ -659,6 +659,8 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
                                                           float min_value, float target)
 {
     __shared__ double sh[16];
+    partial += (long long)blockIdx.x * count;             // stacked views: block v reduces view v's partials into its own pair
+    scal += 2 * blockIdx.x;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     long long i = threadIdx.x;
     for (; i + 3 * 1024 < count; i += 4 * 1024) {
@@ -746,7 +748,19 @@ struct ZConvArgs {
     int           stride, frows;
     // tiles: nch chunks along z x nkxb groups of NLZ columns x py rows, on a 1-D grid (zconv_tile)
     int           nch, nkxb, py, plain_order;
+    // stacked views (mvsim_simulate_views_dev; blockIdx.y = view): view v finds its planes, its outputs and the taps of ITS PSF that
+    // many elements further on, and its partial sums behind those of the views before it
+    long long     src_view, dst_view, taps_view;
 };
+
+__device__ __forceinline__ void zconv_view(ZConvArgs& p)
+{
+    const long long v = blockIdx.y;                       // 0 for a single view (strides unused)
+    p.src += v * p.src_view;
+    p.dst += v * p.dst_view;
+    p.taps += v * p.taps_view;
+    if (p.sum_partial) p.sum_partial += v * ((long long)p.nch * p.nkxb * p.py);
+}
 
 // Which tile a block of the z pass works on.  Workgroups go to the eight XCDs round robin by their linear id, and the chunks of one
 // column group share their halo rows and all of their taps: with the chunk index fastest in the GRID, neighbours landed on different
@@ -780,6 +794,7 @@ constexpr int TNIT = 64 / ZRPI;                       // kzp <= 64 rows of taps
 __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
 {
     extern __shared__ __align__(16) float2 lds[];
+    zconv_view(p);
     const int kzp = (p.kz + ZJ - 1) / ZJ * ZJ;            // taps padded with zeros to whole chunks
     const int padf = kzp - p.kz;                          // leading zero rows the padded taps may touch
     int chunk, kxb, ky;
@@ -993,6 +1008,7 @@ template <int S>
 __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv_strided(ZConvArgs p)
 {
     extern __shared__ __align__(16) float2 lds[];
+    zconv_view(p);
     constexpr int PITCH = NLZ;
     const int nq = (p.kz + S - 1) / S;                    // taps of phase 0 (the longest)
     const int qp = (nq + ZJ - 1) / ZJ * ZJ;               // ... padded to whole chunks
@@ -1240,12 +1256,13 @@ static dim3 zconv_grid(ZConvArgs& a, int py, int cols, int env_exp)
     return dim3((unsigned)((total + 7) / 8 * 8));
 }
 
-static int launch_zconv(mvsim_ctx* ctx, const ZConvArgs& args, int py, int cols = 0)
+static int launch_zconv(mvsim_ctx* ctx, const ZConvArgs& args, int py, int views = 1)
 {
     hipStream_t s = ctx->stream;
     ZConvArgs a = args;
     const size_t lds = zconv_lds(a.zc, a.kz);
-    const dim3 grid = zconv_grid(a, py, cols, ctx->opt.exp);
+    dim3 grid = zconv_grid(a, py, 0, ctx->opt.exp);
+    grid.y = (unsigned)views;
     MVSIM_TRY(set_lds(ctx, k_zconv, lds));
     hipLaunchKernelGGL(k_zconv, grid, dim3(ZT), lds, s, a);
     MVSIM_HIP(hipGetLastError());
@@ -1292,11 +1309,12 @@ static int zconv_strided_chunk(int nz, int kz, int s, bool force, int* frows_out
     return zc;
 }
 
-static int launch_zconv_strided(mvsim_ctx* ctx, const ZConvArgs& args, int py, size_t lds)
+static int launch_zconv_strided(mvsim_ctx* ctx, const ZConvArgs& args, int py, size_t lds, int views = 1)
 {
     hipStream_t s = ctx->stream;
     ZConvArgs a = args;
-    const dim3 grid = zconv_grid(a, py, 0, ctx->opt.exp);
+    dim3 grid = zconv_grid(a, py, 0, ctx->opt.exp);
+    grid.y = (unsigned)views;
     switch (a.stride) {
     case 2: MVSIM_TRY(set_lds(ctx, k_zconv_strided<2>, lds)); hipLaunchKernelGGL(k_zconv_strided<2>, grid, dim3(ZT), lds, s, a); break;
     case 3: MVSIM_TRY(set_lds(ctx, k_zconv_strided<3>, lds)); hipLaunchKernelGGL(k_zconv_strided<3>, grid, dim3(ZT), lds, s, a); break;
@@ -1588,6 +1606,19 @@ bool custom_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t g[
     return true;
 }
 
+bool custom_fft_batchable(const mvsim_ctx* ctx, const int64_t dim[3], const int64_t kdim[3])
+{
+    using namespace fft;
+    const Options& o = ctx->opt;
+    int64_t P[3];
+    if (!custom_fft_sizes(dim, kdim, P, o)) return false;
+    const int ny = (int)dim[1], ky = (int)kdim[1], kz = (int)kdim[2];
+    const bool zdirect = o.zpass == 2 ? false : kz <= 64;
+    if (!zdirect || !o.early_sum || o.fuse_tail || o.zpass == 3) return false;
+    if (o.zpass == 0 && kz >= MVSIM_ZINLINE_MIN_KZ && P[2] >= 512 && lines_per_tile((int)P[2]) == 16) return false;   // the inline FFT z pass
+    return ny > 1 && ky / 2 < ny && ky - 1 - ky / 2 < ny;         // one reflection reaches every halo row (ymirror)
+}
+
 // Rotate (about x) + attenuate + pass A as one kernel (rotate_fft.hip) when the view's geometry allows it: the attenuated
 // volume then never crosses HBM unless the caller asked for it.  *done = false: nothing was enqueued, the caller runs the
 // separate kernels.  On success the context's spectrum buffer F holds what pass A would have written for `att`, and the
@@ -1668,6 +1699,10 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
 {
     using namespace fft;
     const bool is_slab = slab.nz_in != (int)dim[2] || slab.nz_out != (int)dim[2];
+    // stacked views (ConvTail::views = V > 1; the caller has asked custom_fft_batchable): `img` holds V attenuated volumes back to back,
+    // `psf` V PSFs, `out` receives V convolved volumes (compact planes: V x nk), the context's scalar pairs 0 .. V-1 the sums and factors.
+    // Passes A, B, D, E and the PSF's passes work on planes (rows) and simply see V x as many; the z pass carries the view in its grid.
+    const int V = (tail && tail->views > 1) ? tail->views : 1;
     const int px = (int)P[0], py = (int)P[1], pz = (int)P[2];
     const int kx = (int)kdim[0], ky = (int)kdim[1], kz = (int)kdim[2];
     const int M = px / 2;
@@ -1693,20 +1728,27 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         set_error("z-slab tiling needs the direct z pass (PSF depth %d > 64 or option fft_zpass=fft)", kz);
         return MVSIM_EINVAL;
     }
+    if (V > 1 && (is_slab || !zdirect || !early || fuse || (tail && (tail->x_done || tail->plane_nz)))) {
+        set_error("stacked views need the direct z pass with the early sum on whole views");
+        return MVSIM_EINVAL;
+    }
     const int nzs = slab.nz_in;                                   // planes the image spectrum holds when zdirect
     const int nzo = slab.nz_out;                                  // planes that leave the z pass
     int tw_max = tile_y > tile_z ? tile_y : tile_z;
     if (zdirect) tw_max = tile_y > NLZ ? tile_y : NLZ;
     const int hxp = ((M + 1 + tw_max - 1) / tw_max) * tw_max;
     const int pyb = (py + ZB - 1) / ZB * ZB;                        // rows of a plane in the z-blocked layout
-    const size_t cbytes = (size_t)hxp * (zdirect ? pyb : py) * (zdirect ? nzs : pz) * sizeof(float2);
-    const long long rows_out_early = (long long)dim[1] * nzo;
+    const int nkv = (nzo - 1) / zstride + 1;                        // planes per view that leave passes D and E
+    const int nzp = V > 1 ? nkv * zstride : nzo;                    // plane pitch of a view in the z pass's output: the planes k * zstride of
+                                                                    // every view at multiples of zstride of the stacked index (pass D's stride)
+    const size_t cbytes = (size_t)hxp * (zdirect ? pyb : py) * (zdirect ? (size_t)V * std::max(nzs, nzp) : (size_t)pz) * sizeof(float2);
+    const long long rows_out_early = (long long)dim[1] * nzo * V;
     MVSIM_TRY(ctx->cfft_f.reserve(cbytes));
     MVSIM_TRY(ctx->cfft_g.reserve(cbytes));
     // compact PSF intermediates: G1 [kz][ky][hxp] (x transformed), G2 [kz][py][hxp] (x,y transformed)
-    MVSIM_TRY(ctx->cfft_g1.reserve((size_t)hxp * ky * kz * sizeof(float2)));
-    MVSIM_TRY(ctx->cfft_g2.reserve((size_t)hxp * pyb * kz * sizeof(float2)));
-    MVSIM_TRY(ctx->partials.reserve((size_t)(SUM_BLOCKS + 8) * sizeof(double)));
+    MVSIM_TRY(ctx->cfft_g1.reserve((size_t)V * hxp * ky * kz * sizeof(float2)));
+    MVSIM_TRY(ctx->cfft_g2.reserve((size_t)V * hxp * pyb * kz * sizeof(float2)));
+    MVSIM_TRY(ctx->partials.reserve(PARTIALS_BYTES));
     MVSIM_TRY(ctx->partials_e.reserve((size_t)((rows_out_early + 3) / 4 + 16) * sizeof(double)));
     double* scal = scal_of(ctx);
 
@@ -1721,7 +1763,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     size_t zs_lds = 0;
     const int zs_chunk = (zdirect && zstride > 1 && ctx->opt.zconv_strided && ctx->opt.zpass != 3)
                              ? zconv_strided_chunk(slab.nz_out, kz, zstride, (ctx->opt.exp & 2) != 0, &zs_frows, &zs_lds) : 0;
-    const bool zinline = zdirect && !is_slab && zs_chunk == 0 &&
+    const bool zinline = zdirect && !is_slab && zs_chunk == 0 && V == 1 &&
                          (ctx->opt.zpass == 3 || (ctx->opt.zpass == 0 && kz >= MVSIM_ZINLINE_MIN_KZ && pz >= 512 && lines_per_tile(pz) == 16));
     const float2 *tw_m, *tw_px, *tw_py, *tw_pz;
     MVSIM_TRY(ensure_twiddles(ctx, M, 0, &tw_m));
@@ -1763,15 +1805,15 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         SrcMap m{};
         m.x = DimMap{kx, px, kx - kx / 2, kx / 2, 1, kx / 2};   // embed along x with wrap-around
         m.y = DimMap{ky, ky, ky, 0, 1, 0};                       // compact: identity
-        m.z = DimMap{kz, kz, kz, 0, 1, 0};
-        if ((psf_rc = launch_r2c(ctx, M, psf, m, G1, tw_m, tw_px, hxp, (long long)ky * kz)) != MVSIM_OK) break;
+        m.z = DimMap{kz * V, kz * V, kz * V, 0, 1, 0};             // (stacked PSFs: V x Kz planes of taps)
+        if ((psf_rc = launch_r2c(ctx, M, psf, m, G1, tw_m, tw_px, hxp, (long long)ky * kz * V)) != MVSIM_OK) break;
         LinesArgs a{};
         a.src = G1; a.dst = G2; a.spec = nullptr; a.tw = tw_py;
         a.src_es = hxp; a.src_outer = (long long)hxp * ky;          // per kz plane
         a.dst_es = hxp; a.dst_outer = plane;
-        if (zdirect) { a.dst_outer = (long long)ZB * hxp; a.dst_blk = (long long)kz * ZB * hxp; }   // the z pass reads its taps z-blocked
+        if (zdirect) { a.dst_outer = (long long)ZB * hxp; a.dst_blk = (long long)kz * V * ZB * hxp; }   // the z pass reads its taps z-blocked
         a.lmap = DimMap{ky, py, ky - ky / 2, ky / 2, 1, ky / 2};
-        if ((psf_rc = launch_lines(ctx, py, FWD, true, a, hxp / tile_y, kz)) != MVSIM_OK) break;
+        if ((psf_rc = launch_lines(ctx, py, FWD, true, a, hxp / tile_y, kz * V)) != MVSIM_OK) break;
         if (!zdirect) {
             LinesArgs c{};
             c.src = G2; c.dst = G; c.spec = nullptr; c.tw = tw_pz;
@@ -1802,7 +1844,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             const int left = (int)(kdim[d] - 1 - kdim[d] / 2);
             *dm[d] = DimMap{n[d], Pd[d], n[d] + c, left, 0, 0};
         }
-        if (zdirect) m.z = DimMap{nzs, nzs, nzs, 0, 0, 0};           // no z padding: k_zconv mirrors through an index map
+        if (zdirect) m.z = DimMap{nzs * V, nzs * V, nzs * V, 0, 0, 0};   // no z padding: k_zconv mirrors through an index map
         // direct z pass: the mirrored halo rows along y are copies of rows pass A transforms anyway, so it transforms the Ny
         // rows of a plane only and pass B reads the halo positions from their mirror images (same bytes, from L2)
         SrcMap ma = m;
@@ -1813,7 +1855,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             if (!(zdirect && ymirror) || is_slab) { set_error("x_done without the geometry of the fused x transform"); return MVSIM_EINVAL; }
         } else {
             ev_begin(ctx, ST_PASS_A);
-            MVSIM_TRY(launch_r2c(ctx, M, img, ma, F, tw_m, tw_px, hxp, zdirect ? (long long)(ymirror ? m.y.n : py) * nzs : rows_all));
+            MVSIM_TRY(launch_r2c(ctx, M, img, ma, F, tw_m, tw_px, hxp, zdirect ? (long long)(ymirror ? m.y.n : py) * nzs * V : rows_all));
             ev_end(ctx, ST_PASS_A);
         }
         // zero gap of the padded volume: y in [Ny + cy, Py - lefty), z in [Nz + cz, Pz - leftz).  Pass A does not
@@ -1829,12 +1871,12 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         if (zdirect) {
             // out of place into the z-blocked layout the z pass reads and writes: G[(ky >> ZBS)][z][ky & (ZB-1)][kx]
             b.outer_skip_lo = 1 << 30; b.outer_skip_len = 0;
-            b.dst = G; b.dst_outer = (long long)ZB * hxp; b.dst_blk = (long long)nzs * ZB * hxp;
+            b.dst = G; b.dst_outer = (long long)ZB * hxp; b.dst_blk = (long long)nzs * V * ZB * hxp;
         }
         float2* Fz = F;                                               // where passes D and E find the z-convolved spectrum
         const int* em_flags = nullptr;                                // planes passes D and E skip (see pnz below)
         const int nzd = zdirect ? nzo : (int)dim[2];                  // planes z >= Nz are never read
-        const int nk = (nzd - 1) / zstride + 1;                       // planes 0, zstride, 2 zstride, ...
+        const int nk = ((nzd - 1) / zstride + 1) * V;                 // planes 0, zstride, 2 zstride, ... (of every stacked view)
         {
         // planes the fused rotate kernel found empty: B skips them, C' does not load them and skips tiles made of nothing else, D and E
         // skip the planes whose taps reach nothing but empty planes (exact: their spectra are zero) -- a specimen in empty space
@@ -1857,7 +1899,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             b.nzflags = pnz; b.nz_stride = 1;
         }
         ev_begin(ctx, ST_PASS_B);
-        MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs : pz - b.outer_skip_len));
+        MVSIM_TRY(launch_lines(ctx, py, FWD, false, b, hxp / tile_y, zdirect ? nzs * V : pz - b.outer_skip_len));
         ev_end(ctx, ST_PASS_B);
         b.lmap = ident_none; b.src_mirror = 0;
         if (side) MVSIM_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));    // the z pass reads the PSF spectrum
@@ -1893,8 +1935,9 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         } else if (zdirect) {
             ZConvArgs z{};
             z.src = G; z.dst = F; z.taps = G2; z.hxp = hxp; z.nz = nzo; z.kz = kz; z.c = kz / 2;
-            z.zs = (long long)ZB * hxp; z.src_blk = (long long)nzs * ZB * hxp; z.dst_blk = (long long)nzo * ZB * hxp;
-            z.taps_blk = (long long)kz * ZB * hxp;
+            z.zs = (long long)ZB * hxp; z.src_blk = (long long)nzs * V * ZB * hxp; z.dst_blk = (long long)nzp * V * ZB * hxp;
+            z.taps_blk = (long long)kz * V * ZB * hxp;
+            z.src_view = (long long)nzs * z.zs; z.dst_view = (long long)nzp * z.zs; z.taps_view = (long long)kz * z.zs;
             z.nz_global = (int)dim[2]; z.z_in0 = slab.z_in0; z.z_out0 = slab.z_out0;
             z.zc = zs_chunk > 0 ? zs_chunk : zconv_chunk(nzo, kz);
             z.stride = zs_chunk > 0 ? zstride : 1; z.frows = zs_frows;
@@ -1905,14 +1948,14 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
                 MVSIM_TRY(ensure_box_weights(ctx, (int)dim[0], px, hxp, true, &z.wx));
                 MVSIM_TRY(ensure_box_weights(ctx, (int)dim[1], py, py, false, &z.wy));
                 zblocks = zconv_blocks(z, py);
-                MVSIM_TRY(ctx->partials_z.reserve((size_t)zblocks * sizeof(double)));
+                MVSIM_TRY(ctx->partials_z.reserve((size_t)zblocks * V * sizeof(double)));
                 z.sum_partial = ctx->partials_z.as<double>();
             }
-            if (zs_chunk > 0) MVSIM_TRY(launch_zconv_strided(ctx, z, py, zs_lds));
-            else MVSIM_TRY(launch_zconv(ctx, z, py));
+            if (zs_chunk > 0) MVSIM_TRY(launch_zconv_strided(ctx, z, py, zs_lds, V));
+            else MVSIM_TRY(launch_zconv(ctx, z, py, V));
             if (early) {
                 // same factor pass E applies to every voxel (a float), so that the two sums estimate the same quantity
-                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s, z.sum_partial, zblocks, scal, (double)scale_f,
+                hipLaunchKernelGGL(k_reduce_partials, dim3(V), dim3(1024), 0, s, z.sum_partial, zblocks, scal, (double)scale_f,
                                    corr_n, corr_min, corr_target);
                 MVSIM_HIP(hipGetLastError());
             }
@@ -1933,7 +1976,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         b.store_limit = (int)dim[1];                                  // pass E only reads rows y < Ny
         b.src_outer = b.dst_outer = plane * zstride;
         b.dst_blk = 0;
-        if (zdirect) { b.src = F; b.src_outer = (long long)ZB * hxp * zstride; b.src_blk = (long long)nzo * ZB * hxp; }
+        if (zdirect) { b.src = F; b.src_outer = (long long)ZB * hxp * zstride; b.src_blk = (long long)nzp * V * ZB * hxp; }
         b.nzflags = nullptr;
         if (pnz) { b.nzflags = pnz_dil; b.nz_stride = zstride; em_flags = pnz_dil; }
         ev_begin(ctx, ST_PASS_D);

@@ -264,7 +264,7 @@ int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], con
     MVSIM_TRY(ctx->fft_real.reserve(nreal * sizeof(float)));
     MVSIM_TRY(ctx->fft_spec_img.reserve(ncplx * sizeof(float2)));
     MVSIM_TRY(ctx->fft_spec_psf.reserve(ncplx * sizeof(float2)));
-    MVSIM_TRY(ctx->partials.reserve((SUM_BLOCKS + 8) * sizeof(double)));
+    MVSIM_TRY(ctx->partials.reserve(PARTIALS_BYTES));
     if (pl->work_bytes) {
         MVSIM_TRY(ctx->fft_work.reserve(pl->work_bytes));
         MVSIM_FFT(rocfft_execution_info_set_work_buffer(pl->info, ctx->fft_work.p, pl->work_bytes));

@@ -363,10 +363,18 @@ constexpr int GEO_CHUNK = 512;  // rows per LDS table (24 KB)
 template <int U, bool WRITE_ROT>
 __global__ __launch_bounds__(1024) void k_rotate_attenuate_axis0_lds(const float* __restrict__ in, float* __restrict__ rot_out,
                                                                      float* __restrict__ att_out, int nx, int ny, int nz,
-                                                                     int steps, Affine a, double delta, int z_off, int z_cnt)
+                                                                     int steps, Affine a, double delta, int z_off, int z_cnt,
+                                                                     const Affine* __restrict__ atab, long long view_stride)
 {
     __shared__ RowGeo geo[GEO_CHUNK];
     __shared__ int bclass[GEO_CHUNK / U];
+    if (atab) {
+        // stacked views of ONE ground truth (mvsim_simulate_views_dev): blockIdx.z names the view -- its inverse model from the table,
+        // its planes `view_stride` voxels further on in the outputs
+        a = atab[blockIdx.z];
+        att_out += (long long)blockIdx.z * view_stride;
+        if (WRITE_ROT) rot_out += (long long)blockIdx.z * view_stride;
+    }
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     // Plane order: consecutive block ids go to different XCDs (round-robin dispatch, for speed only), and the output
     // planes z and z + 1 read the same source rows; giving every XCD a contiguous slab of planes keeps that reuse inside
@@ -563,9 +571,11 @@ int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or
         const int waves = (nx + 63) / 64 < 16 ? (nx + 63) / 64 : 16;
         dim3 grid_l((nx + waves * 64 - 1) / (waves * 64), (z_count + 7) / 8 * 8), block_l(waves * 64);
         if (rot_or_null)
-            hipLaunchKernelGGL((k_rotate_attenuate_axis0_lds<8, true>), grid_l, block_l, 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin, z_count);
+            hipLaunchKernelGGL((k_rotate_attenuate_axis0_lds<8, true>), grid_l, block_l, 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin, z_count,
+                               (const Affine*)nullptr, 0ll);
         else
-            hipLaunchKernelGGL((k_rotate_attenuate_axis0_lds<8, false>), grid_l, block_l, 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin, z_count);
+            hipLaunchKernelGGL((k_rotate_attenuate_axis0_lds<8, false>), grid_l, block_l, 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin, z_count,
+                               (const Affine*)nullptr, 0ll);
         MVSIM_HIP(hipGetLastError());
         return MVSIM_OK;
     }
@@ -574,6 +584,20 @@ int launch_rotate_attenuate_planes(hipStream_t s, const float* in, float* rot_or
         hipLaunchKernelGGL((k_rotate_attenuate_axis0<8, true>), grid, dim3(64), 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin);
     else
         hipLaunchKernelGGL((k_rotate_attenuate_axis0<8, false>), grid, dim3(64), 0, s, in, rot_or_null, att, nx, ny, nz, nx, inv, delta, z_begin);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// `nviews` views of one ground truth (rotation about x each, inverse models in the device table `atab`) into the stacked attenuated
+// volumes att[v][Nz][Ny][Nx]: ONE launch whose grid carries the view index, so that views too small to fill the chip fill it
+// together -- a 128^3 view is 256 waves of serial latency, eight of them are two waves per SIMD.
+int launch_rotate_attenuate_views(hipStream_t s, const float* in, float* att, const int64_t dim[3], const Affine* atab, int nviews, double delta)
+{
+    const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
+    const int waves = (nx + 63) / 64 < 16 ? (nx + 63) / 64 : 16;
+    dim3 grid_l((nx + waves * 64 - 1) / (waves * 64), (nz + 7) / 8 * 8, nviews), block_l(waves * 64);
+    hipLaunchKernelGGL((k_rotate_attenuate_axis0_lds<8, false>), grid_l, block_l, 0, s, in, (float*)nullptr, att, nx, ny, nz, nx, Affine{}, delta, 0, nz,
+                       atab, (long long)nx * ny * nz);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
@@ -712,8 +736,9 @@ __global__ __launch_bounds__(256) void k_extract(const float* __restrict__ in, f
                                                  long long plane, long long nzo, int inc, int idx_inc,
                                                  const double* __restrict__ scal, float min_value, double mul,
                                                  uint32_t k0, uint32_t k1, uint32_t stream,
-                                                 unsigned long long index_offset)
+                                                 unsigned long long index_offset, const ExtractView* __restrict__ vt)
 {
+    if (vt) { const ExtractView e = vt[blockIdx.y]; in = e.in; out = e.out; scal = e.scal; k0 = e.k0; k1 = e.k1; stream = e.stream; }
     double corr = 1.0;
     if (ADJUST) corr = scal[1];
     const long long total = plane * nzo;
@@ -736,8 +761,9 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
                                                   long long plane4, long long nzo, int inc,
                                                   const double* __restrict__ scal, float min_value, double mul,
                                                   uint32_t k0, uint32_t k1, uint32_t stream,
-                                                  unsigned long long index_offset)
+                                                  unsigned long long index_offset, const ExtractView* __restrict__ vt)
 {
+    if (vt) { const ExtractView e = vt[blockIdx.y]; in = e.in; out = e.out; scal = e.scal; k0 = e.k0; k1 = e.k1; stream = e.stream; }
     double corr = 1.0;
     if (ADJUST) corr = scal[1];
     const long long total4 = plane4 * nzo;
@@ -783,8 +809,14 @@ __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict
                                                          const double* __restrict__ scal, float min_value, double mul,
                                                          uint32_t k0, uint32_t k1, uint32_t stream,
                                                          unsigned long long index_offset, PItem* __restrict__ queue,
-                                                         unsigned int* __restrict__ qcount, unsigned int segcap)
+                                                         unsigned int* __restrict__ qcount, unsigned int segcap,
+                                                         const ExtractView* __restrict__ vt)
 {
+    if (vt) {
+        const ExtractView e = vt[blockIdx.y];
+        in = e.in; out = e.out; scal = e.scal; k0 = e.k0; k1 = e.k1; stream = e.stream;
+        queue = reinterpret_cast<PItem*>(e.queue); qcount = e.qcount;
+    }
     __shared__ unsigned int nq, nqs;
     __shared__ P1Scratch scratch[4];
     if (threadIdx.x == 0) { nq = 0u; nqs = 0u; }
@@ -835,8 +867,13 @@ __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict
 
 // One block per queue segment (same grid as k_extract4_noise2; the grid-stride walk of that kernel spreads the
 // bright voxels evenly over the segments).
-__global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job)
+__global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job, const ExtractView* __restrict__ vt)
 {
+    if (vt) {
+        const ExtractView e = vt[blockIdx.y];
+        job.out = e.out; job.queue = reinterpret_cast<const PItem*>(e.queue); job.qcount = e.qcount;
+        job.k0 = e.k0; job.k1 = e.k1; job.stream = e.stream;
+    }
     __shared__ unsigned int ticket;
     resolve_segment_body(job, (long long)blockIdx.x, (int)threadIdx.x, &ticket);
 }
@@ -846,7 +883,7 @@ int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const u
 {
     const ResolveJob job{out, reinterpret_cast<const PItem*>(queue_items), qcount, segcap, mul, (uint32_t)seed, (uint32_t)(seed >> 32), stream,
                          (unsigned int)plane, (unsigned int)idx_inc, (unsigned long long)index_offset};
-    hipLaunchKernelGGL(k_poisson_resolve, dim3(segments), dim3(256), 0, s, job);
+    hipLaunchKernelGGL(k_poisson_resolve, dim3(segments), dim3(256), 0, s, job, (const ExtractView*)nullptr);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
@@ -872,13 +909,18 @@ size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)
     return (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);   // [counts][segments]
 }
 
-int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
-                   const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                   uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc)
+// nviews > 0: the same launch for `nviews` views whose inputs, outputs, [sum, factor] slots, RNG keys and queue workspaces come from
+// the device table `vt` (blockIdx.y = view; `vec_all`: every view's buffers allow the 16-byte form; in / out / scal / seed / stream /
+// queue_ws arguments unused)
+static int launch_extract_impl(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
+                               const double* scal, float min_value, bool noise, double mul, uint64_t seed,
+                               uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc,
+                               int nviews, const ExtractView* vt, bool vec_all)
 {
     // index_inc: plane stride of the RNG counter when it differs from the plane stride of the reads (a compact input
     // that holds only the planes k * index_inc of the source volume); 0 = the same as inc
     if (index_inc <= 0) index_inc = inc;
+    const unsigned gy = nviews > 0 ? (unsigned)nviews : 1u;
     const long long plane = (long long)dim[0] * dim[1];
     // phase 1 hands a slot's RNG counters across lanes as 32-bit offsets from lane 0's (poisson_phase1): a slot that straddles
     // two acquired planes must not see them 2^32 voxels apart
@@ -889,29 +931,29 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
     const long long total = plane * nzo;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const bool vec = (plane % 4 == 0) && (index_offset % 4 == 0) &&
-                     ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+                     (nviews > 0 ? vec_all : ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0));
     if (vec) {
         long long want = (total / 4 + 255) / 256;
         int blocks = (int)(want < 1 ? 1 : (want > 256 * 64 ? 256 * 64 : want));
 #define MVSIM_LAUNCH_EX4(A, N)                                                                               \
-    hipLaunchKernelGGL((k_extract4<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, scal, \
-                       min_value, mul, k0, k1, stream, (unsigned long long)index_offset)
-        if (noise && queue_ws && use_queue) {
+    hipLaunchKernelGGL((k_extract4<A, N>), dim3(blocks, gy), dim3(256), 0, s, in, out, plane / 4, nzo, inc, scal, \
+                       min_value, mul, k0, k1, stream, (unsigned long long)index_offset, vt)
+        if (noise && (queue_ws || nviews > 0) && use_queue) {
             int qblocks;
             unsigned int segcap;
             poisson_geometry(total, &qblocks, &segcap);
             unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
-            PItem* queue = reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int));
+            PItem* queue = queue_ws ? reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int)) : nullptr;
             if (adjust) {
-                hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
-                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
+                hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
+                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, vt);
             } else {
-                hipLaunchKernelGGL((k_extract4_noise2<false>), dim3(qblocks), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
-                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap);
+                hipLaunchKernelGGL((k_extract4_noise2<false>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
+                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, vt);
             }
             const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream, (unsigned int)plane, (unsigned int)index_inc,
                                   (unsigned long long)index_offset};
-            hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks), dim3(256), 0, s, rjob);
+            hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks, gy), dim3(256), 0, s, rjob, vt);
         }
         else if (adjust && noise) MVSIM_LAUNCH_EX4(true, true);
         else if (adjust) MVSIM_LAUNCH_EX4(true, false);
@@ -924,8 +966,8 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
     long long want = (total + 255) / 256;
     int blocks = (int)(want < 1 ? 1 : (want > 256 * 32 ? 256 * 32 : want));
 #define MVSIM_LAUNCH_EX(A, N)                                                                             \
-    hipLaunchKernelGGL((k_extract<A, N>), dim3(blocks), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, \
-                       min_value, mul, k0, k1, stream, (unsigned long long)index_offset)
+    hipLaunchKernelGGL((k_extract<A, N>), dim3(blocks, gy), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, \
+                       min_value, mul, k0, k1, stream, (unsigned long long)index_offset, vt)
     if (adjust && noise) MVSIM_LAUNCH_EX(true, true);
     else if (adjust) MVSIM_LAUNCH_EX(true, false);
     else if (noise) MVSIM_LAUNCH_EX(false, true);
@@ -933,6 +975,28 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
 #undef MVSIM_LAUNCH_EX
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
+}
+
+int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
+                   const double* scal, float min_value, bool noise, double mul, uint64_t seed,
+                   uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc)
+{
+    return launch_extract_impl(s, in, out, dim, inc, adjust, scal, min_value, noise, mul, seed, stream, index_offset, queue_ws, queue_mode,
+                               index_inc, 0, nullptr, false);
+}
+
+// the queue region of one view inside a workspace of poisson_queue_bytes(n_out) bytes: [counts][segments]
+void poisson_queue_split(void* queue_ws, void** queue_items, unsigned int** qcount)
+{
+    *qcount = reinterpret_cast<unsigned int*>(queue_ws);
+    *queue_items = reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int);
+}
+
+int launch_extract_views(hipStream_t s, const int64_t dim[3], int inc, bool adjust, float min_value, bool noise, double mul,
+                         int queue_mode, int index_inc, int nviews, const ExtractView* vt_dev, bool vec_all)
+{
+    return launch_extract_impl(s, nullptr, nullptr, dim, inc, adjust, nullptr, min_value, noise, mul, 0, 0, 0, nullptr, queue_mode, index_inc,
+                               nviews, vt_dev, vec_all);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -56,6 +56,13 @@ for name in names:
         want = [ctx.download(a, (nzo, n, n)) for a in acq]
         print(f"{name}: {n}^3, PSF {k}^3, inc {inc}, {nv} views  {' '.join('='.join(kv) for kv in extra)}")
         print(f"  sequential simulate_view_dev : {ms:7.3f} ms/view = {n ** 3 / ms / 1e6:6.1f} Gvoxel/s   (host issue {issue * 1e3:5.0f} us/view)")
+        ctx.set_option("view_batch", 1)
+        ms, issue = clock(batched)
+        got = [ctx.download(a, (nzo, n, n)) for a in acq]
+        same = all(np.array_equal(a, b) for a, b in zip(got, want))
+        print(f"  simulate_views_dev, stacked   : {ms:7.3f} ms/view = {n ** 3 / ms / 1e6:6.1f} Gvoxel/s   (host issue {issue * 1e3:5.0f} us/view)"
+              f"   {'bit-identical' if same else 'DIFFERS'}")
+        ctx.set_option("view_batch", 0)
         for L in lanes:
             ctx.set_option("view_lanes", L)
             ms, issue = clock(batched)
