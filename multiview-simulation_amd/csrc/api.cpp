@@ -653,7 +653,7 @@ int mvsim_extract_slices_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[
     MVSIM_CHECK_ARG(inc >= 1, "inc must be >= 1");
     const bool noise = snr >= 0.0f;   // SMVD:211
     void* qws = nullptr;
-    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(dim[0] * dim[1] * mvsim_extract_nz(dim[2], inc), nullptr))); qws = ctx->pqueue.p; }
+    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(dim[0] * dim[1], mvsim_extract_nz(dim[2], inc)))); qws = ctx->pqueue.p; }
     ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, in, out, dim, inc, false, nullptr, 0.0f, noise,
                              mvsim_poisson_mul((double)snr), seed, stream, 0, qws, ctx->opt.poisson_queue));
@@ -809,7 +809,7 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
     // convolution need not produce the other planes (the convolution says whether it could honour that)
     ConvTail tail;
     const long long plane_vox = (long long)dim[0] * dim[1];
-    tail.zstride = (!materialise && p->inc > 1 && plane_vox % 4 == 0 && (!noise || ctx->opt.poisson_queue == 1)) ? p->inc : 1;
+    tail.zstride = (!materialise && p->inc > 1 && (!noise || ctx->opt.poisson_queue == 1)) ? p->inc : 1;
     tail.corr_n = n; tail.min_value = p->min_value; tail.target_average = p->target_average;
     tail.x_done = x_done;
     tail.plane_nz = x_done ? plane_nz : nullptr;
@@ -835,7 +835,7 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
 
     void* qws = nullptr;
     const int64_t n_out = dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc);
-    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(n_out, nullptr))); qws = ctx->pqueue.p; }
+    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(dim[0] * dim[1], mvsim_extract_nz(dim[2], p->inc)))); qws = ctx->pqueue.p; }
     // The tail runs on a stream of its own and is joined by whatever the context does next (join_tail): the next view's
     // rotate+attenuate leaves most of the chip idle and runs beside it.
     // (not beside the fused rotate + attenuate + x transform of the next view: that kernel is bound by vector issue like the
@@ -1058,10 +1058,10 @@ static int views_enqueue_batched(mvsim_ctx* ctx, const float* gt, const int64_t 
     const size_t up_bytes = off_p + (size_t)V * k3 * sizeof(float);
     MVSIM_TRY(ctx->view_tab.reserve(up_bytes));
     MVSIM_TRY(ctx->vol_b.reserve((size_t)V * n * sizeof(float)));                       // att[v]
-    const int zstride = (p0.inc > 1 && plane_vox % 4 == 0) ? p0.inc : 1;                // (as view_enqueue: compact planes when the sampler takes 16-byte rows)
+    const int zstride = p0.inc > 1 ? p0.inc : 1;                                        // (as view_enqueue: only the planes extractSlices reads)
     const int64_t con_planes = zstride > 1 ? nzo : dim[2];
     MVSIM_TRY(ctx->vol_a.reserve((size_t)V * plane_vox * con_planes * sizeof(float)));  // con[v]
-    const size_t qbytes = noise ? ((poisson_queue_bytes(n_out, nullptr) + 255) & ~(size_t)255) : 0;
+    const size_t qbytes = noise ? ((poisson_queue_bytes_planes(plane_vox, nzo) + 255) & ~(size_t)255) : 0;
     if (noise) MVSIM_TRY(ctx->pqueue.reserve(qbytes * V));
     double *partial, *scal0;
     MVSIM_TRY(scal_ptr(ctx, &partial, &scal0));
@@ -1324,7 +1324,7 @@ int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim
     const bool noise = p->snr >= 0.0f;
     void* qws = nullptr;
     if (noise) {
-        MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(plane * (k1 - k0), nullptr)));
+        MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(plane, k1 - k0)));
         qws = ctx->pqueue.p;
     }
     return launch_extract(ctx->stream, ctx->vol_a.as<float>() + plane * (first - z0), acq, ldim, p->inc, true, scal,
@@ -1430,7 +1430,7 @@ int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr, uin
     MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
     MVSIM_TRY(ctx->out_buf.reserve(bytes));
     const int64_t dim[3] = {n, 1, 1};
-    MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes(n, nullptr)));
+    MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(n, 1)));
     ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, ctx->vol_a.as<float>(), ctx->out_buf.as<float>(), dim, 1, false, nullptr,
                              0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset, ctx->pqueue.p, ctx->opt.poisson_queue));

@@ -285,6 +285,9 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
                    uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc = 0);
 // bytes of the Poisson work queue (HBM) for n_out output voxels
 size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity);
+// ... for nzo planes of `plane` voxels whichever sampler kernel takes them (planes that are no multiple of four voxels or unaligned
+// buffers go group by group through k_extract_noise2_any, whose wave slots are padded per plane)
+size_t poisson_queue_bytes_planes(long long plane, long long nzo);
 // ---- stacked views (mvsim_simulate_views_dev): one launch per stage for V views of one ground truth; blockIdx.y / .z = view
 struct ExtractView {              // per-view operands of the extract + Poisson kernels (device table)
     const float*  in;             // the view's convolved planes

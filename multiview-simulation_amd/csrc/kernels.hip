@@ -865,6 +865,74 @@ __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict
     }
 }
 
+// The same two-launch sampler for planes that are no multiple of four voxels (the reference's own 289^3 run: 83 521 voxels per
+// plane) or buffers that are not 16-byte aligned.  Philox groups are four consecutive voxels of the SOURCE index (poisson_dev.h),
+// and a plane then starts anywhere inside a group: a lane takes one group of one acquired plane -- up to four voxels, the ones
+// that fall inside the plane (scalar loads and stores under a mask; the others enter phase 1 as zeros, which it ignores) --, and the
+// 64 lanes of a wave take 64 consecutive groups of the SAME plane, so that a wave's outputs stay consecutive (what phase 1's pair
+// compaction assumes).  Same arithmetic per (voxel, attempt) as every other form: bit-identical counts.
+template <bool ADJUST>
+__global__ __launch_bounds__(256) void k_extract_noise2_any(const float* __restrict__ in, float* __restrict__ out,
+                                                            long long plane, long long nzo, int inc, int idx_inc,
+                                                            const double* __restrict__ scal, float min_value, double mul,
+                                                            uint32_t k0, uint32_t k1, uint32_t stream,
+                                                            unsigned long long index_offset, PItem* __restrict__ queue,
+                                                            unsigned int* __restrict__ qcount, unsigned int segcap,
+                                                            long long slots_per_plane, const ExtractView* __restrict__ vt)
+{
+    if (vt) {
+        const ExtractView e = vt[blockIdx.y];
+        in = e.in; out = e.out; scal = e.scal; k0 = e.k0; k1 = e.k1; stream = e.stream;
+        queue = reinterpret_cast<PItem*>(e.queue); qcount = e.qcount;
+    }
+    __shared__ unsigned int nq, nqs;
+    __shared__ P1Scratch scratch[4];
+    if (threadIdx.x == 0) { nq = 0u; nqs = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    P1Args pa;
+    pa.mul = mul; pa.mulf = (float)mul; pa.k0 = k0; pa.k1 = k1; pa.stream = stream;
+    pa.seg = queue + (unsigned long long)blockIdx.x * segcap; pa.segcap = segcap; pa.nq = &nq; pa.nqs = &nqs;
+    double corr = 1.0;
+    if (ADJUST) corr = scal[1];
+    const long long slots = slots_per_plane * nzo;        // wave slots: 64 groups each
+    for (long long sl = (long long)blockIdx.x * 4 + wave; sl < slots; sl += (long long)gridDim.x * 4) {
+        const long long k = sl / slots_per_plane, jb = sl - k * slots_per_plane;
+        const unsigned long long ibase = index_offset + (unsigned long long)(k * idx_inc) * (unsigned long long)plane;   // RNG index of the plane's voxel 0
+        const unsigned long long g = (ibase >> 2) + (unsigned long long)(jb * 64 + lane);      // this lane's Philox group
+        const long long i0 = (long long)(4ull * g - ibase);                                   // its first voxel inside the plane (may be < 0)
+        const float* __restrict__ src = in + k * inc * plane;
+        float vv[4];
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long i = i0 + c;
+            const bool ok = i >= 0 && i < plane;
+            float v = 0.f;
+            if (ok) {
+                v = src[i];
+                if (ADJUST) v = adjust_one(v, corr, min_value);
+            }
+            vv[c] = ok ? v : 0.f;
+            any |= ok;
+        }
+        float ov[4];
+        // (output position of component 0; negative for a plane's first group when the plane starts inside it -- the valid components
+        // land at non-negative positions all the same, in 64-bit wrap-around arithmetic)
+        poisson_phase1(vv, any, 4ull * g, (unsigned long long)(k * plane + i0), pa, &scratch[wave], lane, ov);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long i = i0 + c;
+            if (i >= 0 && i < plane) out[k * plane + i] = ov[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        qcount[2 * blockIdx.x] = nq;
+        qcount[2 * blockIdx.x + 1] = nqs;
+    }
+}
+
 // One block per queue segment (same grid as k_extract4_noise2; the grid-stride walk of that kernel spreads the
 // bright voxels evenly over the segments).
 __global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job, const ExtractView* __restrict__ vt)
@@ -907,6 +975,30 @@ size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)
     poisson_geometry(n_out, &blocks, &segcap);
     if (capacity) *capacity = (unsigned long long)blocks * segcap;
     return (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);   // [counts][segments]
+}
+
+// The same for k_extract_noise2_any: a wave slot is 64 Philox groups of ONE plane (a plane of `plane` voxels that starts anywhere
+// inside a group touches up to plane / 4 + 1 of them, rounded up to whole slots), `blocks` blocks of four waves walk the slots with a
+// grid stride, and a block's segment holds every voxel of its trips.
+static void poisson_geometry_any(long long plane, long long nzo, int* blocks, unsigned int* segcap, long long* slots_per_plane)
+{
+    const long long spp = ((plane + 3) / 4 + 1 + 63) / 64;
+    const long long slots = spp * nzo;
+    long long want = (slots + 3) / 4;
+    const int b = (int)(want < 1 ? 1 : (want > POISSON_MAX_BLOCKS ? POISSON_MAX_BLOCKS : want));
+    const long long trips = (slots + (long long)b * 4 - 1) / ((long long)b * 4);
+    *blocks = b; *segcap = (unsigned int)(trips * 1024); *slots_per_plane = spp;
+}
+
+size_t poisson_queue_bytes_planes(long long plane, long long nzo)
+{
+    int blocks;
+    unsigned int segcap;
+    long long spp;
+    poisson_geometry_any(plane, nzo, &blocks, &segcap, &spp);
+    const size_t any = (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);
+    const size_t vec = poisson_queue_bytes(plane * nzo, nullptr);
+    return any > vec ? any : vec;
 }
 
 // nviews > 0: the same launch for `nviews` views whose inputs, outputs, [sum, factor] slots, RNG keys and queue workspaces come from
@@ -960,6 +1052,26 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
         else if (noise) MVSIM_LAUNCH_EX4(false, true);
         else MVSIM_LAUNCH_EX4(false, false);
 #undef MVSIM_LAUNCH_EX4
+        MVSIM_HIP(hipGetLastError());
+        return MVSIM_OK;
+    }
+    if (noise && (queue_ws || nviews > 0) && use_queue) {
+        // planes that are no multiple of four voxels / unaligned buffers: the same two launches, group by group (k_extract_noise2_any)
+        int qblocks;
+        unsigned int segcap;
+        long long spp;
+        poisson_geometry_any(plane, nzo, &qblocks, &segcap, &spp);
+        unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
+        PItem* queue = queue_ws ? reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int)) : nullptr;
+        if (adjust)
+            hipLaunchKernelGGL((k_extract_noise2_any<true>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, min_value,
+                               mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, spp, vt);
+        else
+            hipLaunchKernelGGL((k_extract_noise2_any<false>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, min_value,
+                               mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, spp, vt);
+        const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream, (unsigned int)plane, (unsigned int)index_inc,
+                              (unsigned long long)index_offset};
+        hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks, gy), dim3(256), 0, s, rjob, vt);
         MVSIM_HIP(hipGetLastError());
         return MVSIM_OK;
     }

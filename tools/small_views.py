@@ -13,9 +13,10 @@ mvs = importlib.import_module("multiview-simulation_amd")
 synth = importlib.import_module("multiview-simulation_amd.synthetic")
 
 CASES = {"c0": (128, 15, 1, 8), "ref": (289, 51, 3, 7), "256": (256, 31, 1, 8), "512": (512, 31, 1, 8), "64": (64, 9, 1, 8)}
-names, lanes, reps, extra = [], [1, 2, 4, 8], 20, []
+names, lanes, reps, extra, only = [], [1, 2, 4, 8], 20, [], None
 for a in sys.argv[1:]:
     if a.startswith("lanes="): lanes = [int(x) for x in a[6:].split(",")]
+    elif a.startswith("only="): only = a[5:]              # only=stacked | only=sequential: one form alone (profiles)
     elif a.startswith("reps="): reps = int(a[5:])
     elif "=" in a: extra.append(a.split("=", 1))
     else: names.append(a)
@@ -52,7 +53,15 @@ for name in names:
             ctx.synchronize()
             return (time.perf_counter() - t0) / (reps * nv) * 1e3, t_issue / (reps * nv) * 1e3
 
+        if only == "stacked":
+            ctx.set_option("view_batch", 1)
+            ms, issue = clock(batched)
+            print(f"{name}: stacked only: {ms:7.3f} ms/view = {n ** 3 / ms / 1e6:6.1f} Gvoxel/s")
+            continue
         ms, issue = clock(sequential)
+        if only == "sequential":
+            print(f"{name}: sequential only: {ms:7.3f} ms/view = {n ** 3 / ms / 1e6:6.1f} Gvoxel/s")
+            continue
         want = [ctx.download(a, (nzo, n, n)) for a in acq]
         print(f"{name}: {n}^3, PSF {k}^3, inc {inc}, {nv} views  {' '.join('='.join(kv) for kv in extra)}")
         print(f"  sequential simulate_view_dev : {ms:7.3f} ms/view = {n ** 3 / ms / 1e6:6.1f} Gvoxel/s   (host issue {issue * 1e3:5.0f} us/view)")
