@@ -90,6 +90,8 @@ def parse_args():
                     help="launcher / rendezvous check only: every rank joins the process group, all-reduces a 1 and rank 0 prints "
                          "{n_gpus, ranks_seen}; no GPU, no libmvsim (what the CPU test of the self-launcher runs with --backend gloo)")
     ap.add_argument("--no-size-1024", action="store_true", help="skip the 1024^3 sub-record")
+    ap.add_argument("--no-small-views", action="store_true",
+                    help="skip the `small_views` sub-record (N = 1 only): the reference's own small sizes, views stacked in one call")
     ap.add_argument("--no-tiled-1024", action="store_true",
                     help="N > 1 data path only: skip the `tiled_1024` sub-record (BASELINE configs[3]: every 1024^3 view cut into N z slabs)")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the `no_empty_space` sub-record (N = 1 only)")
@@ -457,8 +459,16 @@ def end_to_end_record(mvs, dev_index: int, gt_host: np.ndarray, psfs_raw: list, 
         for key, fresh in (("same_ground_truth", False), ("fresh_ground_truth_per_view", True)):
             dt = run(fresh, 2)
             out[key] = {"ms_per_view": dt * 1e3, "views_per_s": 1.0 / dt, "Mvoxel_per_s": n ** 3 / dt / 1e6,
-                        "host_bytes_per_view": (4 * n ** 3 if fresh else 0) + 4 * n * n * nzo}
+                        "host_bytes_per_view": (4 * n ** 3 if fresh else 0) + 2 * n * n * nzo}
         assert float(acq[0].max()) > 0
+        u16_views, u16_fallbacks = c.transfer_stats()
+        out["acquisition_transfer"] = {"views_as_uint16": u16_views, "fell_back_to_float32": u16_fallbacks,
+                                       "note": "Poisson counts (Tools.java:84 stores them as floats) cross PCIe as uint16 and are widened into the caller's "
+                                               "float32 buffer by mvsim_wait (host threads, streaming stores); a view with a count beyond 65 535 is fetched "
+                                               "as float32 automatically; identical arrays either way"}
+        c.set_option("acq_transfer", "f32")
+        dt = run(False, 2)
+        out["same_ground_truth_float32_transfer"] = {"ms_per_view": dt * 1e3, "Mvoxel_per_s": n ** 3 / dt / 1e6, "host_bytes_per_view": 4 * n * n * nzo}
         del gts, acq
     out["note"] = ("page-locked host buffers in and out (mvsim_host_alloc), mvsim_simulate_view_async + mvsim_wait: two staging "
                    "sets, three HIP streams; PCIe-inclusive, reported beside `value`, never as `value`")
@@ -503,6 +513,52 @@ def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.nd
             "views": reps, "ms_per_view": wall * 1e3, "value": n ** 3 / wall / 1e6, "unit": "Mvoxel/s",
             "serial": {"ms_per_view": wall_serial * 1e3, "value": n ** 3 / wall_serial / 1e6},
             "first_plane_mean_count": mean_count, "roofline": rl}
+
+
+def small_views_record(mvs, synth, dev_index: int) -> dict:
+    """Views that cannot fill the chip one at a time -- the sizes the REFERENCE itself runs: BASELINE configs[0] (128^3, 15^3 PSF) and
+    the run `main` ships with (289^3 phantom, 51^3 PSF stacks, lightsheet spacing 3, seven views: SimulateMultiViewDataset.java:376-380,
+    399, 531-548, loop :567), plus 256^3.  Per size: V sequential mvsim_simulate_view_dev calls against ONE mvsim_simulate_views_dev call
+    (the views stacked: one launch per stage for all of them), wall clock over `reps` datasets, device-resident; the acquisitions of the
+    two forms are compared bit for bit."""
+    out = {}
+    for name, n, k, inc, nv, reps in (("128^3_psf15_inc1_x8", 128, 15, 1, 8, 30), ("289^3_psf51_inc3_x7", 289, 51, 3, 7, 10), ("256^3_psf31_inc1_x8", 256, 31, 1, 8, 10)):
+        gt = synth.sphere_phantom(n)
+        nzo = (n - 1) // inc + 1
+        psfs = [synth.gaussian_psf(k, sigma=(k / 15.0, k / 14.0, k / 5.0 + 0.05 * v)) for v in range(nv)]
+        with mvs.Context(dev_index) as c:
+            d_gt = c.dev_alloc(gt.nbytes)
+            c.upload(d_gt, gt)
+            acq = [c.dev_alloc(nzo * n * n * 4) for _ in range(nv)]
+            params = [c.view_params(degrees=15 + (360 * v) // nv, inc=inc, snr=25.0, seed=464232194, stream=v, conv_method=1) for v in range(nv)]
+
+            def sequential():
+                for v in range(nv):
+                    c.simulate_view_dev(d_gt, (n, n, n), psfs[v].copy(), params[v], acq[v])
+
+            def stacked():
+                c.simulate_views_dev(d_gt, (n, n, n), [p.copy() for p in psfs], params, acq)
+
+            def clock(fn):
+                for _ in range(2):
+                    fn()
+                c.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                c.synchronize()
+                return (time.perf_counter() - t0) / (reps * nv) * 1e3
+            t_seq = clock(sequential)
+            want = [c.download(a, (nzo, n, n)) for a in acq]
+            t_st = clock(stacked)
+            same = all(np.array_equal(c.download(a, (nzo, n, n)), w) for a, w in zip(acq, want))
+            for d in acq + [d_gt]:
+                c.dev_free(d)
+        out[name] = {"views": nv, "sequential_ms_per_view": round(t_seq, 4), "sequential_Mvoxel_per_s": n ** 3 / t_seq / 1e3,
+                     "ms_per_view": round(t_st, 4), "value": n ** 3 / t_st / 1e3, "unit": "Mvoxel/s", "bit_identical_to_sequential": bool(same)}
+    out["note"] = ("value = one mvsim_simulate_views_dev call per dataset (views stacked: the view index in the kernels' grids, one launch per "
+                   "stage for all views); sequential = one mvsim_simulate_view_dev call per view; wall clock, device-resident, Python call overhead included")
+    return out
 
 
 class Env:
@@ -1160,6 +1216,11 @@ def main():
                 del g512
             except Exception as e:
                 out["size_1024"] = {"failed": repr(e)}
+        if not multi and not args.no_small_views and args.conv_method == 1:
+            try:
+                out["small_views"] = small_views_record(mvs, synth, dev_index)
+            except Exception as e:
+                out["small_views"] = {"failed": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(gt_host, psf_raw, angles[0], args.inc, args.snr, args.cpu_slab, args.cpu_poisson_planes)

@@ -267,6 +267,13 @@ int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt_host, uint64_t gt_
 /* Blocks until the view behind `ticket` has landed in its host buffers; *correction (may be NULL) receives the
  * adjustImage factor.  Tickets may be waited for in any order, each once. */
 int mvsim_wait(mvsim_ctx* ctx, int64_t ticket, double* correction);
+/* How the acquisitions of mvsim_simulate_view_async crossed PCIe.  Tools.poissonProcess stores Poisson COUNTS as floats
+ * (Tools.java:84): a sampled view (snr >= 0) is packed to uint16 on the device, downloaded as half the bytes and widened into the
+ * caller's float buffer by mvsim_wait (a few host threads, option "host_threads" = auto|1..256); a view holding a value that does not
+ * survive the round trip (a count beyond 65 535) is fetched as float32 after all, automatically.  Exact either way.  Option
+ * "acq_transfer" = auto|f32 (f32: never pack).  *views_as_u16: views that took the 16-bit path so far, *fallbacks: how many of them
+ * had to be fetched as float32.  Either pointer may be NULL. */
+int mvsim_get_transfer_stats(mvsim_ctx* ctx, int64_t* views_as_u16, int64_t* fallbacks);
 /* Host buffers given as z slabs: volumes beyond 2^31-1 voxels do not fit one Java array / direct buffer
  * (SimulateMultiViewDataset.java:109 uses ArrayImg and cannot hold them at all), so the ground truth arrives as
  * n_gt_slabs pointers of gt_slab_nz[i] planes each (sum = dim[2]) and the acquisition leaves as n_acq_slabs pointers of

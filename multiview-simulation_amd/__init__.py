@@ -464,6 +464,12 @@ class Context:
             C.byref(o), C.byref(corr) if want_corr else None))
         return corr.value if want_corr else None
 
+    def transfer_stats(self):
+        """(views whose acquisition crossed PCIe as uint16 counts, how many of them fell back to float32)."""
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(self._L.mvsim_get_transfer_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def simulate_views_dev(self, gt_dptr: int, dim_xyz, psfs, params, acq_dptrs, con_dptrs=None) -> None:
         """``len(psfs)`` independent views of one device-resident ground truth in one call (the view loop of `main`,
         SimulateMultiViewDataset.java:567-585): the library runs as many side by side as pays for their size.  ``psfs[v]`` is

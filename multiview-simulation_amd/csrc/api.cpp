@@ -9,7 +9,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
+
+#include <emmintrin.h>
 
 namespace mvsim {
 
@@ -70,6 +75,18 @@ int parse_option(Options& o, const char* name, const char* value)
     if (n == "tail_overlap") {
         if (v == "0" || v == "off") o.tail_overlap = 0; else if (v == "1" || v == "on" || v == "own") o.tail_overlap = 1;
         else if (v == "2" || v == "any") o.tail_overlap = 2; else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
+    if (n == "acq_transfer") {
+        if (v == "auto" || v == "u16") o.acq_u16 = 1; else if (v == "f32") o.acq_u16 = 0; else return MVSIM_EINVAL;
+        return MVSIM_OK;
+    }
+    if (n == "host_threads") {
+        if (v == "auto") { o.host_threads = 0; return MVSIM_OK; }
+        if (v.empty() || v.size() > 3 || v.find_first_not_of("0123456789") != std::string::npos) return MVSIM_EINVAL;
+        const int k = atoi(v.c_str());
+        if (k < 1 || k > 256) return MVSIM_EINVAL;
+        o.host_threads = k;
         return MVSIM_OK;
     }
     if (n == "view_batch") {
@@ -1558,6 +1575,123 @@ int mvsim_splat_spheres(mvsim_ctx* ctx, float* img, const int64_t dim[3], const 
     return down(ctx, img, ctx->vol_a.p, bytes);
 }
 
+// ---- host side of the 16-bit acquisition transfer ----------------------------------------------------------------------------
+// A 512^3 acquisition is 0.54 GB of float32 that hold small integers (Poisson counts, Tools.java:84): it crosses PCIe as 0.27 GB of
+// uint16 and is widened here, by a few host threads with streaming stores (the destination -- the caller's buffer -- is written once
+// and not read back by us), while the next view's transfer is already running.  Process-wide pool, created on first use.
+namespace {
+class HostPool {
+public:
+    static HostPool& get() { static HostPool p; return p; }
+    // fn(chunk) for chunk = 0 .. chunks-1 on up to `threads` threads (the caller's thread takes part); returns when all are done
+    void run(int chunks, int threads, const std::function<void(int)>& fn)
+    {
+        if (chunks <= 0) return;
+        threads = std::max(1, std::min(threads, chunks));
+        std::unique_lock<std::mutex> lk(m_);
+        while ((int)workers_.size() < threads - 1) workers_.emplace_back([this] { loop(); });
+        fn_ = &fn; next_ = 0; total_ = chunks; pending_ = chunks; gen_ += 1;
+        cv_.notify_all();
+        lk.unlock();
+        work();
+        lk.lock();
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    HostPool() = default;
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void work()
+    {
+        for (;;) {
+            int c;
+            const std::function<void(int)>* f;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!fn_ || next_ >= total_) return;
+                c = next_++; f = fn_;
+            }
+            (*f)(c);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && fn_ && next_ < total_); });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int next_ = 0, total_ = 0, pending_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+
+// dst[i] = (float) src[i], i in [0, n): 8 values per step, streaming stores where the destination is 16-byte aligned
+void widen_u16(const unsigned short* src, float* dst, long long n)
+{
+    long long i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 15) != 0) { dst[i] = (float)src[i]; ++i; }
+    const __m128i zero = _mm_setzero_si128();
+    for (; i + 8 <= n; i += 8) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+        _mm_stream_ps(dst + i, _mm_cvtepi32_ps(_mm_unpacklo_epi16(v, zero)));
+        _mm_stream_ps(dst + i + 4, _mm_cvtepi32_ps(_mm_unpackhi_epi16(v, zero)));
+    }
+    for (; i < n; ++i) dst[i] = (float)src[i];
+    _mm_sfence();
+}
+}  // namespace
+
+static int host_threads_of(const mvsim_ctx* ctx)
+{
+    if (ctx->opt.host_threads > 0) return ctx->opt.host_threads;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+}
+
+// the slot's view has landed (ev_d2h synchronised): 16-bit counts become the caller's float32 acquisition -- or, when the device
+// flagged a value that does not fit (or is no integer), the float32 buffer is fetched after all
+static int async_land(mvsim_ctx* ctx, int s)
+{
+    if (!ctx->async_as_u16[s]) return MVSIM_OK;
+    ctx->async_as_u16[s] = false;
+    const long long n = ctx->async_out_n[s];
+    const size_t body = ((size_t)n * sizeof(unsigned short) + 255) & ~(size_t)255;
+    const unsigned int flag = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(ctx->async_u16_host[s]) + body);
+    ctx->u16_views += 1;
+    if (flag != 0u) {
+        ctx->u16_fallbacks += 1;
+        MVSIM_HIP(hipMemcpy(ctx->async_out_acq[s], ctx->async_acq[s].p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        return MVSIM_OK;
+    }
+    const unsigned short* src = reinterpret_cast<const unsigned short*>(ctx->async_u16_host[s]);
+    float* dst = ctx->async_out_acq[s];
+    const long long chunk = (long long)1 << 20;                   // 1 Mi values: 2 MB in, 4 MB out
+    const int chunks = (int)((n + chunk - 1) / chunk);
+    HostPool::get().run(chunks, host_threads_of(ctx), [&](int c) {
+        const long long a = (long long)c * chunk, b = std::min(n, a + chunk);
+        widen_u16(src + a, dst + a, b - a);
+    });
+    return MVSIM_OK;
+}
+
 // ---- pipelined host-buffer views ----------------------------------------------------------------------
 static int async_setup(mvsim_ctx* ctx)
 {
@@ -1579,10 +1713,13 @@ static void async_release(mvsim_ctx* ctx)
     if (!ctx->async_ready) return;
     (void)hipStreamSynchronize(ctx->h2d_stream);
     (void)hipStreamSynchronize(ctx->d2h_stream);
+    for (int s = 0; s < mvsim_ctx::ASYNC_SLOTS; ++s)          // views nobody waited for still owe their caller the widened counts
+        if (ctx->async_inflight[s]) (void)async_land(ctx, s);
     for (int s = 0; s < mvsim_ctx::ASYNC_SLOTS; ++s) {
         (void)hipEventDestroy(ctx->ev_h2d[s]); (void)hipEventDestroy(ctx->ev_compute[s]); (void)hipEventDestroy(ctx->ev_d2h[s]);
-        ctx->async_gt[s].release(); ctx->async_acq[s].release();
-        ctx->async_inflight[s] = false; ctx->async_gt_src[s] = nullptr;
+        ctx->async_gt[s].release(); ctx->async_acq[s].release(); ctx->async_u16[s].release();
+        if (ctx->async_u16_host[s]) { (void)hipHostFree(ctx->async_u16_host[s]); ctx->async_u16_host[s] = nullptr; ctx->async_u16_host_bytes[s] = 0; }
+        ctx->async_inflight[s] = false; ctx->async_gt_src[s] = nullptr; ctx->async_as_u16[s] = false;
     }
     (void)hipStreamDestroy(ctx->h2d_stream);
     (void)hipStreamDestroy(ctx->d2h_stream);
@@ -1609,8 +1746,21 @@ int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt, uint64_t gt_gener
         MVSIM_HIP(hipEventSynchronize(ctx->ev_d2h[s]));
         ctx->async_inflight[s] = false;
         ctx->async_corr_done[ctx->async_ticket[s] % mvsim_ctx::ASYNC_HISTORY] = ctx->async_corr[s];
+        MVSIM_TRY(async_land(ctx, s));
     }
     const bool wants_twins = o->rot || o->att || o->con;
+    // counts as uint16 over PCIe: sampled views only (a view without noise holds reals), 16-byte rows for the packer
+    const long long n_out = (long long)(obytes / sizeof(float));
+    const bool as_u16 = ctx->opt.acq_u16 != 0 && p->snr >= 0.0f;
+    const size_t u16_body = ((size_t)n_out * sizeof(unsigned short) + 255) & ~(size_t)255;
+    if (as_u16) {
+        MVSIM_TRY(ctx->async_u16[s].reserve(u16_body + 256));
+        if (ctx->async_u16_host_bytes[s] < u16_body + 256) {
+            if (ctx->async_u16_host[s]) { (void)hipHostFree(ctx->async_u16_host[s]); ctx->async_u16_host[s] = nullptr; ctx->async_u16_host_bytes[s] = 0; }
+            MVSIM_HIP(hipHostMalloc(&ctx->async_u16_host[s], u16_body + 256, hipHostMallocDefault));
+            ctx->async_u16_host_bytes[s] = u16_body + 256;
+        }
+    }
     mvsim_view_outputs dev = {nullptr, nullptr, nullptr, nullptr};
     {
         // the staging buffer may move when a later view is larger: what it held is gone then, whatever the caller's pointer
@@ -1649,14 +1799,23 @@ int mvsim_simulate_view_async(mvsim_ctx* ctx, const float* gt, uint64_t gt_gener
         MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
         MVSIM_HIP(hipMemcpyAsync(&ctx->async_corr[s], scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (as_u16) {
+        unsigned int* flag = reinterpret_cast<unsigned int*>(ctx->async_u16[s].as<char>() + u16_body);
+        MVSIM_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned int), ctx->stream));
+        MVSIM_TRY(launch_pack_u16(ctx->stream, dev.acq, ctx->async_u16[s].as<unsigned short>(), n_out, flag));
+    }
     MVSIM_HIP(hipEventRecord(ctx->ev_compute[s], ctx->stream));
     // download
     MVSIM_HIP(hipStreamWaitEvent(ctx->d2h_stream, ctx->ev_compute[s], 0));
     if (o->rot) MVSIM_HIP(hipMemcpyAsync(o->rot, dev.rot, vbytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
     if (o->att) MVSIM_HIP(hipMemcpyAsync(o->att, dev.att, vbytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
     if (o->con) MVSIM_HIP(hipMemcpyAsync(o->con, dev.con, vbytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
-    MVSIM_HIP(hipMemcpyAsync(o->acq, dev.acq, obytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    if (as_u16) MVSIM_HIP(hipMemcpyAsync(ctx->async_u16_host[s], ctx->async_u16[s].p, u16_body + sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->d2h_stream));
+    else MVSIM_HIP(hipMemcpyAsync(o->acq, dev.acq, obytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
     MVSIM_HIP(hipEventRecord(ctx->ev_d2h[s], ctx->d2h_stream));
+    ctx->async_as_u16[s] = as_u16;
+    ctx->async_out_acq[s] = o->acq;
+    ctx->async_out_n[s] = n_out;
     ctx->async_inflight[s] = true;
     ctx->async_ticket[s] = k;
     ctx->async_twins_busy = wants_twins;
@@ -1675,9 +1834,18 @@ int mvsim_wait(mvsim_ctx* ctx, int64_t ticket, double* correction)
         MVSIM_HIP(hipEventSynchronize(ctx->ev_d2h[s]));
         ctx->async_inflight[s] = false;
         ctx->async_corr_done[ticket % mvsim_ctx::ASYNC_HISTORY] = ctx->async_corr[s];
+        MVSIM_TRY(async_land(ctx, s));
     }
     // otherwise the view has landed already: a later call on the same staging set, or an earlier wait, saw to that
     if (correction) *correction = ctx->async_corr_done[ticket % mvsim_ctx::ASYNC_HISTORY];
+    return MVSIM_OK;
+}
+
+int mvsim_get_transfer_stats(mvsim_ctx* ctx, int64_t* views_as_u16, int64_t* fallbacks)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");
+    if (views_as_u16) *views_as_u16 = ctx->u16_views;
+    if (fallbacks) *fallbacks = ctx->u16_fallbacks;
     return MVSIM_OK;
 }
 

@@ -134,6 +134,9 @@ struct Options {
                                        // vector issue (0.61 ms against 0.25 + 0.36 ms for pass E and the streaming Poisson kernel
                                        // at 512^3): measured neutral to slightly slower, so off by default
     int     graph = 0;                 // replay simulate_view_dev from a captured hipGraph (small, launch-bound volumes)
+    int     acq_u16 = 1;               // host-buffer views (mvsim_simulate_view_async): the acquisition crosses PCIe as uint16 counts when the
+                                       // view is sampled (snr >= 0), widened on the host; automatic float32 fallback per view.  0: always float32
+    int     host_threads = 0;          // threads of the host-side widening (0 = auto: min(16, hardware threads))
     int     view_lanes = 0;            // mvsim_simulate_views_dev: views in flight side by side (0 = auto: from the size of a view)
     int     view_batch = 2;            // mvsim_simulate_views_dev: the views STACKED -- one launch per stage for all of them (api.cpp:
                                        // views_enqueue_batched): 0 never, 1 whenever the views allow it, 2 auto (views of <= 2^26 voxels)
@@ -219,6 +222,14 @@ struct mvsim_ctx {
     bool        tail_pending = false;
     const char *tail_lo[2] = {nullptr, nullptr}, *tail_hi[2] = {nullptr, nullptr};   // byte ranges the pending tail writes / reads
     mvsim::DevBuf async_gt[ASYNC_SLOTS], async_acq[ASYNC_SLOTS];
+    // acquisitions cross PCIe as 16-bit counts (option acq_transfer): packed on the device, widened on the host by mvsim_wait
+    mvsim::DevBuf async_u16[ASYNC_SLOTS];         // [n_out uint16, padded to 256 bytes][flag word]
+    void*      async_u16_host[ASYNC_SLOTS] = {};  // page-locked twin
+    size_t     async_u16_host_bytes[ASYNC_SLOTS] = {};
+    bool       async_as_u16[ASYNC_SLOTS] = {};
+    float*     async_out_acq[ASYNC_SLOTS] = {};   // the caller's acquisition buffer of the slot's view
+    long long  async_out_n[ASYNC_SLOTS] = {};
+    long long  u16_views = 0, u16_fallbacks = 0;  // statistics (mvsim_get_transfer_stats)
     hipEvent_t ev_h2d[ASYNC_SLOTS] = {}, ev_compute[ASYNC_SLOTS] = {}, ev_d2h[ASYNC_SLOTS] = {};
     bool       async_inflight[ASYNC_SLOTS] = {};
     long long  async_ticket[ASYNC_SLOTS] = {};
@@ -258,7 +269,7 @@ inline mvsim_ctx::mvsim_ctx()
 {
     for (mvsim::DevBuf* b : {&vol_a, &vol_b, &vol_c, &out_buf, &psf_dev, &stencil_psf, &fft_real, &fft_spec_img, &fft_spec_psf, &fft_work,
                              &pqueue, &view_tab, &sphere_list, &weight_img, &plane_flags, &host_gt, &host_rot, &host_att, &host_con, &partials, &partials_e, &cfft_f, &cfft_g,
-                             &cfft_g1, &cfft_g2, &partials_z, &async_gt[0], &async_gt[1], &async_acq[0], &async_acq[1]})
+                             &cfft_g1, &cfft_g2, &partials_z, &async_gt[0], &async_gt[1], &async_acq[0], &async_acq[1], &async_u16[0], &async_u16[1]})
         b->epoch = &alloc_epoch;
 }
 
@@ -301,6 +312,7 @@ int launch_rotate_attenuate_views(hipStream_t s, const float* in, float* att, co
 void poisson_queue_split(void* queue_ws, void** queue_items, unsigned int** qcount);
 int launch_extract_views(hipStream_t s, const int64_t dim[3], int inc, bool adjust, float min_value, bool noise, double mul,
                          int queue_mode, int index_inc, int nviews, const ExtractView* vt_dev, bool vec_all);
+int launch_pack_u16(hipStream_t s, const float* in, unsigned short* out16, int64_t n, unsigned int* flag);
 int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc);
 // phantom generator (phantom.hip)
 int launch_downsample2x(hipStream_t s, const float* in, const int64_t dim[3], float* out);

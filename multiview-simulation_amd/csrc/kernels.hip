@@ -1112,6 +1112,46 @@ int launch_extract_views(hipStream_t s, const int64_t dim[3], int inc, bool adju
 }
 
 // ------------------------------------------------------------------------------------------------
+// Acquisitions cross PCIe as 16-bit counts (host-buffer views): Tools.poissonProcess stores raw Poisson COUNTS as floats
+// (Tools.java:84), so a view's acquisition is integer-valued and -- at the reference's SNRs -- far below 65 536.  out16[i] = (uint16) in[i];
+// *flag is raised when any value does not survive the round trip (a count beyond 65 535, a non-integer because the view was
+// simulated without noise, a NaN): the host then fetches the float32 buffer instead.  Exact: counts are integers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_u16(const float* __restrict__ in, unsigned short* __restrict__ out16, long long n,
+                                                  unsigned int* __restrict__ flag)
+{
+    const long long nthreads = (long long)gridDim.x * 256;
+    const long long n8 = n >> 3;
+    bool bad = false;
+    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in);
+    uint4* __restrict__ out8 = reinterpret_cast<uint4*>(out16);
+    auto cvt = [&](float v) -> unsigned int {
+        const unsigned int u = (unsigned int)fminf(fmaxf(v, 0.f), 65535.f);
+        bad |= !((float)u == v);
+        return u;
+    };
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += nthreads) {
+        const float4 a = in4[2 * i], b = in4[2 * i + 1];
+        uint4 o;
+        o.x = cvt(a.x) | (cvt(a.y) << 16); o.y = cvt(a.z) | (cvt(a.w) << 16);
+        o.z = cvt(b.x) | (cvt(b.y) << 16); o.w = cvt(b.z) | (cvt(b.w) << 16);
+        out8[i] = o;
+    }
+    for (long long i = (n8 << 3) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += nthreads) out16[i] = (unsigned short)cvt(in[i]);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+// in: n floats (16-byte aligned), out16: n uint16 (16-byte aligned); *flag must be zero before the launch
+int launch_pack_u16(hipStream_t s, const float* in, unsigned short* out16, int64_t n, unsigned int* flag)
+{
+    long long want = ((n >> 3) + 255) / 256;
+    const int blocks = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+    hipLaunchKernelGGL(k_pack_u16, dim3(blocks), dim3(256), 0, s, in, out16, (long long)n, flag);
+    MVSIM_HIP(hipGetLastError());
+    return MVSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // makeIsotropic (SimulateMultiViewDataset.java:144-171): z = (float)l / (float)inc (Q4), x and y
 // integral => the 8-tap interpolator degenerates to two planes (weights of the x+1 / y+1 taps
 // are exactly 0); mirror-single extension along z.

@@ -1278,6 +1278,44 @@ def test_async_pipelined_views_equal_synchronous_views(ctx, synth):
         ctx.wait(10_000)
 
 
+def test_async_acquisitions_cross_pcie_as_uint16_counts(mvs, synth):
+    """Tools.poissonProcess stores Poisson COUNTS as floats (Tools.java:84): mvsim_simulate_view_async packs a sampled view's
+    acquisition to uint16 on the device, downloads half the bytes and widens them on the host (mvsim_wait).  Identical arrays to the
+    float32 transfer -- for unaligned output buffers and odd sizes too; a view whose counts exceed 65 535 (SNR 700: lambda ~ 10^5) is
+    fetched as float32 after all, automatically; a view without noise (snr < 0) never takes the 16-bit path.  (The volume is the
+    phantom on a pedestal: adjustImage sets the MEAN to 1, so the bright voxels of a small, mostly empty phantom alone would reach
+    counts beyond 65 535 at SNR 25 already -- the automatic fallback, which the SNR 700 case exercises.)"""
+    gt = (synth.sphere_phantom(61) + np.float32(0.5)).astype(np.float32)
+    psf = synth.gaussian_psf(7, sigma=(1.1, 1.2, 1.6))
+    with mvs.Context(0) as c:
+        g = c.pinned_empty(gt.shape)
+        g[...] = gt
+        for snr, u16_expected, fallback_expected in ((25.0, True, False), (700.0, True, True), (-1.0, False, False)):
+            p = c.view_params(degrees=40, inc=2, snr=snr, seed=SEED, stream=2)
+            nzo = (61 - 1) // 2 + 1
+            c.set_option("acq_transfer", "f32")
+            want = c.pinned_empty((nzo, 61, 61))
+            c.wait(c.simulate_view_async(g, psf.copy(), p, {"acq": want}))
+            before = c.transfer_stats()
+            assert before == c.transfer_stats()                       # float32 transfers are not counted
+            c.set_option("acq_transfer", "auto")
+            c.set_option("host_threads", 3)
+            backing = np.zeros(nzo * 61 * 61 + 3, np.float32)
+            got = backing[1:-2].reshape(nzo, 61, 61)                  # 4-byte aligned only: the widening's scalar head and tail
+            tickets = [c.simulate_view_async(g, psf.copy(), p, {"acq": got})]
+            got2 = c.pinned_empty((nzo, 61, 61))
+            tickets.append(c.simulate_view_async(g, psf.copy(), p, {"acq": got2}))     # two outstanding views: both staging sets
+            for t in tickets:
+                c.wait(t)
+            after = c.transfer_stats()
+            assert np.array_equal(got, want) and np.array_equal(got2, want), snr
+            assert (after[0] - before[0] == 2) == u16_expected and (after[1] - before[1] == 2) == fallback_expected, (snr, before, after)
+            if snr == 700.0:
+                assert want.max() > 65535
+            if snr == 25.0:
+                assert 0 < want.max() < 65535 and np.all(want == np.round(want))
+
+
 def test_async_ground_truth_cache_is_dropped_when_the_staging_buffer_changes(mvs, synth):
     """the upload of a ground truth is skipped only while the staging set really holds it -- a view of another size
     (the staging buffer moves or is laid out differently) and a host block that went back to the allocator both invalidate
