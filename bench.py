@@ -28,7 +28,7 @@ with a rocprofv3 --kernel-trace of `bench.py --serial`).
 Rank 0 prints ONE JSON line (schema in the task contract) including
   roofline     -- dominant stage: algorithmic bytes / HIP-event time against the 8 TB/s HBM peak, `fused_bytes` /
                   `frac_fused` on the bytes the fused path must move, plus the PMC-measured traffic of the same stage
-                  (profiles/r04_traffic.json, valid only for the kernel sources it was measured on); with
+                  (profiles/r05_traffic.json, valid only for the kernel sources it was measured on); with
                   --conv-method 2 the direct stencil against the 157.3 Tflop/s fp32 vector peak (bound "fp32")
   cpu_baseline -- the CPU oracle (C restatement of the reference's ImgLib2 path, not the JVM) on a bounded sample, two modes:
                   as_reference (the reference's threading) and all_cores
@@ -57,7 +57,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (same guide); the direct stencil's bound
 # PMC traffic record of the running build (tools/profile_all.sh writes it first and points the bench at it through the environment)
-TRAFFIC_JSON = os.environ.get("MVSIM_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_JSON = os.environ.get("MVSIM_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_JSON_1024 = os.environ.get("MVSIM_TRAFFIC_JSON_1024") or os.path.join(ROOT, "profiles", "r05_traffic_1024.json")
 
 
 def parse_args():
@@ -287,12 +288,14 @@ def cpu_baseline(gt: np.ndarray, psf_raw: np.ndarray, degrees: int, inc: int, sn
     }
 
 
-def load_traffic(n: int, psf: int, inc: int, streams: int, conv_method: int, kernel_sha: str):
+def load_traffic(n: int, psf: int, inc: int, streams: int, conv_method: int, kernel_sha: str, path: str = None):
     """PMC-measured HBM bytes per view and stage (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes), written
     by tools/pmc_traffic.py --json.  Valid only for the workload and the kernel sources it was collected on."""
-    if not os.path.exists(TRAFFIC_JSON):
-        return None, f"{os.path.relpath(TRAFFIC_JSON, ROOT)} not present"
-    rec = json.load(open(TRAFFIC_JSON))
+    path = path or TRAFFIC_JSON
+    if not os.path.exists(path):
+        return None, f"{os.path.relpath(path, ROOT)} not present"
+    rec = json.load(open(path))
+    rec["file"] = os.path.relpath(path, ROOT)
     w = rec.get("workload", {})
     if (w.get("size"), w.get("psf"), w.get("inc")) != (n, psf, inc):
         return None, f"profiled workload {w} differs from this run"
@@ -304,7 +307,7 @@ def load_traffic(n: int, psf: int, inc: int, streams: int, conv_method: int, ker
 
 
 def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: int, conv_method: int, traffic, traffic_note,
-                    view_wall_ms: float | None = None, overlapped: bool = False):
+                    view_wall_ms: float | None = None, overlapped: bool = False, plane_stats=None):
     """Roofline object from per-stage HIP-event times (ms).  Two byte models, never blended:
       algorithmic_bytes / frac       -- SURVEY.md 8(d): every REFERENCE stage reads its input once and writes its output once
                                         (rotate 8N + attenuate 8N; convolve 8N + 4K^3; extract + Poisson 8N'; view 24N + 8N')
@@ -365,13 +368,23 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
     if conv_method == 1 and mvs._lib.load().mvsim_fft_geometry((C.c_int64 * 3)(n, n, n), (C.c_int64 * 3)(psf_edge, psf_edge, psf_edge), geo) == 0:
         px, py_, planes, hxp, zdirect = (int(v) for v in geo)
         cplx = 8 * hxp * py_ * planes
+        # planes the passes really processed: a specimen in empty space leaves planes whose spectrum is exactly zero, and the passes
+        # skip them -- the byte model follows (mvsim_get_plane_stats of the last flagged view), so that no pass shows a
+        # rate it did not run at.  fin: share of the planes that enter pass B / the z pass, fout: share that leaves the z pass.
+        fin = fout = 1.0
+        if plane_stats and plane_stats[0] == planes and zdirect:
+            fin = 1.0 - plane_stats[1] / planes
+            fout = 1.0 - plane_stats[2] / planes
         pb = {"A k_fft_x_r2c": (4 * nvox + cplx, stage["pass_a_ms"]),
-              "B k_fft_lines<FWD>": (2 * cplx, stage["pass_b_ms"]),
-              ("C k_zconv" if zdirect else "C k_fft_lines<CONV>"): (2 * cplx + (0 if zdirect else cplx), stage["pass_c_ms"]),
-              "D k_fft_lines<INV>": (2 * cplx, stage["pass_d_ms"]),
-              "E k_fft_x_c2r": (cplx + 4 * nvox, stage["pass_e_ms"])}
-        passes = {k: {"bytes": b, "ms": round(t, 4), "GBps": b / (t * 1e-3) / 1e9, "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+              "B k_fft_lines<FWD>": (2 * cplx * fin, stage["pass_b_ms"]),
+              ("C k_zconv" if zdirect else "C k_fft_lines<CONV>"): (cplx * fin + cplx * fout + (0 if zdirect else cplx), stage["pass_c_ms"]),
+              "D k_fft_lines<INV>": (2 * cplx * fout, stage["pass_d_ms"]),
+              "E k_fft_x_c2r": (cplx * fout + 4 * nvox, stage["pass_e_ms"])}
+        passes = {k: {"bytes": int(b), "ms": round(t, 4), "GBps": b / (t * 1e-3) / 1e9, "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
                   for k, (b, t) in pb.items() if t > 0}
+        passes["planes"] = {"of_the_spectrum": planes, "share_entering_the_y_and_z_passes": round(fin, 4), "share_leaving_the_z_pass": round(fout, 4),
+                            "note": "bytes = the pass's own reads + writes of the planes it processed (empty planes are skipped exactly, "
+                                    "option skip_empty); a dense volume has both shares at 1"}
     view_ms = view_wall_ms if view_wall_ms else stage["total_ms"]
     if conv_method == 2:
         flop = 2.0 * k3 * nvox
@@ -389,7 +402,7 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
                 "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stages[dom]["frac"],
                 "fused_bytes": fused[dom], "frac_fused": stages[dom]["frac_fused"],
                 # HBM bytes of the dominant stage per view from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE,
-                # separate passes of `bench.py --serial` (profiles/r04_traffic.json); null when that record does not describe
+                # separate passes of `bench.py --serial` (profiles/r05_traffic.json); null when that record does not describe
                 # this build / workload
                 "traffic": stages[dom].get("traffic"),
                 "hbm_measured": stages[dom].get("hbm_measured"),
@@ -416,7 +429,7 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
     if traffic is None:
         rec["traffic_note"] = traffic_note
     else:
-        rec["traffic_source"] = {"file": os.path.relpath(TRAFFIC_JSON, ROOT), "kernel_sha": traffic.get("kernel_sha"),
+        rec["traffic_source"] = {"file": traffic.get("file"), "kernel_sha": traffic.get("kernel_sha"),
                                  "views_profiled": traffic.get("views_profiled")}
         tv = sum(per_view.values())
         rec["whole_view"]["traffic"] = tv
@@ -504,8 +517,10 @@ def size_1024_record(mvs, torch, dev, dev_index: int, gt_dev_512, psf_raw: np.nd
         wall_serial = run()
         stage = c.timings()
         c.enable_timing(False)
-        rl = roofline_record(mvs, stage, n ** 3, n * n * nzo, n, psf_raw.shape[0], 1, None, "not profiled at this size",
-                             view_wall_ms=wall_serial * 1e3)
+        build = importlib.import_module("multiview-simulation_amd.build")
+        traffic, tnote = load_traffic(n, psf_raw.shape[0], inc, 1, 1, build.source_sha(), TRAFFIC_JSON_1024)
+        rl = roofline_record(mvs, stage, n ** 3, n * n * nzo, n, psf_raw.shape[0], 1, traffic, tnote,
+                             view_wall_ms=wall_serial * 1e3, plane_stats=c.plane_stats())
     mean_count = float(acq[: n * n].double().mean().item())
     del acq, g
     torch.cuda.empty_cache()
@@ -1032,6 +1047,7 @@ def main():
                       "note": "options tail_overlap = psf_overlap = 0 (kernels strictly one at a time): the leg `roofline` is read from"}
         set_overlap(True)
 
+    plane_stats = ctx.plane_stats() if (rank == 0 and my_views) else None      # of the leg `roofline` is read from (before the dense leg)
     no_empty = None
     if rank == 0 and not multi and my_views and args.conv_method == 1 and not args.no_dense_leg:
         # The rotate + attenuate + x-transform kernel skips the fp64 blends and the transforms of rows that hold no non-zero voxel
@@ -1113,7 +1129,7 @@ def main():
             wall_ms = (serial_leg["ms_per_step"] if serial_leg else ms_per_step)
             wall_view = wall_ms / max(1, len(my_views)) if len(ctxs) == 1 else None
             out["roofline"] = roofline_record(mvs, stage, nvox, n * n * nzo, n, args.psf, args.conv_method, traffic, note,
-                                              view_wall_ms=wall_view, overlapped=stage_overlapped)
+                                              view_wall_ms=wall_view, overlapped=stage_overlapped, plane_stats=plane_stats)
             out["kernel_sha"] = kernel_sha
     if rank == 0 and not multi and len(ctxs) == 1 and not args.no_main_iteration and args.conv_method == 1 and my_views:
         # The whole body of `main`'s view loop (SimulateMultiViewDataset.java:567-613): the view, then makeIsotropic and the

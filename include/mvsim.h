@@ -315,6 +315,11 @@ int mvsim_fft_geometry(const int64_t dim[3], const int64_t kdim[3], int64_t geom
  * tile serves, LDS bytes per block, blocks per CU}.  Any PSF of 1..64 taps per axis is accepted (SimulateMultiViewDataset.java:579
  * loads 51^3 stacks); beyond that MVSIM_EINVAL (use the FFT method). */
 int mvsim_stencil_geometry(const int64_t kdim[3], int64_t geometry[5]);
+/* Planes the convolution passes of the last FLAGGED view skipped (option "skip_empty"; exact: the spectrum of an empty attenuated plane
+ * is zero): stats = {planes of the view, planes whose attenuated image is empty (pass B does not transform them, the z pass does not
+ * read them), planes of the z pass's output that are empty (passes D and E skip them)}.  Read from a page-locked word the device
+ * writes, without synchronising: call after the view has completed.  All zero when no view has carried flags yet. */
+int mvsim_get_plane_stats(mvsim_ctx* ctx, int64_t stats[3]);
 int mvsim_enable_timing(mvsim_ctx* ctx, int enable);
 int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t);
 

@@ -464,6 +464,12 @@ class Context:
             C.byref(o), C.byref(corr) if want_corr else None))
         return corr.value if want_corr else None
 
+    def plane_stats(self):
+        """(planes of the last flagged view, its empty attenuated planes, its empty planes behind the z pass): what option skip_empty skipped."""
+        st = (C.c_int64 * 3)()
+        _lib.check(self._L.mvsim_get_plane_stats(self._h, st))
+        return int(st[0]), int(st[1]), int(st[2])
+
     def transfer_stats(self):
         """(views whose acquisition crossed PCIe as uint16 counts, how many of them fell back to float32)."""
         a, b = C.c_int64(), C.c_int64()

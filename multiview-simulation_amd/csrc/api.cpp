@@ -1841,6 +1841,17 @@ int mvsim_wait(mvsim_ctx* ctx, int64_t ticket, double* correction)
     return MVSIM_OK;
 }
 
+int mvsim_get_plane_stats(mvsim_ctx* ctx, int64_t stats[3])
+{
+    MVSIM_CHECK_ARG(ctx != nullptr && stats != nullptr, "null pointer");
+    stats[0] = stats[1] = stats[2] = 0;
+    if (ctx->empty_hint && ctx->empty_hint[0] >= 0) {
+        const volatile int* h = ctx->empty_hint;
+        stats[0] = h[2]; stats[1] = h[0]; stats[2] = h[1] >= 0 ? h[1] : 0;
+    }
+    return MVSIM_OK;
+}
+
 int mvsim_get_transfer_stats(mvsim_ctx* ctx, int64_t* views_as_u16, int64_t* fallbacks)
 {
     MVSIM_CHECK_ARG(ctx != nullptr, "ctx is null");

@@ -615,10 +615,10 @@ __global__ __launch_bounds__(1024) void k_plane_flags_finish(const int* __restri
 {
     // the flags once through LDS (volumes of up to 16384 planes; beyond that straight from memory): every thread then reads up to 64 of them
     __shared__ unsigned char sf[16384];
-    __shared__ int cnt;
+    __shared__ int cnt, cnt_dil;
     const int t = threadIdx.x;
     const bool in_lds = n <= 16384;
-    if (t == 0) cnt = 0;
+    if (t == 0) { cnt = 0; cnt_dil = 0; }
     __syncthreads();
     int mine = 0;
     for (int z = t; z < n; z += 1024) {
@@ -645,10 +645,18 @@ __global__ __launch_bounds__(1024) void k_plane_flags_finish(const int* __restri
             if (i / 32 + 1 < nwords) bits[i / 32 + 1] = (unsigned int)(m >> 32);
         }
     }
+    int mine_dil = 0;
     for (int z = t; z < n; z += 1024) {
         int any = 0;
         for (int tt = 0; tt < kz; ++tt) any |= flag(mir(z + c - tt));
         dil[z] = any;
+        mine_dil += !any;
+    }
+    if (empty_hint) {
+        // (statistics only: how many planes of the z pass's OUTPUT are empty -- what passes D and E skip; mvsim_get_plane_stats)
+        if (mine_dil) atomicAdd(&cnt_dil, mine_dil);
+        __syncthreads();
+        if (t == 0) { empty_hint[1] = cnt_dil; empty_hint[2] = n; }
     }
 }
 
@@ -1670,8 +1678,8 @@ int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, f
     bool want_flags = plane_nz && ctx->opt.skip_empty;
     if (want_flags) {
         if (!ctx->empty_hint) {
-            MVSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->empty_hint), sizeof(int), hipHostMallocDefault));
-            *ctx->empty_hint = -1;
+            MVSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->empty_hint), 4 * sizeof(int), hipHostMallocDefault));
+            ctx->empty_hint[0] = -1; ctx->empty_hint[1] = -1; ctx->empty_hint[2] = 0; ctx->empty_hint[3] = 0;
         }
         const int hint = *reinterpret_cast<volatile int*>(ctx->empty_hint);
         if (hint == 0 && ctx->views_since_flags < 15) { want_flags = false; ctx->views_since_flags += 1; }

@@ -1105,7 +1105,7 @@ def test_config4_as_stated_stencil_through_pinned_zslabs(mvs, orc):
             orc.norm_image(pn)
             acq_all = np.concatenate([a.reshape(-1, ny, nx) for a in acq_s], axis=0)
             rng = np.random.default_rng(4)
-            for zlo, zhi, zs in ((0, 35, (0, 3)), (219, 285, (249, 252))):
+            for zlo, zhi, zs in ((0, 35, (0, 3)), (218, 285, (249, 252))):     # 63 taps, centre 31: plane z reads z - 31 .. z + 31
                 win = c.download(d_att + zlo * ny * nx * 4, (zhi - zlo, ny, nx))
                 ys = np.concatenate([np.arange(3), rng.integers(0, ny, 60), [1000]])
                 xs = np.concatenate([np.arange(3), rng.integers(0, nx, 60), [1100]])
@@ -2004,3 +2004,22 @@ def test_graph_capture_with_the_side_stream_options(mvs, synth):
             c.dev_free(d_acq)
     for k, v in outs.items():
         assert np.array_equal(v, outs["plain"]), k
+
+
+@pytest.mark.parametrize("tool,kwargs", [
+    ("fuzz_strided_zpass", dict(n_cases=50, seed=11)),            # k_zconv_strided forced wherever its geometry allows, any plane size
+    ("fuzz_strided_zpass", dict(n_cases=25, seed=12, EXP=3)),     # ... with the z pass's tiles in plain grid order as well
+    ("fuzz_fused_rotate", dict(count=30, seed=2025)),             # fused rotate + attenuate + x transform against the separate kernels, bit for bit
+    ("fuzz_stencil", dict(count=30, seed=100, oracle_limit=4e8)), # direct stencil against the oracle's exact sum (small cases) / the FFT passes
+])
+def test_seeded_fuzzers(tool, kwargs):
+    """The three random-geometry stress tools of tools/ as seeded test cases (they used to be one-off runs: 1 900 cases in round 4): each
+    returns its number of failing cases."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        mod = importlib.import_module(tool)
+        assert mod.run(verbose=False, **kwargs) == 0
+    finally:
+        sys.path.remove(os.path.join(ROOT, "tools"))
+

@@ -56,8 +56,8 @@ def main():
     fd, wd, views = argv[0], argv[1], int(argv[2])
     rd, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; no trace domains), "
-          "python3 bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline")
-    print("# workload: 512^3 x 8 views, 31^3 PSF, inc 1.  Counter unit KiB; gfx950: FETCH_SIZE reports 1/2 of a wide "
+          + opts.get("command", "python3 bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline"))
+    print("# workload: " + opts.get("workload", "512^3 x 8 views, 31^3 PSF, inc 1") + ".  Counter unit KiB; gfx950: FETCH_SIZE reports 1/2 of a wide "
           "coalesced read stream")
     print("# (MI355X_MICROARCH.md, HBM section) -> x2 correction applied to the read column.  Values are means per launch.")
     print(f"{'kernel':100s} {'launches':>8s} {'read_GB':>9s} {'write_GB':>9s}")
@@ -79,8 +79,8 @@ def main():
         rec = {"kernel_sha": sha, "workload": {"size": int(opts.get("size", 512)), "psf": int(opts.get("psf", 31)), "inc": int(opts.get("inc", 1))},
                "views_profiled": views, "per_view_bytes": {k: v for k, v in stages.items() if k != "other"},
                "per_kernel": per_kernel,
-               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (no trace domains) of "
-                         "`python3 bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams`; counter unit "
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (no trace domains) of `"
+                         + opts.get("command", "python3 bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams") + "`; counter unit "
                          "KiB; FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md)"}
         json.dump(rec, open(opts["json"], "w"), indent=1)
         print(f"# wrote {opts['json']} (kernel_sha {sha})")

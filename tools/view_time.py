@@ -12,11 +12,19 @@ nx, ny, nz, kx, ky, kz, inc = (int(a) for a in sys.argv[1:8])
 rng = np.random.default_rng(1)
 ctx = mvs.Context(0)
 ctx.set_option("tail_overlap", 0); ctx.set_option("psf_overlap", 0)   # one kernel at a time: stage times are the kernels' own
+gt_kind = "blob"
 for kv in sys.argv[8:]:
-    ctx.set_option(*kv.split("=", 1))
+    if kv.startswith("gt="):
+        gt_kind = kv[3:]                 # gt=phantom2x: the 512^3 sphere phantom up-sampled 2x (what bench.py's size_1024 record runs on)
+    else:
+        ctx.set_option(*kv.split("=", 1))
 # cheap compactly supported volume built on the host plane by plane
 w = lambda n: np.clip(1 - ((np.arange(n, dtype=np.float32) - (n - 1) / 2) / (0.3 * n)) ** 2, 0, None) ** 2
-gt = (w(nz)[:, None, None] * w(ny)[None, :, None]).astype(np.float32) * w(nx)[None, None, :]
+if gt_kind == "phantom2x":
+    assert nx == ny == nz and nx % 2 == 0
+    gt = np.ascontiguousarray(synth.sphere_phantom(nx // 2).repeat(2, axis=0).repeat(2, axis=1).repeat(2, axis=2))
+else:
+    gt = (w(nz)[:, None, None] * w(ny)[None, :, None]).astype(np.float32) * w(nx)[None, None, :]
 d_gt = ctx.dev_alloc(gt.nbytes); ctx.upload(d_gt, gt)
 nzo = (nz - 1) // inc + 1
 d_acq = ctx.dev_alloc(nzo * ny * nx * 4)
