@@ -226,6 +226,12 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
 int mvsim_simulate_views_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* const* psf_host,
                              const int64_t kdim[3], const mvsim_view_params* params, const mvsim_view_outputs* outs,
                              int n_views);
+/* The same with HOST buffers: the ground truth goes up once, the views run in one call (stacked / side by side as above), and the
+ * acquisitions -- acq_host[v] of dim[0] * dim[1] * mvsim_extract_nz(dim[2], params[v].inc) floats -- come back together, as uint16 counts
+ * over PCIe where the views are sampled (see mvsim_get_transfer_stats).  Synchronous; what a JVM calls for the reference's own run
+ * (SimulateMultiViewDataset.java:567-585: seven views of one 289^3 volume). */
+int mvsim_simulate_views(mvsim_ctx* ctx, const float* gt_host, const int64_t dim[3], float* const* psf_host,
+                         const int64_t kdim[3], const mvsim_view_params* params, float* const* acq_host, int n_views);
 /* One whole iteration of `main`'s view loop (SimulateMultiViewDataset.java:567-613), device-resident: the view above
  * (rotate, attenuate, convolve, adjust, extractSlices + Poisson) followed by what the loop does with its results --
  *   iso          = makeIsotropic(acq, inc)                                    (:588)   Nx*Ny*isotropic_nz

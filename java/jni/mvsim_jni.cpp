@@ -438,6 +438,49 @@ JNIEXPORT jdouble JNICALL JNI_FN(waitView)(JNIEnv* env, jclass, jlong h, jlong t
 
 JNIEXPORT void JNICALL JNI_FN(waitViewQuiet)(JNIEnv*, jclass, jlong h, jlong ticket) { (void)mvsim_wait(ctx_of(h), ticket, nullptr); }
 
+// mvsim_simulate_views: V views of one ground truth in one call (host buffers; the library stacks them when they cannot fill the chip
+// one at a time and brings the acquisitions back as 16-bit counts)
+JNIEXPORT void JNICALL JNI_FN(simulateViewsBatch)(JNIEnv* env, jclass, jlong h, jobject gt, jlongArray dim, jobjectArray psfs, jlongArray kdim,
+                                                  jintArray degrees, jdouble delta, jfloat min_value, jfloat target, jint inc, jfloat snr,
+                                                  jlongArray seeds, jobjectArray acqs)
+{
+    Dim d(env, dim);
+    if (!d.ok) return;
+    Dim k(env, kdim);
+    if (!k.ok) return;
+    if (inc < 1) { throw_new(env, "java/lang/IllegalArgumentException", "simulateViewsBatch: inc must be >= 1"); return; }
+    if (!psfs || !degrees || !seeds || !acqs) { throw_new(env, "java/lang/IllegalArgumentException", "simulateViewsBatch: null argument"); return; }
+    const jsize n = env->GetArrayLength(degrees);
+    if (env->GetArrayLength(psfs) != n || env->GetArrayLength(seeds) != n || env->GetArrayLength(acqs) != n) {
+        throw_new(env, "java/lang/IllegalArgumentException", "simulateViewsBatch: one PSF, seed and acquisition buffer per view");
+        return;
+    }
+    float* pg = fptr(env, gt, d.n(), "simulateViewsBatch: ground-truth buffer smaller than the dimensions");
+    if (!pg) return;
+    const int64_t acq_floats = d.d[0] * d.d[1] * mvsim_extract_nz(d.d[2], inc);
+    std::vector<jint> deg(static_cast<size_t>(n));
+    std::vector<jlong> sd(static_cast<size_t>(n));
+    if (n > 0) {
+        env->GetIntArrayRegion(degrees, 0, n, deg.data());
+        if (env->ExceptionCheck()) return;
+        env->GetLongArrayRegion(seeds, 0, n, sd.data());
+        if (env->ExceptionCheck()) return;
+    }
+    std::vector<float*> pp(static_cast<size_t>(n)), pa(static_cast<size_t>(n));
+    std::vector<mvsim_view_params> par(static_cast<size_t>(n));
+    for (jsize v = 0; v < n; ++v) {
+        jobject b = env->GetObjectArrayElement(psfs, v);
+        if (env->ExceptionCheck()) return;
+        pp[v] = fptr(env, b, k.n(), "simulateViewsBatch: PSF buffer smaller than its dimensions");
+        jobject a = env->GetObjectArrayElement(acqs, v);
+        if (env->ExceptionCheck()) return;
+        pa[v] = fptr(env, a, acq_floats, "simulateViewsBatch: acquisition buffer smaller than nx * ny * ((nz - 1) / inc + 1) floats");
+        if (!pp[v] || !pa[v]) return;
+        fill_params(&par[v], 0, deg[v], delta, min_value, target, inc, snr, sd[v], v);
+    }
+    throw_for(env, mvsim_simulate_views(ctx_of(h), pg, d.d, pp.data(), k.d, par.data(), pa.data(), (int)n));
+}
+
 // ---- mvsim_group_* -------------------------------------------------------------------------------------------------
 JNIEXPORT jlong JNICALL JNI_FN(groupCreate)(JNIEnv* env, jclass, jint ndev)
 {

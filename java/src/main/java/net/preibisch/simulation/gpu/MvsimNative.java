@@ -74,6 +74,10 @@ final class MvsimNative
 	static native void groupDestroy( long group );
 	static native void groupBroadcastVolume( long group, FloatBuffer gt, long[] dim );
 	/** dim = the dimensions given to groupBroadcastVolume: the shim checks every acquisition buffer against them */
+	/** mvsim_simulate_views: all views of one ground truth in ONE native call (stacked kernels for views that cannot fill the chip) */
+	static native void simulateViewsBatch( long ctx, FloatBuffer gt, long[] dim, FloatBuffer[] psfs, long[] kdim, int[] degrees, double delta,
+			float minValue, float targetAverage, int inc, float snr, long[] seeds, FloatBuffer[] acqs );
+
 	static native void groupSimulateViews( long group, FloatBuffer[] psfs, long[] kdim, long[] dim, int[] degrees, double delta, float minValue,
 			float targetAverage, int inc, float snr, long[] seeds, FloatBuffer[] acqs );
 }

@@ -286,6 +286,53 @@ public class SimulateMultiViewDatasetGPU
 	 * sets inside the library, three HIP streams).  The ground truth crosses PCIe ONCE (same buffer for every angle); per
 	 * view only the acquisition comes back.  psfs.get( v ) is normalised in place like convolve does.
 	 */
+	private static boolean sameDimensions( final List< Img< FloatType > > imgs )
+	{
+		for ( final Img< FloatType > i : imgs )
+			for ( int k = 0; k < 3; ++k )
+				if ( Buffers.dims( i )[ k ] != Buffers.dims( imgs.get( 0 ) )[ k ] )
+					return false;
+		return true;
+	}
+
+	private static List< Img< FloatType > > simulateViewsBatched( final long ctx, final RandomAccessibleInterval< FloatType > groundTruth,
+			final List< Img< FloatType > > psfs, final int[] degrees, final double attenuation, final int lightsheetSpacing, final float poissonSNR,
+			final Random rnd, final long[] d, final long[] o )
+	{
+		final int n = degrees.length;
+		final Buffers.Block[] acq = new Buffers.Block[ n ], psf = new Buffers.Block[ n ];
+		final java.nio.FloatBuffer[] pb = new java.nio.FloatBuffer[ n ], ab = new java.nio.FloatBuffer[ n ];
+		final long[] seeds = new long[ n ];
+		try ( Buffers.Block gt = Buffers.toBlock( Views.zeroMin( groundTruth ) ) )
+		{
+			for ( int v = 0; v < n; ++v )
+			{
+				psf[ v ] = Buffers.toBlock( psfs.get( v ) );
+				acq[ v ] = Buffers.direct( Buffers.size( o ) );
+				pb[ v ] = psf[ v ].floats;
+				ab[ v ] = acq[ v ].floats;
+				seeds[ v ] = rnd.nextLong();                              // one draw per view, in view order, as the pipelined form does
+			}
+			MvsimNative.simulateViewsBatch( ctx, gt.floats, d, pb, Buffers.dims( psfs.get( 0 ) ), degrees, attenuation, minValue, avgIntensity,
+					lightsheetSpacing, poissonSNR, seeds, ab );
+			final List< Img< FloatType > > result = new ArrayList<>();
+			for ( int v = 0; v < n; ++v )
+			{
+				result.add( Buffers.toImg( acq[ v ], o ) );
+				Buffers.copyBack( psf[ v ], psfs.get( v ) );              // normalised in place, as convolve() leaves it (Q5)
+			}
+			return result;
+		}
+		finally
+		{
+			for ( int v = 0; v < n; ++v )
+			{
+				if ( acq[ v ] != null ) acq[ v ].close();
+				if ( psf[ v ] != null ) psf[ v ].close();
+			}
+		}
+	}
+
 	public static List< Img< FloatType > > simulateViews( final RandomAccessibleInterval< FloatType > groundTruth, final List< Img< FloatType > > psfs,
 			final int[] degrees, final double attenuation, final int lightsheetSpacing, final float poissonSNR, final Random rnd )
 	{
@@ -293,6 +340,10 @@ public class SimulateMultiViewDatasetGPU
 		final long[] o = new long[] { d[ 0 ], d[ 1 ], ( d[ 2 ] - 1 ) / lightsheetSpacing + 1 };
 		final long ctx = GpuContextPool.get();
 		final List< Img< FloatType > > result = new ArrayList<>();
+		// Views that cannot fill the chip one at a time -- the reference's own run: seven views of a 289^3 volume (:376-380, :567) -- go to
+		// the library in ONE call: it stacks them (one kernel launch per stage for all views) and brings the counts back as 16-bit values.
+		if ( Buffers.size( d ) <= ( 1L << 26 ) && degrees.length > 1 && degrees.length <= 32 && sameDimensions( psfs ) )
+			return simulateViewsBatched( ctx, groundTruth, psfs, degrees, attenuation, lightsheetSpacing, poissonSNR, rnd, d, o );
 		final Buffers.Block[] acq = new Buffers.Block[ 2 ], psf = new Buffers.Block[ 2 ];
 		final long[] ticket = new long[ 2 ];
 		try ( Buffers.Block gt = Buffers.toBlock( Views.zeroMin( groundTruth ) ) )

@@ -495,6 +495,27 @@ class Context:
                                   for v in range(nv)])
         _lib.check(self._L.mvsim_simulate_views_dev(self._h, C.c_void_p(gt_dptr), (C.c_int64 * 3)(*dim_xyz), pp, _dim(psfs[0]), pa, oo, nv))
 
+    def simulate_views(self, gt: np.ndarray, psfs, params) -> list:
+        """Host buffers: ``len(psfs)`` views of one ground truth in ONE call (mvsim_simulate_views) -- the view loop of `main`
+        (SimulateMultiViewDataset.java:567-585).  ``psfs[v]`` is normalised in place.  Returns the acquisitions."""
+        g = _as_volume(gt, "ground truth")
+        nv = len(psfs)
+        if len(params) != nv:
+            raise ValueError("psfs and params must have the same length")
+        if nv == 0:
+            return []
+        for p in psfs:
+            _check_inplace(p, "psf")
+            if p.shape != psfs[0].shape:
+                raise ValueError("all PSFs of one call share their dimensions")
+        nz, ny, nx = g.shape
+        outs = [np.empty((self._L.mvsim_extract_nz(nz, pr.inc), ny, nx), dtype=np.float32) for pr in params]
+        pp = (C.c_void_p * nv)(*[p.ctypes.data for p in psfs])
+        oo = (C.c_void_p * nv)(*[o.ctypes.data for o in outs])
+        pa = (ViewParams * nv)(*params)
+        _lib.check(self._L.mvsim_simulate_views(self._h, _ptr(g), _dim(g), pp, _dim(psfs[0]), pa, oo, nv))
+        return outs
+
     def simulate_iteration_dev(self, gt_dptr: int, dim_xyz, psf: np.ndarray, params: ViewParams, back_degrees: int, acq_dptr: int,
                                iso_dptr: int = 0, view_dptr: int = 0, view_weights_dptr: int = 0, view_psf_dptr: int = 0,
                                rot_dptr: int = 0, att_dptr: int = 0, con_dptr: int = 0) -> None:

@@ -111,6 +111,7 @@ SIGNATURES = {
     "mvsim_get_transfer_stats": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mvsim_simulate_views_dev": (C.c_int, [_vp, _vp, _i64p, C.POINTER(_vp), _i64p, C.POINTER(ViewParams),
                                            C.POINTER(ViewOutputs), C.c_int]),
+    "mvsim_simulate_views": (C.c_int, [_vp, _vp, _i64p, C.POINTER(_vp), _i64p, C.POINTER(ViewParams), C.POINTER(_vp), C.c_int]),
     "mvsim_simulate_iteration_dev": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams), C.c_int,
                                                C.POINTER(ViewOutputs), C.POINTER(IterationOutputs)]),
     "mvsim_simulate_view": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams),

@@ -1012,15 +1012,18 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
     return MVSIM_OK;
 }
 
-// How many views of this size run side by side.  A view is a chain of ~12 dependent launches; below ~2^25 voxels most of them
-// leave CUs idle (128^3: a few hundred blocks per launch; 289^3: the rotate + attenuate kernel is 1 300 serial waves) and what a
-// view costs is the latency of the chain, not its work.  Measured (profiles/r05_small_views.txt): see DESIGN 4.8.
+// How many views of this size run side by side on LANES -- the form for views that cannot be stacked (an adjusted volume requested,
+// another spacing per view, ...).  A view is a chain of ~12 dependent launches that each leave CUs idle below ~2^24 voxels, so two to
+// four chains side by side hide part of each other's latency; beyond that the host's launch rate is the bound (~75 us per view), and
+// from 289^3 up lanes LOSE (kernels that each fill the CUs run one after the other anyway, and their working sets evict each other).
+// Measured (profiles/r05_small_views.txt): 64^3 3.4 -> 4.5 Gvoxel/s and 128^3 16.7 -> 25.0 with four lanes, 256^3 41 -> 49 with two
+// (37 with four), 289^3 48 -> 24 with four: DESIGN 4.8.
 static int pick_view_lanes(const mvsim_ctx* ctx, const int64_t dim[3], int n_views)
 {
     int lanes = ctx->opt.view_lanes;
     if (lanes <= 0) {
         const int64_t n = dim[0] * dim[1] * dim[2];
-        lanes = n <= ((int64_t)1 << 22) ? 8 : n <= ((int64_t)1 << 25) ? 4 : n < ((int64_t)1 << 27) ? 2 : 1;
+        lanes = n <= ((int64_t)1 << 22) ? 4 : n <= ((int64_t)1 << 24) ? 2 : 1;
     }
     return std::max(1, std::min(lanes, n_views));
 }
@@ -1838,6 +1841,80 @@ int mvsim_wait(mvsim_ctx* ctx, int64_t ticket, double* correction)
     }
     // otherwise the view has landed already: a later call on the same staging set, or an earlier wait, saw to that
     if (correction) *correction = ctx->async_corr_done[ticket % mvsim_ctx::ASYNC_HISTORY];
+    return MVSIM_OK;
+}
+
+// Host buffers in and out for the stacked / side-by-side views of mvsim_simulate_views_dev: the ground truth goes up once, the V views
+// run in one call, and the acquisitions come back together -- as uint16 counts where the views are sampled (one transfer of half the
+// bytes, widened by the host threads), as float32 for a view that holds a value beyond 65 535 or was simulated without noise.
+int mvsim_simulate_views(mvsim_ctx* ctx, const float* gt_host, const int64_t dim[3], float* const* psf_host, const int64_t kdim[3],
+                         const mvsim_view_params* params, float* const* acq_host, int n_views)
+{
+    MVSIM_TRY(set_device(ctx));
+    MVSIM_TRY(check_dim(dim));
+    MVSIM_CHECK_ARG(gt_host && psf_host && kdim && params && acq_host, "null pointer");
+    MVSIM_CHECK_ARG(n_views >= 0 && n_views <= MVSIM_MAX_VIEWS, "n_views must be in [0, MVSIM_MAX_VIEWS]");
+    if (n_views == 0) return MVSIM_OK;
+    SyncOnExit sync{ctx};
+    const int64_t n = nvox(dim), plane = dim[0] * dim[1];
+    // per-view acquisition sizes (the spacing may differ from view to view), 256-byte aligned slots
+    std::vector<size_t> off((size_t)n_views + 1, 0), off16((size_t)n_views + 1, 0);
+    std::vector<long long> cnt((size_t)n_views);
+    for (int v = 0; v < n_views; ++v) {
+        MVSIM_CHECK_ARG(acq_host[v] != nullptr && params[v].inc >= 1, "null acquisition buffer or inc < 1");
+        cnt[(size_t)v] = plane * mvsim_extract_nz(dim[2], params[v].inc);
+        off[(size_t)v + 1] = off[(size_t)v] + (((size_t)cnt[(size_t)v] * sizeof(float) + 255) & ~(size_t)255);
+        off16[(size_t)v + 1] = off16[(size_t)v] + (((size_t)cnt[(size_t)v] * sizeof(unsigned short) + 255) & ~(size_t)255);
+    }
+    MVSIM_TRY(up(ctx, ctx->host_gt, gt_host, (size_t)n * sizeof(float)));
+    MVSIM_TRY(ctx->out_buf.reserve(off[(size_t)n_views]));
+    std::vector<mvsim_view_outputs> outs((size_t)n_views, mvsim_view_outputs{nullptr, nullptr, nullptr, nullptr});
+    for (int v = 0; v < n_views; ++v) outs[(size_t)v].acq = reinterpret_cast<float*>(ctx->out_buf.as<char>() + off[(size_t)v]);
+    MVSIM_TRY(mvsim_simulate_views_dev(ctx, ctx->host_gt.as<float>(), dim, psf_host, kdim, params, outs.data(), n_views));
+    MVSIM_TRY(set_device(ctx));
+    // pack the sampled views, fetch everything that was packed in ONE transfer (+ the flags), widen; float32 for the rest
+    const size_t flags_at = off16[(size_t)n_views], u16_bytes = flags_at + (size_t)n_views * sizeof(unsigned int);
+    bool any16 = false;
+    std::vector<char> as16((size_t)n_views, 0);
+    for (int v = 0; v < n_views; ++v) { as16[(size_t)v] = (ctx->opt.acq_u16 != 0 && params[v].snr >= 0.0f) ? 1 : 0; any16 = any16 || as16[(size_t)v]; }
+    if (any16) {
+        MVSIM_TRY(ctx->async_u16[0].reserve(u16_bytes));
+        if (ctx->async_u16_host_bytes[0] < u16_bytes) {
+            if (ctx->async_u16_host[0]) { (void)hipHostFree(ctx->async_u16_host[0]); ctx->async_u16_host[0] = nullptr; ctx->async_u16_host_bytes[0] = 0; }
+            MVSIM_HIP(hipHostMalloc(&ctx->async_u16_host[0], u16_bytes, hipHostMallocDefault));
+            ctx->async_u16_host_bytes[0] = u16_bytes;
+        }
+        char* d16 = ctx->async_u16[0].as<char>();
+        MVSIM_HIP(hipMemsetAsync(d16 + flags_at, 0, (size_t)n_views * sizeof(unsigned int), ctx->stream));
+        for (int v = 0; v < n_views; ++v)
+            if (as16[(size_t)v])
+                MVSIM_TRY(launch_pack_u16(ctx->stream, outs[(size_t)v].acq, reinterpret_cast<unsigned short*>(d16 + off16[(size_t)v]), cnt[(size_t)v],
+                                          reinterpret_cast<unsigned int*>(d16 + flags_at) + v));
+        MVSIM_HIP(hipMemcpyAsync(ctx->async_u16_host[0], d16, u16_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    for (int v = 0; v < n_views; ++v)
+        if (!as16[(size_t)v])
+            MVSIM_HIP(hipMemcpyAsync(acq_host[v], outs[(size_t)v].acq, (size_t)cnt[(size_t)v] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    if (any16) {
+        const char* h16 = reinterpret_cast<const char*>(ctx->async_u16_host[0]);
+        const unsigned int* flags = reinterpret_cast<const unsigned int*>(h16 + flags_at);
+        struct Job { const unsigned short* src; float* dst; long long n; };
+        std::vector<Job> jobs;
+        const long long chunk = (long long)1 << 20;
+        for (int v = 0; v < n_views; ++v) {
+            if (!as16[(size_t)v]) continue;
+            ctx->u16_views += 1;
+            if (flags[v] != 0u) {
+                ctx->u16_fallbacks += 1;
+                MVSIM_HIP(hipMemcpy(acq_host[v], outs[(size_t)v].acq, (size_t)cnt[(size_t)v] * sizeof(float), hipMemcpyDeviceToHost));
+                continue;
+            }
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(h16 + off16[(size_t)v]);
+            for (long long a = 0; a < cnt[(size_t)v]; a += chunk) jobs.push_back(Job{src + a, acq_host[v] + a, std::min(chunk, cnt[(size_t)v] - a)});
+        }
+        HostPool::get().run((int)jobs.size(), host_threads_of(ctx), [&](int j) { widen_u16(jobs[(size_t)j].src, jobs[(size_t)j].dst, jobs[(size_t)j].n); });
+    }
     return MVSIM_OK;
 }
 

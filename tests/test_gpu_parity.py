@@ -1316,6 +1316,28 @@ def test_async_acquisitions_cross_pcie_as_uint16_counts(mvs, synth):
                 assert 0 < want.max() < 65535 and np.all(want == np.round(want))
 
 
+def test_simulate_views_with_host_buffers(mvs, synth):
+    """mvsim_simulate_views: the view loop of `main` (SimulateMultiViewDataset.java:567-585) in ONE call with host buffers -- ground
+    truth up once, the views stacked, the acquisitions back together as 16-bit counts -- equals one mvsim_simulate_view call per view,
+    also with a different spacing per view (then the views run side by side instead of stacked) and for a view without noise."""
+    gt = (synth.sphere_phantom(57) + np.float32(0.4)).astype(np.float32)
+    psfs = [synth.gaussian_psf(9, sigma=(1.2, 1.4, 2.0 + 0.1 * v)) for v in range(5)]
+    with mvs.Context(0) as c:
+        for incs, snrs in (([3] * 5, [25.0] * 5), ([1, 2, 3, 1, 2], [25.0] * 5), ([2] * 5, [25.0, -1.0, 25.0, 25.0, 900.0])):
+            params = [c.view_params(degrees=15 + 50 * v, inc=incs[v], snr=snrs[v], seed=SEED + v, stream=v, conv_method=1) for v in range(5)]
+            want = [c.simulate_view(gt, psfs[v].copy(), params[v])["acq"] for v in range(5)]
+            before = c.transfer_stats()
+            mine = [p.copy() for p in psfs]
+            got = c.simulate_views(gt, mine, params)
+            after = c.transfer_stats()
+            for v in range(5):
+                assert got[v].shape == want[v].shape and np.array_equal(got[v], want[v]), (incs, snrs, v)
+                assert abs(float(mine[v].astype(np.float64).sum()) - 1.0) < 1e-6
+            sampled = sum(1 for x in snrs if x >= 0)
+            assert after[0] - before[0] == sampled and after[1] - before[1] == sum(1 for x in snrs if x > 500)
+        assert c.simulate_views(gt, [], []) == []
+
+
 def test_async_ground_truth_cache_is_dropped_when_the_staging_buffer_changes(mvs, synth):
     """the upload of a ground truth is skipped only while the staging set really holds it -- a view of another size
     (the staging buffer moves or is laid out differently) and a host block that went back to the allocator both invalidate
