@@ -32,9 +32,17 @@ Rank 0 prints ONE JSON line (schema in the task contract) including
                   --conv-method 2 the direct stencil against the 157.3 Tflop/s fp32 vector peak (bound "fp32")
   cpu_baseline -- the CPU oracle (C restatement of the reference's ImgLib2 path, not the JVM) on a bounded sample, two modes:
                   as_reference (the reference's threading) and all_cores
+  value_dense  -- top level, beside `value`: the same workload without a single empty voxel (= no_empty_space.value)
   no_empty_space -- N = 1: the serial leg again on the phantom + 1e-6 (nothing for the exact zero-row fast paths to skip)
-  end_to_end   -- N = 1: the same views with page-locked HOST buffers in and out (PCIe-inclusive; never `value`)
-  size_1024    -- N = 1: one 1024^3 view, same stage timings and roofline keys
+  end_to_end   -- N = 1: the same views with page-locked HOST buffers in and out (PCIe-inclusive; never `value`); acquisitions cross as
+                  uint16 counts, the float32 transfer is timed beside it
+  size_1024    -- N = 1: one 1024^3 view, same stage timings and roofline keys, its own PMC traffic record.  N > 1: `--views-total` 1024^3
+                  views sharded v % N with one 4.3 GB broadcast per step and the `multi_gpu` diagnostics of the main line
+  tiled_1024   -- N > 1 (and --rehearse-multi): BASELINE configs[3] as stated -- 1024^3, 31 x 31 x 63 PSF, inc 4, six views, EVERY view cut into
+                  N z slabs, one per rank (multiview-simulation_amd/tiling.py), the one double of adjustImage's sum reduced by the C ABI's
+                  mvsim_comm_allreduce_sum_f64; per-rank slab / all-reduce / finish times and the halo-recompute share
+  small_views  -- N = 1: the sizes the reference itself runs (128^3 x 8, 289^3 / 51^3 / inc 3 x 7, 256^3 x 8): sequential views against ONE
+                  mvsim_simulate_views_dev call (views stacked), bit-identity checked
 """
 from __future__ import annotations
 

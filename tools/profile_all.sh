@@ -34,7 +34,7 @@ echo "counters done"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $O/sq -o run -- python3 $BENCH --steps 1 --warmup 1 > $O/sq.log 2>&1
 python3 tools/pmc_sq_report.py $O/sq > $O/sq_counters.txt
 # the whole iteration of main's loop (mvsim_simulate_iteration_dev): the rotate-back kernels and makeIsotropic
-rocprofv3 --kernel-trace --stats -d $O/trace_it -o run -- python3 bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg > $O/trace_it.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace_it -o run -- python3 bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg --no-small-views > $O/trace_it.log 2>&1
 python3 tools/kstats.py $O/trace_it 24 $O/main_iteration_kernel_stats.csv > $O/main_iteration_kernel_stats.txt
 echo "iteration trace done"
 # HBM traffic of the views of BASELINE configs[3] and configs[4]: same two counter passes, one view at a time
