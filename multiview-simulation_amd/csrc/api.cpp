@@ -1586,14 +1586,19 @@ namespace {
 class HostPool {
 public:
     static HostPool& get() { static HostPool p; return p; }
-    // fn(chunk) for chunk = 0 .. chunks-1 on up to `threads` threads (the caller's thread takes part); returns when all are done
+    // fn(chunk) for chunk = 0 .. chunks-1 on up to `threads` threads (the caller's thread takes part); returns when all are done.
+    // One job at a time: callers on different host threads (one context each) queue up behind each other.
     void run(int chunks, int threads, const std::function<void(int)>& fn)
     {
         if (chunks <= 0) return;
+        std::lock_guard<std::mutex> one_job(run_m_);
         threads = std::max(1, std::min(threads, chunks));
         std::unique_lock<std::mutex> lk(m_);
-        while ((int)workers_.size() < threads - 1) workers_.emplace_back([this] { loop(); });
-        fn_ = &fn; next_ = 0; total_ = chunks; pending_ = chunks; gen_ += 1;
+        while ((int)workers_.size() < threads - 1) {
+            const int id = (int)workers_.size();
+            workers_.emplace_back([this, id] { loop(id); });
+        }
+        fn_ = &fn; next_ = 0; total_ = chunks; pending_ = chunks; helpers_ = threads - 1; gen_ += 1;
         cv_.notify_all();
         lk.unlock();
         work();
@@ -1619,29 +1624,29 @@ private:
                 if (!fn_ || next_ >= total_) return;
                 c = next_++; f = fn_;
             }
-            (*f)(c);
+            (*f)(c);                                   // (run() does not return before pending_ is 0, so *f outlives every call)
             std::lock_guard<std::mutex> lk(m_);
             if (--pending_ == 0) done_.notify_all();
         }
     }
-    void loop()
+    void loop(int id)
     {
         unsigned long long seen = 0;
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && fn_ && next_ < total_); });
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && fn_ && next_ < total_ && id < helpers_); });
                 if (stop_) return;
                 seen = gen_;
             }
             work();
         }
     }
-    std::mutex m_;
+    std::mutex m_, run_m_;
     std::condition_variable cv_, done_;
     std::vector<std::thread> workers_;
     const std::function<void(int)>* fn_ = nullptr;
-    int next_ = 0, total_ = 0, pending_ = 0;
+    int next_ = 0, total_ = 0, pending_ = 0, helpers_ = 0;
     unsigned long long gen_ = 0;
     bool stop_ = false;
 };
@@ -1856,6 +1861,15 @@ int mvsim_simulate_views(mvsim_ctx* ctx, const float* gt_host, const int64_t dim
     MVSIM_CHECK_ARG(n_views >= 0 && n_views <= MVSIM_MAX_VIEWS, "n_views must be in [0, MVSIM_MAX_VIEWS]");
     if (n_views == 0) return MVSIM_OK;
     SyncOnExit sync{ctx};
+    // views of the pipelined entry point that are still in flight own the 16-bit staging this call is about to use: land them first
+    if (ctx->async_ready)
+        for (int q = 0; q < mvsim_ctx::ASYNC_SLOTS; ++q)
+            if (ctx->async_inflight[q]) {
+                MVSIM_HIP(hipEventSynchronize(ctx->ev_d2h[q]));
+                ctx->async_inflight[q] = false;
+                ctx->async_corr_done[ctx->async_ticket[q] % mvsim_ctx::ASYNC_HISTORY] = ctx->async_corr[q];
+                MVSIM_TRY(async_land(ctx, q));
+            }
     const int64_t n = nvox(dim), plane = dim[0] * dim[1];
     // per-view acquisition sizes (the spacing may differ from view to view), 256-byte aligned slots
     std::vector<size_t> off((size_t)n_views + 1, 0), off16((size_t)n_views + 1, 0);
