@@ -1188,6 +1188,7 @@ def main():
     gt512 = gt_bufs[0]                                     # rank 0's phantom (every rank's after a broadcast): the 1024^3 legs up-sample it
     run.close()
     legs = {}
+    legs_error = None
     if multi and args.conv_method == 1 and n <= 512:
         # the other sizes north_star names, on the N > 1 data path: 1024^3 views sharded v % N (`size_1024`) and BASELINE configs[3] as
         # stated -- every 1024^3 view cut into N z slabs (`tiled_1024`).  Every rank takes part; rank 0 reports.  (The legs run at twice
@@ -1217,9 +1218,11 @@ def main():
                     torch.cuda.synchronize()
                 legs[f"tiled_{n2}"] = tiled_leg(env, gt2, n2, leg_steps)
         except Exception as e:
-            if world > 1:
-                raise                                      # a rank that drops out of a collective must end the job, not hang it
-            legs.setdefault(f"size_{n2}", {"failed": repr(e)})
+            # The line of record is complete at this point and must not be lost to a leg: rank 0 still prints it (below), with the
+            # failure in it; with N > 1 the job then ends with a non-zero status (a rank that dropped out of a collective must end
+            # the job, not leave the others waiting).
+            legs_error = f"rank {rank}: {e!r}"
+            legs.setdefault(f"size_{n2}" if f"size_{n2}" not in legs and not args.no_size_1024 else f"tiled_{n2}", {"failed": repr(e)})
         del gt2
     del gt512
     torch.cuda.empty_cache()
@@ -1251,8 +1254,14 @@ def main():
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "Mvoxel/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
+        if legs_error:
+            out["legs_failed"] = legs_error
         print(json.dumps(out), flush=True)
 
+    if legs_error and world > 1:
+        sys.stderr.write(f"bench.py: a leg behind the line of record failed ({legs_error}); ending the job\n")
+        sys.stderr.flush()
+        os._exit(3)                                        # the other ranks may be inside a collective: no orderly teardown
     if world > 1:
         dist.destroy_process_group()
 
