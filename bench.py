@@ -1189,6 +1189,19 @@ def main():
     run.close()
     legs = {}
     legs_error = None
+    watchdog = None
+    if world > 1 and rank == 0:
+        # The legs below are collectives over every rank: a rank that dies inside one leaves the others waiting.  The line of record
+        # exists already; if the legs have not come back after ten minutes, rank 0 prints it without them and ends the job.
+        import threading
+
+        def give_up():
+            out["legs_failed"] = "the legs behind the line of record did not finish within 600 s (a rank lost inside a collective?)"
+            print(json.dumps(out), flush=True)
+            os._exit(4)
+        watchdog = threading.Timer(600.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if multi and args.conv_method == 1 and n <= 512:
         # the other sizes north_star names, on the N > 1 data path: 1024^3 views sharded v % N (`size_1024`) and BASELINE configs[3] as
         # stated -- every 1024^3 view cut into N z slabs (`tiled_1024`).  Every rank takes part; rank 0 reports.  (The legs run at twice
@@ -1224,6 +1237,8 @@ def main():
             legs_error = f"rank {rank}: {e!r}"
             legs.setdefault(f"size_{n2}" if f"size_{n2}" not in legs and not args.no_size_1024 else f"tiled_{n2}", {"failed": repr(e)})
         del gt2
+    if watchdog is not None:
+        watchdog.cancel()
     del gt512
     torch.cuda.empty_cache()
     if bc_ctx is not None:
