@@ -1312,8 +1312,14 @@ int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t 
         return MVSIM_EINVAL;
     }
     const SlabRange slab{(int)za, (int)(zb - za), (int)z0, (int)(z1 - z0)};
+    // a slab that starts at a multiple of the view's spacing convolves along z -- and sends through passes D and E -- only the planes
+    // extractSlices reads, like an untiled compact view (the sum over ALL of the slab's planes comes from the z pass's input rows)
+    ConvTail tail;
+    tail.zstride = (p->inc > 1 && z0 % p->inc == 0) ? p->inc : 1;
+    ctx->slab_z0 = ctx->slab_z1 = -1;
     MVSIM_TRY(custom_fft_convolve_slab(ctx, ctx->vol_b.as<float>(), dim, ctx->psf_dev.as<float>(), kdim, P, slab,
-                                       ctx->vol_a.as<float>(), nullptr));
+                                       ctx->vol_a.as<float>(), &tail));
+    ctx->slab_z0 = z0; ctx->slab_z1 = z1; ctx->slab_zstride = tail.zstride;
     double *partial, *scal;
     MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
     MVSIM_HIP(hipMemcpyAsync(slab_sum, scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1330,7 +1336,9 @@ int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim
     MVSIM_CHECK_ARG(0 <= z0 && z0 < z1 && z1 <= dim[2], "slab must satisfy 0 <= z0 < z1 <= Nz");
     MVSIM_CHECK_ARG(p->inc >= 1, "inc must be >= 1");
     const int64_t plane = dim[0] * dim[1];
-    MVSIM_CHECK_ARG(ctx->vol_a.bytes >= (size_t)(plane * (z1 - z0)) * sizeof(float), "no convolved slab in this context");
+    MVSIM_CHECK_ARG(ctx->slab_z0 == z0 && ctx->slab_z1 == z1 && ctx->vol_a.bytes >= (size_t)(plane * (z1 - z0)) * sizeof(float),
+                    "no convolved slab [z0, z1) in this context (mvsim_view_slab_convolve_dev first)");
+    MVSIM_CHECK_ARG(ctx->slab_zstride == 1 || ctx->slab_zstride == p->inc, "the slab was convolved for another spacing");
     double *partial, *scal;
     MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
     MVSIM_HIP(hipMemcpyAsync(scal, &total_sum, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1339,6 +1347,15 @@ int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim
     const int64_t k0 = (z0 + p->inc - 1) / p->inc, k1 = (z1 + p->inc - 1) / p->inc;     // acquired planes k: z0 <= k*inc < z1
     if (n_planes) *n_planes = k1 - k0;
     if (k1 <= k0) return MVSIM_OK;
+    if (ctx->slab_zstride > 1) {
+        // compact slab: vol_a holds the planes z0 + k * inc alone, in order (z0 is a multiple of inc: plane k0 * inc = z0)
+        const int64_t cdim[3] = {dim[0], dim[1], k1 - k0};
+        const bool noise_c = p->snr >= 0.0f;
+        void* q = nullptr;
+        if (noise_c) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(plane, k1 - k0))); q = ctx->pqueue.p; }
+        return launch_extract(ctx->stream, ctx->vol_a.as<float>(), acq, cdim, 1, true, scal, p->min_value, noise_c, mvsim_poisson_mul((double)p->snr),
+                              p->seed, p->stream, (uint64_t)(z0 * plane), q, ctx->opt.poisson_queue, p->inc);
+    }
     const int64_t first = k0 * p->inc;                      // global index of the first acquired source plane
     const int64_t ldim[3] = {dim[0], dim[1], z1 - first};
     const bool noise = p->snr >= 0.0f;

@@ -259,6 +259,11 @@ struct mvsim_ctx {
     hipEvent_t  ev_lane_fork = nullptr;
     bool        is_lane = false;
 
+    // z-slab tiling: what mvsim_view_slab_convolve_dev left in vol_a for mvsim_view_slab_finish_dev -- the slab's planes [z0, z1), or only
+    // the planes k * slab_zstride of it (compact, slab_zstride > 1: the slab starts at a multiple of the view's spacing)
+    int64_t slab_z0 = -1, slab_z1 = -1;
+    int     slab_zstride = 1;
+
     // RCCL
     void* comm = nullptr;
     void* peer_copy = nullptr;             // broadcast=peer_copy: IPC maps, copy streams (comm.cpp)

@@ -1719,7 +1719,9 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
     const bool zdirect = ctx->opt.zpass == 2 ? false : kz <= 64;
     const bool early = zdirect && ctx->opt.early_sum;             // adjustImage's sum from pass C' instead of pass E
     // with the sum known before passes D and E, they only have to produce the planes extractSlices reads
-    int zstride = (tail && early && !is_slab && tail->zstride > 1) ? tail->zstride : 1;
+    // (a z slab may ask for it too: its first output plane is then a multiple of the stride -- the caller's promise -- so that the planes
+    // k * zstride of the SLAB are planes k' * zstride of the view)
+    int zstride = (tail && early && tail->zstride > 1 && (!is_slab || slab.z_out0 % tail->zstride == 0)) ? tail->zstride : 1;
     // fused tail: pass E adjusts, extracts and samples (needs the sum first, whole rows of float4 groups, aligned outputs)
     long long fblocks = 0;
     unsigned int fsegcap = 0;
