@@ -545,7 +545,7 @@ def small_views_record(mvs, synth, dev_index: int) -> dict:
     (the views stacked: one launch per stage for all of them), wall clock over `reps` datasets, device-resident; the acquisitions of the
     two forms are compared bit for bit."""
     out = {}
-    for name, n, k, inc, nv, reps in (("128^3_psf15_inc1_x8", 128, 15, 1, 8, 30), ("289^3_psf51_inc3_x7", 289, 51, 3, 7, 10), ("256^3_psf31_inc1_x8", 256, 31, 1, 8, 10)):
+    for name, n, k, inc, nv, reps in (("128^3_psf15_inc1_x8", 128, 15, 1, 8, 40), ("289^3_psf51_inc3_x7", 289, 51, 3, 7, 30), ("256^3_psf31_inc1_x8", 256, 31, 1, 8, 20)):
         gt = synth.sphere_phantom(n)
         nzo = (n - 1) // inc + 1
         psfs = [synth.gaussian_psf(k, sigma=(k / 15.0, k / 14.0, k / 5.0 + 0.05 * v)) for v in range(nv)]
@@ -563,7 +563,7 @@ def small_views_record(mvs, synth, dev_index: int) -> dict:
                 c.simulate_views_dev(d_gt, (n, n, n), [p.copy() for p in psfs], params, acq)
 
             def clock(fn):
-                for _ in range(2):
+                for _ in range(3):
                     fn()
                 c.synchronize()
                 t0 = time.perf_counter()

@@ -325,6 +325,102 @@ static void psf_normalise_host(float* psf_host, int64_t n)
     for (int64_t i = 0; i < n; ++i) psf_host[i] = (float)((double)psf_host[i] / sum);
 }
 
+// ---- host side of the 16-bit acquisition transfer ----------------------------------------------------------------------------
+// A 512^3 acquisition is 0.54 GB of float32 that hold small integers (Poisson counts, Tools.java:84): it crosses PCIe as 0.27 GB of
+// uint16 and is widened here, by a few host threads with streaming stores (the destination -- the caller's buffer -- is written once
+// and not read back by us), while the next view's transfer is already running.  Process-wide pool, created on first use.
+namespace {
+class HostPool {
+public:
+    static HostPool& get() { static HostPool p; return p; }
+    // fn(chunk) for chunk = 0 .. chunks-1 on up to `threads` threads (the caller's thread takes part); returns when all are done.
+    // One job at a time: callers on different host threads (one context each) queue up behind each other.
+    void run(int chunks, int threads, const std::function<void(int)>& fn)
+    {
+        if (chunks <= 0) return;
+        std::lock_guard<std::mutex> one_job(run_m_);
+        threads = std::max(1, std::min(threads, chunks));
+        std::unique_lock<std::mutex> lk(m_);
+        while ((int)workers_.size() < threads - 1) {
+            const int id = (int)workers_.size();
+            workers_.emplace_back([this, id] { loop(id); });
+        }
+        fn_ = &fn; next_ = 0; total_ = chunks; pending_ = chunks; helpers_ = threads - 1; gen_ += 1;
+        cv_.notify_all();
+        lk.unlock();
+        work();
+        lk.lock();
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    HostPool() = default;
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void work()
+    {
+        for (;;) {
+            int c;
+            const std::function<void(int)>* f;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!fn_ || next_ >= total_) return;
+                c = next_++; f = fn_;
+            }
+            (*f)(c);                                   // (run() does not return before pending_ is 0, so *f outlives every call)
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop(int id)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && fn_ && next_ < total_ && id < helpers_); });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::mutex m_, run_m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int next_ = 0, total_ = 0, pending_ = 0, helpers_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+
+// dst[i] = (float) src[i], i in [0, n): 8 values per step, streaming stores where the destination is 16-byte aligned
+void widen_u16(const unsigned short* src, float* dst, long long n)
+{
+    long long i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 15) != 0) { dst[i] = (float)src[i]; ++i; }
+    const __m128i zero = _mm_setzero_si128();
+    for (; i + 8 <= n; i += 8) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+        _mm_stream_ps(dst + i, _mm_cvtepi32_ps(_mm_unpacklo_epi16(v, zero)));
+        _mm_stream_ps(dst + i + 4, _mm_cvtepi32_ps(_mm_unpackhi_epi16(v, zero)));
+    }
+    for (; i < n; ++i) dst[i] = (float)src[i];
+    _mm_sfence();
+}
+}  // namespace
+
+static int host_threads_of(const mvsim_ctx* ctx)
+{
+    if (ctx->opt.host_threads > 0) return ctx->opt.host_threads;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+}
+
 // Normalise the PSF on the host exactly as Tools.normImage does, in place (Q5), then place it in device memory.
 static int psf_prepare(mvsim_ctx* ctx, float* psf_host, const int64_t kdim[3], const int64_t dim[3])
 {
@@ -1105,9 +1201,13 @@ static int views_enqueue_batched(mvsim_ctx* ctx, const float* gt, const int64_t 
         if (noise) poisson_queue_split(ctx->pqueue.as<char>() + (size_t)v * qbytes, &e.queue, &e.qcount);
         e.k0 = (uint32_t)params[v].seed; e.k1 = (uint32_t)(params[v].seed >> 32); e.stream = params[v].stream; e.pad = 0;
         vec_all = vec_all && ((reinterpret_cast<uintptr_t>(e.in) | reinterpret_cast<uintptr_t>(e.out)) % 16 == 0);
+    }
+    // Tools.normImage of the V PSFs (in place, Q5) and their copy into the upload block: one host thread per view -- a 51^3 stack is 0.13 ms of
+    // summation and division, and nothing reaches the GPU before the last of them is done
+    HostPool::get().run(V, host_threads_of(ctx), [&](int v) {
         psf_normalise_host(psf_host[v], k3);
         std::memcpy(hp + off_p + (size_t)v * k3 * sizeof(float), psf_host[v], (size_t)k3 * sizeof(float));
-    }
+    });
     MVSIM_HIP(hipMemcpyAsync(dp, hp, up_bytes, hipMemcpyHostToDevice, ctx->stream));
     MVSIM_HIP(hipEventRecord(ctx->pinned.ev[slot], ctx->stream));
     ctx->pinned.busy[slot] = true;
@@ -1593,102 +1693,6 @@ int mvsim_splat_spheres(mvsim_ctx* ctx, float* img, const int64_t dim[3], const 
     MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
     MVSIM_TRY(splat_spheres_dev(ctx, ctx->vol_a.as<float>(), dim, spheres, n));
     return down(ctx, img, ctx->vol_a.p, bytes);
-}
-
-// ---- host side of the 16-bit acquisition transfer ----------------------------------------------------------------------------
-// A 512^3 acquisition is 0.54 GB of float32 that hold small integers (Poisson counts, Tools.java:84): it crosses PCIe as 0.27 GB of
-// uint16 and is widened here, by a few host threads with streaming stores (the destination -- the caller's buffer -- is written once
-// and not read back by us), while the next view's transfer is already running.  Process-wide pool, created on first use.
-namespace {
-class HostPool {
-public:
-    static HostPool& get() { static HostPool p; return p; }
-    // fn(chunk) for chunk = 0 .. chunks-1 on up to `threads` threads (the caller's thread takes part); returns when all are done.
-    // One job at a time: callers on different host threads (one context each) queue up behind each other.
-    void run(int chunks, int threads, const std::function<void(int)>& fn)
-    {
-        if (chunks <= 0) return;
-        std::lock_guard<std::mutex> one_job(run_m_);
-        threads = std::max(1, std::min(threads, chunks));
-        std::unique_lock<std::mutex> lk(m_);
-        while ((int)workers_.size() < threads - 1) {
-            const int id = (int)workers_.size();
-            workers_.emplace_back([this, id] { loop(id); });
-        }
-        fn_ = &fn; next_ = 0; total_ = chunks; pending_ = chunks; helpers_ = threads - 1; gen_ += 1;
-        cv_.notify_all();
-        lk.unlock();
-        work();
-        lk.lock();
-        done_.wait(lk, [this] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-private:
-    HostPool() = default;
-    ~HostPool()
-    {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        cv_.notify_all();
-        for (auto& t : workers_) t.join();
-    }
-    void work()
-    {
-        for (;;) {
-            int c;
-            const std::function<void(int)>* f;
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                if (!fn_ || next_ >= total_) return;
-                c = next_++; f = fn_;
-            }
-            (*f)(c);                                   // (run() does not return before pending_ is 0, so *f outlives every call)
-            std::lock_guard<std::mutex> lk(m_);
-            if (--pending_ == 0) done_.notify_all();
-        }
-    }
-    void loop(int id)
-    {
-        unsigned long long seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && fn_ && next_ < total_ && id < helpers_); });
-                if (stop_) return;
-                seen = gen_;
-            }
-            work();
-        }
-    }
-    std::mutex m_, run_m_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> workers_;
-    const std::function<void(int)>* fn_ = nullptr;
-    int next_ = 0, total_ = 0, pending_ = 0, helpers_ = 0;
-    unsigned long long gen_ = 0;
-    bool stop_ = false;
-};
-
-// dst[i] = (float) src[i], i in [0, n): 8 values per step, streaming stores where the destination is 16-byte aligned
-void widen_u16(const unsigned short* src, float* dst, long long n)
-{
-    long long i = 0;
-    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 15) != 0) { dst[i] = (float)src[i]; ++i; }
-    const __m128i zero = _mm_setzero_si128();
-    for (; i + 8 <= n; i += 8) {
-        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
-        _mm_stream_ps(dst + i, _mm_cvtepi32_ps(_mm_unpacklo_epi16(v, zero)));
-        _mm_stream_ps(dst + i + 4, _mm_cvtepi32_ps(_mm_unpackhi_epi16(v, zero)));
-    }
-    for (; i < n; ++i) dst[i] = (float)src[i];
-    _mm_sfence();
-}
-}  // namespace
-
-static int host_threads_of(const mvsim_ctx* ctx)
-{
-    if (ctx->opt.host_threads > 0) return ctx->opt.host_threads;
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
 }
 
 // the slot's view has landed (ev_d2h synchronised): 16-bit counts become the caller's float32 acquisition -- or, when the device
