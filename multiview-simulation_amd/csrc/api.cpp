@@ -536,7 +536,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     view_graphs_release(ctx);
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->psf_dev.release(); ctx->view_tab.release(); ctx->stencil_psf.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
+    ctx->psf_dev.release(); ctx->view_tab.release(); ctx->sync_u16.release(); ctx->stencil_psf.release(); ctx->partials.release(); ctx->partials_e.release(); ctx->pqueue.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     ctx->pinned.release_all();
     if (ctx->ev_created)
@@ -545,6 +545,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamDestroy(ctx->tail_stream); (void)hipEventDestroy(ctx->ev_tail_fork); (void)hipEventDestroy(ctx->ev_tail); }
     if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     if (ctx->empty_hint) (void)hipHostFree(ctx->empty_hint);
+    if (ctx->sync_u16_host) (void)hipHostFree(ctx->sync_u16_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MVSIM_OK;
@@ -589,7 +590,7 @@ int mvsim_release_caches(mvsim_ctx* ctx)
     view_graphs_release(ctx);                             // captured launches point into the workspaces released below
     fft_release(ctx);
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
-    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->view_tab.release(); ctx->stencil_psf.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
+    ctx->pqueue.release(); ctx->psf_dev.release(); ctx->view_tab.release(); ctx->sync_u16.release(); ctx->stencil_psf.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
     return MVSIM_OK;
 }
@@ -1483,6 +1484,39 @@ static int down(mvsim_ctx* ctx, float* h, const void* d, size_t bytes)
     return MVSIM_OK;
 }
 
+// Download of an acquisition that holds Poisson COUNTS (sampled: snr >= 0; Tools.java:84 stores them as floats): packed to uint16 on
+// the device, half the bytes over PCIe, widened into the caller's buffer by the host threads -- or float32 after all when a value does
+// not survive the round trip (the device says so).  Synchronous, like down().  Small outputs are not worth the extra launch.
+static int down_counts(mvsim_ctx* ctx, float* h, const float* d, int64_t n, bool sampled)
+{
+    if (!sampled || ctx->opt.acq_u16 == 0 || n < ((int64_t)1 << 20) || (reinterpret_cast<uintptr_t>(d) & 15) != 0)
+        return down(ctx, h, d, (size_t)n * sizeof(float));
+    const size_t body = ((size_t)n * sizeof(unsigned short) + 255) & ~(size_t)255;
+    MVSIM_TRY(ctx->sync_u16.reserve(body + 256));
+    if (ctx->sync_u16_host_bytes < body + 256) {
+        if (ctx->sync_u16_host) { (void)hipHostFree(ctx->sync_u16_host); ctx->sync_u16_host = nullptr; ctx->sync_u16_host_bytes = 0; }
+        MVSIM_HIP(hipHostMalloc(&ctx->sync_u16_host, body + 256, hipHostMallocDefault));
+        ctx->sync_u16_host_bytes = body + 256;
+    }
+    unsigned int* flag = reinterpret_cast<unsigned int*>(ctx->sync_u16.as<char>() + body);
+    MVSIM_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned int), ctx->stream));
+    MVSIM_TRY(launch_pack_u16(ctx->stream, d, ctx->sync_u16.as<unsigned short>(), n, flag));
+    MVSIM_HIP(hipMemcpyAsync(ctx->sync_u16_host, ctx->sync_u16.p, body + sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    MVSIM_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->u16_views += 1;
+    if (*reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(ctx->sync_u16_host) + body) != 0u) {
+        ctx->u16_fallbacks += 1;
+        return down(ctx, h, d, (size_t)n * sizeof(float));
+    }
+    const unsigned short* src = reinterpret_cast<const unsigned short*>(ctx->sync_u16_host);
+    const long long chunk = (long long)1 << 20;
+    HostPool::get().run((int)((n + chunk - 1) / chunk), host_threads_of(ctx), [&](int c) {
+        const long long a = (long long)c * chunk, b = std::min<long long>(n, a + chunk);
+        widen_u16(src + a, h + a, b - a);
+    });
+    return MVSIM_OK;
+}
+
 int mvsim_rotate_around_axis(mvsim_ctx* ctx, const float* in, const int64_t dim[3], int axis, int degrees, float* out)
 {
     MVSIM_TRY(set_device(ctx));
@@ -1555,7 +1589,7 @@ int mvsim_extract_slices(mvsim_ctx* ctx, const float* in, const int64_t dim[3], 
     MVSIM_TRY(up(ctx, ctx->vol_a, in, bytes));
     MVSIM_TRY(ctx->out_buf.reserve(obytes));
     MVSIM_TRY(mvsim_extract_slices_dev(ctx, ctx->vol_a.as<float>(), dim, inc, snr, seed, stream, ctx->out_buf.as<float>()));
-    return down(ctx, out, ctx->out_buf.p, obytes);
+    return down_counts(ctx, out, ctx->out_buf.as<float>(), (int64_t)(obytes / sizeof(float)), snr >= 0.0f);
 }
 
 int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr, uint64_t seed, uint32_t stream,
@@ -1572,7 +1606,7 @@ int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr, uin
     MVSIM_TRY(launch_extract(ctx->stream, ctx->vol_a.as<float>(), ctx->out_buf.as<float>(), dim, 1, false, nullptr,
                              0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset, ctx->pqueue.p, ctx->opt.poisson_queue));
     ev_end(ctx, ST_EXTRACT);
-    return down(ctx, img, ctx->out_buf.p, bytes);
+    return down_counts(ctx, img, ctx->out_buf.as<float>(), n, true);
 }
 
 int mvsim_draw_spheres_dev(mvsim_ctx* ctx, float* img, const int64_t dim[3], double min_value, double max_value,
@@ -1671,7 +1705,7 @@ int mvsim_simulate_view(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], f
     if (rc == MVSIM_OK && o->rot) rc = down(ctx, o->rot, dev.rot, vbytes);
     if (rc == MVSIM_OK && o->att) rc = down(ctx, o->att, dev.att, vbytes);
     if (rc == MVSIM_OK && o->con) rc = down(ctx, o->con, dev.con, vbytes);
-    if (rc == MVSIM_OK) rc = down(ctx, o->acq, dev.acq, obytes);
+    if (rc == MVSIM_OK) rc = down_counts(ctx, o->acq, dev.acq, (int64_t)(obytes / sizeof(float)), p->snr >= 0.0f);
     (void)hipStreamSynchronize(ctx->stream);
     return rc;
 }

@@ -230,6 +230,9 @@ struct mvsim_ctx {
     float*     async_out_acq[ASYNC_SLOTS] = {};   // the caller's acquisition buffer of the slot's view
     long long  async_out_n[ASYNC_SLOTS] = {};
     long long  u16_views = 0, u16_fallbacks = 0;  // statistics (mvsim_get_transfer_stats)
+    mvsim::DevBuf sync_u16;                       // the same transfer for the synchronous host-buffer entry points (down_counts)
+    void*      sync_u16_host = nullptr;
+    size_t     sync_u16_host_bytes = 0;
     hipEvent_t ev_h2d[ASYNC_SLOTS] = {}, ev_compute[ASYNC_SLOTS] = {}, ev_d2h[ASYNC_SLOTS] = {};
     bool       async_inflight[ASYNC_SLOTS] = {};
     long long  async_ticket[ASYNC_SLOTS] = {};
@@ -274,7 +277,7 @@ inline mvsim_ctx::mvsim_ctx()
 {
     for (mvsim::DevBuf* b : {&vol_a, &vol_b, &vol_c, &out_buf, &psf_dev, &stencil_psf, &fft_real, &fft_spec_img, &fft_spec_psf, &fft_work,
                              &pqueue, &view_tab, &sphere_list, &weight_img, &plane_flags, &host_gt, &host_rot, &host_att, &host_con, &partials, &partials_e, &cfft_f, &cfft_g,
-                             &cfft_g1, &cfft_g2, &partials_z, &async_gt[0], &async_gt[1], &async_acq[0], &async_acq[1], &async_u16[0], &async_u16[1]})
+                             &cfft_g1, &cfft_g2, &partials_z, &async_gt[0], &async_gt[1], &async_acq[0], &async_acq[1], &async_u16[0], &async_u16[1], &sync_u16})
         b->epoch = &alloc_epoch;
 }
 
