@@ -118,10 +118,13 @@ def parse_args():
     ap.add_argument("--collective", choices=("auto", "mvsim", "torch"), default="auto",
                     help="who broadcasts the ground truth: the C ABI's RCCL collective (default with the nccl backend) or "
                          "torch.distributed (gloo rehearsals: RCCL cannot place two ranks on one GPU)")
-    ap.add_argument("--broadcast", choices=("scatter_allgather", "ring", "peer_copy"), default="scatter_allgather",
+    ap.add_argument("--broadcast", choices=("scatter_allgather", "ring", "peer_copy", "pipelined"), default="scatter_allgather",
                     help="form of the ground-truth broadcast in the C ABI: RCCL scatter + all-gather over all links (default), one RCCL "
-                         "ring broadcast, or the same scatter + all-gather as copy-engine transfers between IPC-mapped buffers "
-                         "(peer_copy: no CUs taken from the views; two 16-byte all-reduces per broadcast remain as barriers)")
+                         "ring broadcast, the same scatter + all-gather as copy-engine transfers between IPC-mapped buffers "
+                         "(peer_copy: no CUs taken from the views; two 16-byte all-reduces per broadcast remain as barriers), or the "
+                         "pipelined form (the root scatters the whole volume as N - 1 chunks while the peers all-gather the pieces "
+                         "that have arrived: ~S / ((N - 1) b) instead of 2 S / (N b); its schedule is checked on the CPU, the form has "
+                         "never run with more than one rank)")
     ap.add_argument("--serial-broadcast", action="store_true",
                     help="N > 1: broadcast the ground truth at the start of each step instead of one step ahead")
     return ap.parse_args()

@@ -25,8 +25,19 @@ import numpy as np
 from . import _lib
 from ._lib import MvsimError, MvsimNoDeviceError, Sphere, Timings, ViewOutputs, ViewParams  # noqa: F401
 
-__all__ = ["Context", "Group", "JavaRandom", "SimulateMultiViewDataset", "Tools", "default_context", "MvsimError",
+__all__ = ["Context", "Group", "JavaRandom", "SimulateMultiViewDataset", "Tools", "broadcast_plan", "default_context", "MvsimError",
            "MvsimNoDeviceError", "ViewParams", "shard_views", "version"]
+
+
+def broadcast_plan(nranks: int, rank: int, root: int, count: int, pieces: int = 8):
+    """The schedule of the pipelined ground-truth broadcast (mvsim_comm_broadcast_plan; host only): a list of
+    (stage, 'send' | 'recv', peer, first float, floats) in the order the rank issues them."""
+    L = _lib.load()
+    n = C.c_int(0)
+    _lib.check(L.mvsim_comm_broadcast_plan(nranks, rank, root, count, pieces, None, 0, C.byref(n)))
+    ops = (_lib.BcastOp * max(1, n.value))()
+    _lib.check(L.mvsim_comm_broadcast_plan(nranks, rank, root, count, pieces, ops, n.value, C.byref(n)))
+    return [(o.stage, "send" if o.kind == 0 else "recv", o.peer, o.first, o.count) for o in ops[: n.value]]
 
 
 def version() -> str:

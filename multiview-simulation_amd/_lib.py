@@ -32,6 +32,10 @@ class ViewParams(C.Structure):
     ]
 
 
+class BcastOp(C.Structure):
+    _fields_ = [("stage", C.c_int32), ("kind", C.c_int32), ("peer", C.c_int32), ("pad", C.c_int32), ("first", C.c_int64), ("count", C.c_int64)]
+
+
 class ViewOutputs(C.Structure):
     _fields_ = [("rot", C.c_void_p), ("att", C.c_void_p), ("con", C.c_void_p), ("acq", C.c_void_p)]
 
@@ -136,6 +140,7 @@ SIGNATURES = {
     "mvsim_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "mvsim_comm_library_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "mvsim_comm_broadcast_volume": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "mvsim_comm_broadcast_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, C.POINTER(C.c_int)]),
     "mvsim_comm_register_volume": (C.c_int, [_vp, _vp, C.c_int64]),
     "mvsim_comm_unregister_volume": (C.c_int, [_vp, _vp]),
     "mvsim_comm_allreduce_sum": (C.c_int, [_vp, _vp, C.c_int64]),

@@ -104,9 +104,10 @@ int parse_option(Options& o, const char* name, const char* value)
     }
     if (n == "graph") { bool g = false; const int rc = flag(&g); o.graph = g ? 1 : 0; return rc; }
     if (n == "broadcast") {
-        if (v == "scatter_allgather" || v == "auto") { o.bcast_ring = false; o.bcast_peer_copy = false; }
-        else if (v == "ring") { o.bcast_ring = true; o.bcast_peer_copy = false; }
-        else if (v == "peer_copy") { o.bcast_ring = false; o.bcast_peer_copy = true; }
+        if (v == "scatter_allgather" || v == "auto") { o.bcast_ring = false; o.bcast_peer_copy = false; o.bcast_pipelined = false; }
+        else if (v == "ring") { o.bcast_ring = true; o.bcast_peer_copy = false; o.bcast_pipelined = false; }
+        else if (v == "peer_copy") { o.bcast_ring = false; o.bcast_peer_copy = true; o.bcast_pipelined = false; }
+        else if (v == "pipelined") { o.bcast_ring = false; o.bcast_peer_copy = false; o.bcast_pipelined = true; }
         else return MVSIM_EINVAL;
         return MVSIM_OK;
     }

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -273,6 +274,87 @@ static int bcast_peer_copy(mvsim_ctx* ctx, float* vol, int64_t count, int root)
     return MVSIM_OK;
 }
 
+// ---- broadcast=pipelined -------------------------------------------------------------------------------------------
+// The schedule (mvsim_comm_broadcast_plan, include/mvsim.h).  Peers = the ranks other than the root, peer index j = (rank - root - 1) mod N.
+// The volume is cut into N - 1 chunks of whole 64-byte units (chunk j belongs to peer j), every chunk into `pieces` pieces.
+//   stage s < pieces:   root -> peer j: piece s of chunk j                       (the root's N - 1 outbound links)
+//   stage s >= 1:       peer j -> every other peer: piece s - 1 of chunk j       (the peer <-> peer links; received in stage s - 1)
+//   last stage + 1:     the floats that do not divide into aligned chunks, root -> every peer
+// A rank issues the ops of one stage inside ONE ncclGroupStart / ncclGroupEnd, so that the root's sends of piece s and the peers' exchange of
+// piece s - 1 run at the same time; stages follow each other in stream order, which is what orders a piece's arrival before its forwarding.
+static void bcast_plan(int n, int rank, int root, int64_t count, int pieces, std::vector<mvsim_bcast_op>& ops)
+{
+    ops.clear();
+    if (n < 2 || count <= 0) return;
+    const int np = n - 1;
+    const int64_t chunk = (count / np) & ~(int64_t)15;
+    pieces = chunk == 0 ? 0 : std::max(1, std::min<int>(pieces, (int)std::min<int64_t>(chunk / 16, 64)));
+    auto piece_first = [&](int s) { return ((chunk / 16) * s / pieces) * 16; };     // whole 64-byte units per piece
+    auto peer_rank = [&](int j) { return (root + 1 + j) % n; };
+    const bool is_root = rank == root;
+    const int me = is_root ? -1 : ((rank - root - 1) % n + n) % n;
+    for (int s = 0; s <= pieces && pieces > 0; ++s) {
+        if (s < pieces) {
+            const int64_t f = piece_first(s), len = piece_first(s + 1) - f;
+            if (is_root) { for (int j = 0; j < np; ++j) ops.push_back(mvsim_bcast_op{s, 0, peer_rank(j), 0, (int64_t)j * chunk + f, len}); }
+            else ops.push_back(mvsim_bcast_op{s, 1, root, 0, (int64_t)me * chunk + f, len});
+        }
+        if (s >= 1 && !is_root) {
+            const int64_t f = piece_first(s - 1), len = piece_first(s) - f;
+            for (int j = 0; j < np; ++j) {
+                if (j == me) continue;
+                ops.push_back(mvsim_bcast_op{s, 0, peer_rank(j), 0, (int64_t)me * chunk + f, len});
+                ops.push_back(mvsim_bcast_op{s, 1, peer_rank(j), 0, (int64_t)j * chunk + f, len});
+            }
+        }
+    }
+    const int64_t tail = count - chunk * np;
+    if (tail > 0) {
+        const int s = pieces > 0 ? pieces + 1 : 0;
+        if (is_root) { for (int j = 0; j < np; ++j) ops.push_back(mvsim_bcast_op{s, 0, peer_rank(j), 0, chunk * np, tail}); }
+        else ops.push_back(mvsim_bcast_op{s, 1, root, 0, chunk * np, tail});
+    }
+}
+
+int mvsim_comm_broadcast_plan(int nranks, int rank, int root, int64_t count, int pieces, mvsim_bcast_op* ops, int capacity, int* n_ops)
+{
+    MVSIM_CHECK_ARG(nranks >= 1 && rank >= 0 && rank < nranks && root >= 0 && root < nranks && count >= 0 && pieces >= 1 && n_ops,
+                    "broadcast_plan: bad rank / root / count / pieces or null n_ops");
+    std::vector<mvsim_bcast_op> v;
+    bcast_plan(nranks, rank, root, count, pieces, v);
+    *n_ops = (int)v.size();
+    if (!ops) return MVSIM_OK;
+    MVSIM_CHECK_ARG(capacity >= (int)v.size(), "broadcast_plan: capacity too small");
+    std::memcpy(ops, v.data(), v.size() * sizeof(mvsim_bcast_op));
+    return MVSIM_OK;
+}
+
+constexpr int BCAST_PIECES = 8;
+
+static int bcast_pipelined(mvsim_ctx* ctx, float* vol, int64_t count, int root)
+{
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    std::vector<mvsim_bcast_op> ops;
+    bcast_plan(ctx->nranks, ctx->rank, root, count, BCAST_PIECES, ops);
+    size_t i = 0;
+    while (i < ops.size()) {
+        const int stage = ops[i].stage;
+        ncclResult_t bad = ncclSuccess;
+        MVSIM_NCCL(ncclGroupStart());
+        for (; i < ops.size() && ops[i].stage == stage && bad == ncclSuccess; ++i) {
+            const mvsim_bcast_op& o = ops[i];
+            bad = o.kind == 0 ? ncclSend(vol + o.first, (size_t)o.count, ncclFloat, o.peer, comm, ctx->stream)
+                              : ncclRecv(vol + o.first, (size_t)o.count, ncclFloat, o.peer, comm, ctx->stream);
+        }
+        const ncclResult_t end = ncclGroupEnd();
+        if (bad != ncclSuccess || end != ncclSuccess) {
+            mvsim::set_error("pipelined broadcast, stage %d: %s", stage, ncclGetErrorString(bad != ncclSuccess ? bad : end));
+            return MVSIM_ERCCL;
+        }
+    }
+    return MVSIM_OK;
+}
+
 // Broadcast of the ground truth.  xGMI is point-to-point (7 links per GPU): a ring/chain broadcast moves the whole
 // volume over ONE link of every GPU (0.54 GB at 512^3: ~3.5 ms, longer than a 2.4 ms view), so the default form is
 //   phase 0  scatter: root sends chunk r (count / nranks floats) to rank r -- nranks-1 concurrent sends, one per link
@@ -326,6 +408,7 @@ int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, i
     MVSIM_TRY(mvsim::join_tail(ctx));
     if (count == 0) return MVSIM_OK;
     if (ctx->opt.bcast_peer_copy) return bcast_peer_copy(ctx, vol_dev, count, root);
+    if (ctx->opt.bcast_pipelined) return bcast_pipelined(ctx, vol_dev, count, root);
     for (int phase = 0; phase < 3; ++phase) MVSIM_TRY(bcast_phase(ctx, vol_dev, count, root, phase));
     return MVSIM_OK;
 }

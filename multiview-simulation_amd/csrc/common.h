@@ -142,6 +142,8 @@ struct Options {
                                        // views_enqueue_batched): 0 never, 1 whenever the views allow it, 2 auto (views of <= 2^26 voxels)
     bool    bcast_ring = false;        // ground-truth broadcast as one ncclBroadcast instead of scatter + all-gather
     bool    bcast_peer_copy = false;   // ... or as copy-engine transfers between IPC-mapped buffers (comm.cpp: bcast_peer_copy)
+    bool    bcast_pipelined = false;   // ... or the pipelined form: the root scatters the WHOLE volume as nranks - 1 chunks while the peers all-gather
+                                       // the pieces that have arrived among themselves (mvsim_comm_broadcast_plan; comm.cpp: bcast_pipelined)
     int64_t fft_pad[3] = {0, 0, 0};    // explicit padded sizes on the rocFFT path (0: choose)
     bool    skip_empty = true;         // convolution passes skip planes the fused rotate kernel found empty (exact; option for A/B runs)
 };

@@ -32,7 +32,7 @@ def main():
         n = 1_000_003
         truth = np.random.default_rng(17).random(n, dtype=np.float32)
         d = c.dev_alloc(n * 4)
-        for form in ("scatter_allgather", "ring", "peer_copy", "peer_copy"):
+        for form in ("scatter_allgather", "ring", "peer_copy", "peer_copy", "pipelined"):
             c.set_option("broadcast", form)
             if form == "peer_copy":
                 c.comm_register_volume(d, n)            # collective; the second round replaces the first registration

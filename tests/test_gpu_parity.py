@@ -1161,6 +1161,10 @@ def test_rccl_entry_points_single_rank(mvs, synth):
             with pytest.raises(ValueError, match="not registered"):
                 c.comm_broadcast_volume(d3, vol.size, 0)
             c.dev_free(d3)
+            c.set_option("broadcast", "pipelined")                        # one rank: an empty schedule (tests/test_host_logic.py walks the real ones)
+            c.comm_broadcast_volume(d, vol.size, 0)
+            c.synchronize()
+            assert np.array_equal(c.download(d, vol.shape), vol)
             c.set_option("broadcast", "scatter_allgather")
             c.comm_allreduce_sum(d, vol.size)
             c.synchronize()
@@ -1782,7 +1786,7 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
     import subprocess
     import sys
     bench = os.path.join(ROOT, "bench.py")
-    for extra in (["--broadcast", "scatter_allgather"], ["--broadcast", "ring", "--serial"], ["--broadcast", "peer_copy"]):
+    for extra in (["--broadcast", "scatter_allgather"], ["--broadcast", "ring", "--serial"], ["--broadcast", "peer_copy"], ["--broadcast", "pipelined"]):
         r = subprocess.run([sys.executable, bench, "--rehearse-multi", "--size", "256", "--psf", "15", "--steps", "2", "--warmup", "1",
                             "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -383,3 +383,35 @@ def test_committed_pmc_traffic_belongs_to_this_build():
         pytest.skip(f"{os.path.relpath(path, ROOT)} was collected on kernel sources {rec['kernel_sha']}, this tree is {build.source_sha()}: "
                     "bench.py will print roofline.traffic = null until `bash tools/profile_all.sh TAG` has been run again")
     assert rec["views_profiled"] >= 1 and rec["per_view_bytes"]["convolve"] > 0
+
+
+@pytest.mark.parametrize("nranks,root,count,pieces", [(2, 0, 1000, 8), (2, 1, 100003, 3), (3, 0, 100003, 8), (4, 2, 134217728, 8),
+                                                        (8, 0, 134217728, 8), (8, 5, 1 << 20, 4), (8, 0, 100, 8), (5, 4, 17, 8), (8, 3, 4097, 1)])
+def test_pipelined_broadcast_plan_is_complete_and_matched(mvs, nranks, root, count, pieces):
+    """mvsim_comm_broadcast_plan (the schedule of option broadcast=pipelined, host only): simulated over every rank of the job --
+    in each stage every send has exactly one matching receive at its peer (same range) and vice versa (a group of ncclSend /
+    ncclRecv cannot deadlock then), a rank only sends floats it already holds at the START of the stage (stages follow each other in
+    stream order; inside a stage nothing is ordered), and after the last stage every rank holds every float.  The root's outbound
+    traffic is the volume once per peer-chunk, not twice."""
+    plans = [mvs.broadcast_plan(nranks, r, root, count, pieces) for r in range(nranks)]
+    have = [np.zeros(count, bool) for _ in range(nranks)]
+    have[root][:] = True
+    nstage = 1 + max([op[0] for p in plans for op in p], default=-1)
+    sent_by_root = 0
+    for st in range(nstage):
+        sends = sorted((r, op[2], op[3], op[4]) for r, p in enumerate(plans) for op in p if op[0] == st and op[1] == "send")
+        recvs = sorted((op[2], r, op[3], op[4]) for r, p in enumerate(plans) for op in p if op[0] == st and op[1] == "recv")
+        assert sends == recvs, (st, sends[:3], recvs[:3])                       # (from, to, first, count) on both sides
+        assert len(set((a, b) for a, b, _, _ in sends)) == len(sends)          # at most one transfer per ordered pair and stage
+        for a, b, first, n in sends:
+            assert n > 0 and first >= 0 and first + n <= count and a != b
+            assert have[a][first:first + n].all(), (st, a, b, first, n)        # the source holds what it sends before the stage starts
+        for a, b, first, n in sends:
+            have[b][first:first + n] = True
+            sent_by_root += n if a == root else 0
+        for p in plans:                                                         # stages are issued in order
+            stages = [op[0] for op in p]
+            assert stages == sorted(stages)
+    assert all(h.all() for h in have)
+    assert sent_by_root == count * (1 if nranks > 1 else 0) + (count - (count // (nranks - 1) & ~15) * (nranks - 1)) * (nranks - 2 if nranks > 1 else 0)
+
