@@ -1,8 +1,9 @@
 // JNI shim: net.preibisch.simulation.gpu.MvsimNative  ->  C ABI of libmvsim.so (include/mvsim.h).
 //
-// SOURCE ONLY in this repository (the build image has no JDK / jni.h): this file has never been run, and compiled only with
-// -fsyntax-only against the hand-written jni.h subset of tests/jni_stub (tests/test_host_logic.py) -- a syntax and type check
-// of this file against include/mvsim.h, nothing more.
+// SOURCE ONLY in this repository (the build image has no JDK / jni.h): this file has never been loaded by a JVM.  What runs here:
+// a syntax and type check against the hand-written jni.h subset of tests/jni_stub (tests/test_host_logic.py), and the functions
+// below EXECUTED against a fake JNIEnv (tests/jni_fake, tests/test_jni_shim.py): the capacity checks, the exception mapping and,
+// on the GPU, results bit-identical to the same calls through the C ABI.  Neither says anything about a real JVM.
 // Build on a host with a JDK:
 //   g++ -shared -fPIC -std=c++17 -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include
 //       mvsim_jni.cpp -L../../multiview-simulation_amd -lmvsim -Wl,-rpath,'$ORIGIN' -o libmvsim_jni.so
@@ -59,6 +60,7 @@ struct Dim {
 // optional == true: a null buffer is allowed and gives nullptr without an exception.
 float* fptr(JNIEnv* env, jobject buf, int64_t need, const char* what, bool optional = false)
 {
+    if (env->ExceptionCheck()) return nullptr;              // an earlier argument already failed: no JNI call with that pending
     if (!buf) {
         if (!optional) throw_new(env, "java/lang/IllegalArgumentException", what);
         return nullptr;

@@ -1,9 +1,9 @@
 /*
  * NOT the JDK's jni.h.  A hand-written subset of the JNI C++ surface -- the typedefs and the JNIEnv member functions
  * java/jni/mvsim_jni.cpp uses, with the signatures of the JNI specification (chapter 4, "JNI Functions") -- so that the
- * shim can be syntax- and type-checked (g++ -fsyntax-only) in an image without a JDK.  It declares, it defines nothing:
- * no object can be linked or run against it, and passing this check pins nothing about the behaviour of the shim on a
- * real JVM.  The build image has no JDK; on a host that has one, the JDK's own headers are used.
+ * shim can be syntax- and type-checked (g++ -fsyntax-only) in an image without a JDK.  It declares, it defines nothing
+ * (tests/jni_fake/fake_jni.cpp defines the members over a fake object table, for tests/test_jni_shim.py); passing either
+ * check pins nothing about the behaviour of the shim on a real JVM.  The build image has no JDK; on a host that has one, the JDK's own headers are used.
  */
 #ifndef MVSIM_TEST_JNI_STUB_H
 #define MVSIM_TEST_JNI_STUB_H
