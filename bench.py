@@ -34,6 +34,7 @@ Rank 0 prints ONE JSON line (schema in the task contract) including
                   as_reference (the reference's threading) and all_cores
   value_dense  -- top level, beside `value`: the same workload without a single empty voxel (= no_empty_space.value)
   no_empty_space -- N = 1: the serial leg again on the phantom + 1e-6 (nothing for the exact zero-row fast paths to skip)
+  poisson_queue -- the sampler's work queue after the timed steps: GiB held (and at full size), what a view queued, what full segments refused
   end_to_end   -- N = 1: the same views with page-locked HOST buffers in and out (PCIe-inclusive; never `value`); acquisitions cross as
                   uint16 counts, the float32 transfer is timed beside it
   size_1024    -- N = 1: one 1024^3 view, same stage timings and roofline keys, its own PMC traffic record.  N > 1: `--views-total` 1024^3
@@ -1059,6 +1060,7 @@ def main():
         set_overlap(True)
 
     plane_stats = ctx.plane_stats() if (rank == 0 and my_views) else None      # of the leg `roofline` is read from (before the dense leg)
+    queue_stats = ctx.queue_stats() if (rank == 0 and my_views and args.snr >= 0) else None     # the sampler's work queue after the timed steps
     no_empty = None
     if rank == 0 and not multi and my_views and args.conv_method == 1 and not args.no_dense_leg:
         # The rotate + attenuate + x-transform kernel skips the fp64 blends and the transforms of rows that hold no non-zero voxel
@@ -1134,6 +1136,13 @@ def main():
             out["serial"] = serial_leg
         if no_empty:
             out["no_empty_space"] = no_empty
+        if queue_stats:
+            # the Poisson work queue of this context: per-block segments sized for a share of the block's voxels (automatic: from 5
+            # sixteenths up, growing to what the views need; every voxel would be 16 B per acquired voxel: 2.25 GiB here), what the last view queued, and
+            # what its full segments refused (sampled in place by a third kernel: same counts, slower -- zero on this workload)
+            q = queue_stats
+            out["poisson_queue"] = {"gib": round(q["bytes"] / 2 ** 30, 3), "segment_items": q["segment_items"], "queued_share_of_voxels": round((q["bright"] + q["inversion"]) / (n * n * nzo), 4),
+                                    "fullest_block_pending": q["fullest_block"], "refused_voxels": q["refused"]}
         if stage:
             kernel_sha = build.source_sha()
             traffic, note = load_traffic(n, args.psf, args.inc, len(ctxs), args.conv_method, kernel_sha)

@@ -326,6 +326,16 @@ int mvsim_stencil_geometry(const int64_t kdim[3], int64_t geometry[5]);
  * read them), planes of the z pass's output that are empty (passes D and E skip them)}.  Read from a page-locked word the device
  * writes, without synchronising: call after the view has completed.  All zero when no view has carried flags yet. */
 int mvsim_get_plane_stats(mvsim_ctx* ctx, int64_t stats[3]);
+/* The work queue of the Poisson sampler (Tools.java:73-86 is one sample per voxel; here the voxels whose sample needs the divergent fp64
+ * code wait in per-block segments for a second kernel): stats = {bytes of queue workspace the context holds, items one segment holds,
+ * bright items (lambda >= 10) and inversion items (lambda < 10) the context's last sampled view queued -- the first view of a stacked
+ * call --, voxels its full segments refused (a third kernel samples them where they stand: same counts, slower), pending voxels (queued
+ * or refused) of its fullest block: the segment size that refuses nothing}.
+ * Option "poisson_queue_share" = 1..16 fixes the sixteenths of a block's voxels its segment holds (16: 16 bytes per acquired voxel,
+ * nothing is ever refused).  "auto", the default: 16 for queues of up to 64 MiB; otherwise 5 at first, and after a view whose segments
+ * refused voxels the context's later views get what that view would have needed plus one sixteenth.  Counts are the same for every share.
+ * Synchronises the context.  (Zeros after a view that did not go through the two-launch sampler: options "poisson_queue=0", "fuse_tail=1".) */
+int mvsim_get_queue_stats(mvsim_ctx* ctx, int64_t stats[6]);
 int mvsim_enable_timing(mvsim_ctx* ctx, int enable);
 int mvsim_get_timings(mvsim_ctx* ctx, mvsim_timings* t);
 

@@ -481,6 +481,13 @@ class Context:
         _lib.check(self._L.mvsim_get_plane_stats(self._h, st))
         return int(st[0]), int(st[1]), int(st[2])
 
+    def queue_stats(self):
+        """The Poisson work queue of the last sampled view: dict(bytes, segment_items, bright, inversion, refused, fullest_block) --
+        mvsim_get_queue_stats."""
+        st = (C.c_int64 * 6)()
+        _lib.check(self._L.mvsim_get_queue_stats(self._h, st))
+        return dict(bytes=int(st[0]), segment_items=int(st[1]), bright=int(st[2]), inversion=int(st[3]), refused=int(st[4]), fullest_block=int(st[5]))
+
     def transfer_stats(self):
         """(views whose acquisition crossed PCIe as uint16 counts, how many of them fell back to float32)."""
         a, b = C.c_int64(), C.c_int64()

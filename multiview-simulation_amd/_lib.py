@@ -112,6 +112,7 @@ SIGNATURES = {
     "mvsim_simulate_view_dev": (C.c_int, [_vp, _vp, _i64p, _vp, _i64p, C.POINTER(ViewParams),
                                           C.POINTER(ViewOutputs), C.POINTER(C.c_double)]),
     "mvsim_get_plane_stats": (C.c_int, [_vp, _i64p]),
+    "mvsim_get_queue_stats": (C.c_int, [_vp, _i64p]),
     "mvsim_get_transfer_stats": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mvsim_simulate_views_dev": (C.c_int, [_vp, _vp, _i64p, C.POINTER(_vp), _i64p, C.POINTER(ViewParams),
                                            C.POINTER(ViewOutputs), C.c_int]),

@@ -54,6 +54,14 @@ int parse_option(Options& o, const char* name, const char* value)
         else return MVSIM_EINVAL;
         return MVSIM_OK;
     }
+    if (n == "poisson_queue_share") {                      // sixteenths of a block's voxels its queue segment holds
+        if (v == "auto") { o.poisson_queue_share = 0; return MVSIM_OK; }
+        if (v.empty() || v.size() > 2 || v.find_first_not_of("0123456789") != std::string::npos) return MVSIM_EINVAL;
+        const int k = atoi(v.c_str());
+        if (k < 1 || k > 16) return MVSIM_EINVAL;
+        o.poisson_queue_share = k;
+        return MVSIM_OK;
+    }
     if (n == "attenuate") {
         if (v == "serial") o.attenuate_scan = false; else if (v == "scan") o.attenuate_scan = true; else return MVSIM_EINVAL;
         return MVSIM_OK;
@@ -297,6 +305,21 @@ static int set_device(mvsim_ctx* ctx, bool keep_tail = false)
     return MVSIM_OK;
 }
 
+// The queue share of the context's next sampled view (QueueMode).  Option given: that.  Auto: what this context's views have needed so
+// far -- k_poisson_refused leaves the sixteenths the fullest refused segment would have needed in a page-locked word, read here without
+// synchronising: a view whose segments refuse voxels still gives the right counts (slower), and the views after it get the larger queue.
+static int queue_mode_next(mvsim_ctx* ctx, QueueMode* qm)
+{
+    qm->share = 0; qm->hint = nullptr;
+    if (ctx->opt.poisson_queue != 1) return MVSIM_OK;
+    if (ctx->opt.poisson_queue_share > 0) { qm->share = ctx->opt.poisson_queue_share; return MVSIM_OK; }
+    const unsigned int seen = *reinterpret_cast<volatile unsigned int*>(ctx->queue_hint);
+    if ((int)seen >= ctx->queue_share_learned && seen != 0u) ctx->queue_share_learned = seen >= 15u ? 16 : (int)seen + 1;   // one sixteenth of headroom
+    qm->share = QUEUE_SHARE_AUTO + ctx->queue_share_learned;
+    qm->hint = ctx->queue_hint;
+    return MVSIM_OK;
+}
+
 // Tools.normImage on the host (Tools.java:112-132), in place (Q5): double sum, (float)(v / sum).
 static void psf_normalise_host(float* psf_host, int64_t n)
 {
@@ -517,6 +540,14 @@ int mvsim_create(int device, mvsim_ctx** out)
     ctx->opt = env_options();
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return MVSIM_EHIP; }
     ctx->stream = ctx->own_stream;
+    // (here and not at the first sampled view: that one may be inside a stream capture)
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->queue_hint), 4 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return MVSIM_EHIP;
+    }
+    ctx->queue_hint[0] = ctx->queue_hint[1] = ctx->queue_hint[2] = ctx->queue_hint[3] = 0u;
     *out = ctx;
     return MVSIM_OK;
 }
@@ -546,6 +577,7 @@ int mvsim_destroy(mvsim_ctx* ctx)
     if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamDestroy(ctx->tail_stream); (void)hipEventDestroy(ctx->ev_tail_fork); (void)hipEventDestroy(ctx->ev_tail); }
     if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     if (ctx->empty_hint) (void)hipHostFree(ctx->empty_hint);
+    if (ctx->queue_hint) (void)hipHostFree(ctx->queue_hint);
     if (ctx->sync_u16_host) (void)hipHostFree(ctx->sync_u16_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -768,10 +800,12 @@ int mvsim_extract_slices_dev(mvsim_ctx* ctx, const float* in, const int64_t dim[
     MVSIM_CHECK_ARG(inc >= 1, "inc must be >= 1");
     const bool noise = snr >= 0.0f;   // SMVD:211
     void* qws = nullptr;
-    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(dim[0] * dim[1], mvsim_extract_nz(dim[2], inc)))); qws = ctx->pqueue.p; }
+    QueueMode qm;
+    MVSIM_TRY(queue_mode_next(ctx, &qm));
+    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(dim[0] * dim[1], mvsim_extract_nz(dim[2], inc), qm.share))); qws = ctx->pqueue.p; }
     ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, in, out, dim, inc, false, nullptr, 0.0f, noise,
-                             mvsim_poisson_mul((double)snr), seed, stream, 0, qws, ctx->opt.poisson_queue));
+                             mvsim_poisson_mul((double)snr), seed, stream, 0, qws, qm));
     ev_end(ctx, ST_EXTRACT);
     return MVSIM_OK;
 }
@@ -950,7 +984,9 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
 
     void* qws = nullptr;
     const int64_t n_out = dim[0] * dim[1] * mvsim_extract_nz(dim[2], p->inc);
-    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(dim[0] * dim[1], mvsim_extract_nz(dim[2], p->inc)))); qws = ctx->pqueue.p; }
+    QueueMode qm;
+    MVSIM_TRY(queue_mode_next(ctx, &qm));
+    if (noise) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(dim[0] * dim[1], mvsim_extract_nz(dim[2], p->inc), qm.share))); qws = ctx->pqueue.p; }
     // The tail runs on a stream of its own and is joined by whatever the context does next (join_tail): the next view's
     // rotate+attenuate leaves most of the chip idle and runs beside it.
     // (not beside the fused rotate + attenuate + x transform of the next view: that kernel is bound by vector issue like the
@@ -973,10 +1009,10 @@ static int view_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], c
         // `con` holds the acquired planes only: read them in order, count the RNG in source planes
         const int64_t cdim[3] = {dim[0], dim[1], mvsim_extract_nz(dim[2], p->inc)};
         MVSIM_TRY(launch_extract(ctx->stream, con, o->acq, cdim, 1, true, scal, p->min_value, noise,
-                                 mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws, ctx->opt.poisson_queue, p->inc));
+                                 mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws, qm, p->inc));
     } else {
         MVSIM_TRY(launch_extract(ctx->stream, con, o->acq, dim, p->inc, !materialise, scal, p->min_value, noise,
-                                 mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws, ctx->opt.poisson_queue));
+                                 mvsim_poisson_mul((double)p->snr), p->seed, p->stream, 0, qws, qm));
     }
     ev_end(ctx, ST_EXTRACT);
     if (overlap_ok) {
@@ -1008,8 +1044,8 @@ static std::string view_graph_key(mvsim_ctx* ctx, const float* gt, const int64_t
     add(&o->rot, sizeof(o->rot)); add(&o->att, sizeof(o->att)); add(&o->con, sizeof(o->con)); add(&o->acq, sizeof(o->acq));
     add(&ctx->stream, sizeof(ctx->stream));
     const Options& q = ctx->opt;
-    const int oo[12] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, q.psf_overlap ? 1 : 0,
-                        q.attenuate_scan ? 1 : 0, q.fused_fftx, q.zconv_strided ? 1 : 0, q.skip_empty ? 1 : 0, q.exp};
+    const int oo[14] = {q.zpass, q.rocfft ? 1 : 0, q.fused_rotate, q.poisson_queue, q.early_sum ? 1 : 0, q.fuse_tail ? 1 : 0, q.psf_overlap ? 1 : 0,
+                        q.attenuate_scan ? 1 : 0, q.fused_fftx, q.zconv_strided ? 1 : 0, q.skip_empty ? 1 : 0, q.exp, q.poisson_queue_share, ctx->queue_share_learned};
     add(oo, sizeof(oo));
     add(q.fft_pad, sizeof(q.fft_pad));
     return k;
@@ -1179,7 +1215,9 @@ static int views_enqueue_batched(mvsim_ctx* ctx, const float* gt, const int64_t 
     const int zstride = p0.inc > 1 ? p0.inc : 1;                                        // (as view_enqueue: only the planes extractSlices reads)
     const int64_t con_planes = zstride > 1 ? nzo : dim[2];
     MVSIM_TRY(ctx->vol_a.reserve((size_t)V * plane_vox * con_planes * sizeof(float)));  // con[v]
-    const size_t qbytes = noise ? ((poisson_queue_bytes_planes(plane_vox, nzo) + 255) & ~(size_t)255) : 0;
+    QueueMode qm;
+    MVSIM_TRY(queue_mode_next(ctx, &qm));
+    const size_t qbytes = noise ? ((poisson_queue_bytes_planes(plane_vox, nzo, qm.share) + 255) & ~(size_t)255) : 0;
     if (noise) MVSIM_TRY(ctx->pqueue.reserve(qbytes * V));
     double *partial, *scal0;
     MVSIM_TRY(scal_ptr(ctx, &partial, &scal0));
@@ -1231,10 +1269,10 @@ static int views_enqueue_batched(mvsim_ctx* ctx, const float* gt, const int64_t 
     const ExtractView* evt = reinterpret_cast<const ExtractView*>(dp + off_e);
     if (zstride > 1) {
         const int64_t cdim[3] = {dim[0], dim[1], nzo};                                  // `con` holds the acquired planes only
-        MVSIM_TRY(launch_extract_views(ctx->stream, cdim, 1, true, p0.min_value, noise, mvsim_poisson_mul((double)p0.snr), ctx->opt.poisson_queue,
+        MVSIM_TRY(launch_extract_views(ctx->stream, cdim, 1, true, p0.min_value, noise, mvsim_poisson_mul((double)p0.snr), qm,
                                        p0.inc, V, evt, vec_all));
     } else {
-        MVSIM_TRY(launch_extract_views(ctx->stream, dim, p0.inc, true, p0.min_value, noise, mvsim_poisson_mul((double)p0.snr), ctx->opt.poisson_queue,
+        MVSIM_TRY(launch_extract_views(ctx->stream, dim, p0.inc, true, p0.min_value, noise, mvsim_poisson_mul((double)p0.snr), qm,
                                        0, V, evt, vec_all));
     }
     ev_end(ctx, ST_EXTRACT);
@@ -1449,26 +1487,28 @@ int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim
     const int64_t k0 = (z0 + p->inc - 1) / p->inc, k1 = (z1 + p->inc - 1) / p->inc;     // acquired planes k: z0 <= k*inc < z1
     if (n_planes) *n_planes = k1 - k0;
     if (k1 <= k0) return MVSIM_OK;
+    QueueMode qm;
+    MVSIM_TRY(queue_mode_next(ctx, &qm));
     if (ctx->slab_zstride > 1) {
         // compact slab: vol_a holds the planes z0 + k * inc alone, in order (z0 is a multiple of inc: plane k0 * inc = z0)
         const int64_t cdim[3] = {dim[0], dim[1], k1 - k0};
         const bool noise_c = p->snr >= 0.0f;
         void* q = nullptr;
-        if (noise_c) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(plane, k1 - k0))); q = ctx->pqueue.p; }
+        if (noise_c) { MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(plane, k1 - k0, qm.share))); q = ctx->pqueue.p; }
         return launch_extract(ctx->stream, ctx->vol_a.as<float>(), acq, cdim, 1, true, scal, p->min_value, noise_c, mvsim_poisson_mul((double)p->snr),
-                              p->seed, p->stream, (uint64_t)(z0 * plane), q, ctx->opt.poisson_queue, p->inc);
+                              p->seed, p->stream, (uint64_t)(z0 * plane), q, qm, p->inc);
     }
     const int64_t first = k0 * p->inc;                      // global index of the first acquired source plane
     const int64_t ldim[3] = {dim[0], dim[1], z1 - first};
     const bool noise = p->snr >= 0.0f;
     void* qws = nullptr;
     if (noise) {
-        MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(plane, k1 - k0)));
+        MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(plane, k1 - k0, qm.share)));
         qws = ctx->pqueue.p;
     }
     return launch_extract(ctx->stream, ctx->vol_a.as<float>() + plane * (first - z0), acq, ldim, p->inc, true, scal,
                           p->min_value, noise, mvsim_poisson_mul((double)p->snr), p->seed, p->stream,
-                          (uint64_t)(first * plane), qws, ctx->opt.poisson_queue);
+                          (uint64_t)(first * plane), qws, qm);
 }
 
 // ---- host-buffer entry points (JNI boundary) ---------------------------------------------------------
@@ -1602,10 +1642,12 @@ int mvsim_poisson_process(mvsim_ctx* ctx, float* img, int64_t n, double snr, uin
     MVSIM_TRY(up(ctx, ctx->vol_a, img, bytes));
     MVSIM_TRY(ctx->out_buf.reserve(bytes));
     const int64_t dim[3] = {n, 1, 1};
-    MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(n, 1)));
+    QueueMode qm;
+    MVSIM_TRY(queue_mode_next(ctx, &qm));
+    MVSIM_TRY(ctx->pqueue.reserve(poisson_queue_bytes_planes(n, 1, qm.share)));
     ev_begin(ctx, ST_EXTRACT);
     MVSIM_TRY(launch_extract(ctx->stream, ctx->vol_a.as<float>(), ctx->out_buf.as<float>(), dim, 1, false, nullptr,
-                             0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset, ctx->pqueue.p, ctx->opt.poisson_queue));
+                             0.0f, true, mvsim_poisson_mul(snr), seed, stream, index_offset, ctx->pqueue.p, qm));
     ev_end(ctx, ST_EXTRACT);
     return down_counts(ctx, img, ctx->out_buf.as<float>(), n, true);
 }
@@ -1996,6 +2038,19 @@ int mvsim_get_plane_stats(mvsim_ctx* ctx, int64_t stats[3])
         const volatile int* h = ctx->empty_hint;
         stats[0] = h[2]; stats[1] = h[0]; stats[2] = h[1] >= 0 ? h[1] : 0;
     }
+    return MVSIM_OK;
+}
+
+int mvsim_get_queue_stats(mvsim_ctx* ctx, int64_t stats[6])
+{
+    MVSIM_CHECK_ARG(ctx != nullptr && stats != nullptr, "null pointer");
+    for (int i = 0; i < 6; ++i) stats[i] = 0;
+    stats[0] = (int64_t)ctx->pqueue.bytes;
+    if (!ctx->pqueue.p) return MVSIM_OK;
+    MVSIM_TRY(mvsim_synchronize(ctx));
+    long long q[5] = {0, 0, 0, 0, 0};
+    MVSIM_TRY(poisson_queue_read_stats(ctx->pqueue.p, ctx->pqueue.bytes, q));
+    for (int i = 0; i < 5; ++i) stats[1 + i] = q[i];
     return MVSIM_OK;
 }
 

@@ -113,6 +113,11 @@ struct Options {
                                        // fp64 products (float outputs differ from the serial walk by one ulp on < 1e-6 of the voxels)
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
                                        // resolver, production), 0: one kernel
+    int     poisson_queue_share = 0;   // sixteenths of a block's voxels its queue segment holds.  16: every voxel, 16 B per acquired voxel
+                                       // (2.25 GiB at 512^3, 34 GB at 2048^2 x 512), nothing ever refused; less: what a full segment refuses is
+                                       // sampled where it stands by a third kernel, same counts (k_poisson_refused).  0 = auto: 16 for queues of
+                                       // up to 64 MiB (not worth the third launch), else 5 (0.70 GiB at 512^3) and growing to what the
+                                       // context's views turn out to need (the phantom: 3, a volume without an empty voxel: 12)
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
     int     exp = 0;                   // experiment bits for A/B runs on one box (tools/): 1 = z pass tiles in plain grid order, 2 = k_zconv_strided wherever its
                                        // geometry allows (without the cost rule of zconv_strided_chunk)
@@ -146,6 +151,15 @@ struct Options {
                                        // the pieces that have arrived among themselves (mvsim_comm_broadcast_plan; comm.cpp: bcast_pipelined)
     int64_t fft_pad[3] = {0, 0, 0};    // explicit padded sizes on the rocFFT path (0: choose)
     bool    skip_empty = true;         // convolution passes skip planes the fused rotate kernel found empty (exact; option for A/B runs)
+};
+// How launch_extract samples.  share 0: one launch, no work queue.  1..16: work queue whose per-block segments hold that many sixteenths
+// of the block's voxels.  QUEUE_SHARE_AUTO + L (L = 0..16): the library's choice -- every voxel for queues of up to 64 MiB, else
+// max(QUEUE_SHARE_START, L) sixteenths, L being what this context's views have needed so far (api.cpp: queue_mode_next).
+constexpr int QUEUE_SHARE_AUTO = 32;
+constexpr int QUEUE_SHARE_START = 5;
+struct QueueMode {
+    int           share = 0;
+    unsigned int* hint  = nullptr;  // page-locked word k_poisson_refused raises to the sixteenths the fullest refused block would have needed
 };
 const Options& env_options();
 int parse_option(Options& o, const char* name, const char* value);   // MVSIM_OK / MVSIM_EINVAL
@@ -181,6 +195,8 @@ struct mvsim_ctx {
     mvsim::DevBuf sphere_list;              // phantom generator: (centre, radius, value) items
     mvsim::DevBuf plane_flags;              // per-plane non-zero flags of the current view (rotate_fft.hip -> the convolution passes)
     int*          empty_hint = nullptr;     // page-locked word the device writes: empty planes of the last view that carried flags (-1: none yet)
+    unsigned int* queue_hint = nullptr;     // page-locked word the device raises: sixteenths of a block's voxels the fullest refused queue segment needed
+    int           queue_share_learned = 0;  // ... as the host has seen it so far (auto share: queue_mode_next)
     int           views_since_flags = 0;    // views run WITHOUT flags since (a volume without empty planes pays nothing for the bookkeeping)
     mvsim::DevBuf weight_img;               // computeWeightImage of the last volume size (mvsim_simulate_iteration_dev)
     int64_t       weight_dim[3] = {0, 0, 0};
@@ -303,12 +319,11 @@ int launch_norm_apply(hipStream_t s, float* img, int64_t n, const double* scal);
 // extract (+ optional adjust using scal[1]) (+ optional Poisson).  in: Nx*Ny*Nz, out: Nx*Ny*nzo
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                   uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc = 0);
-// bytes of the Poisson work queue (HBM) for n_out output voxels
-size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity);
-// ... for nzo planes of `plane` voxels whichever sampler kernel takes them (planes that are no multiple of four voxels or unaligned
-// buffers go group by group through k_extract_noise2_any, whose wave slots are padded per plane)
-size_t poisson_queue_bytes_planes(long long plane, long long nzo);
+                   uint32_t stream, uint64_t index_offset, void* queue_ws, QueueMode queue_mode, int index_inc = 0);
+// bytes of the Poisson work queue (HBM) for nzo planes of `plane` voxels whichever sampler kernel takes them (planes that are no
+// multiple of four voxels or unaligned buffers go group by group through k_extract_noise2_any, whose wave slots are padded per plane)
+size_t poisson_queue_bytes_planes(long long plane, long long nzo, int share);
+int poisson_queue_read_stats(const void* queue_ws, size_t bytes, long long stats[5]);
 // ---- stacked views (mvsim_simulate_views_dev): one launch per stage for V views of one ground truth; blockIdx.y / .z = view
 struct ExtractView {              // per-view operands of the extract + Poisson kernels (device table)
     const float*  in;             // the view's convolved planes
@@ -321,7 +336,7 @@ struct ExtractView {              // per-view operands of the extract + Poisson 
 int launch_rotate_attenuate_views(hipStream_t s, const float* in, float* att, const int64_t dim[3], const Affine* atab_dev, int nviews, double delta);
 void poisson_queue_split(void* queue_ws, void** queue_items, unsigned int** qcount);
 int launch_extract_views(hipStream_t s, const int64_t dim[3], int inc, bool adjust, float min_value, bool noise, double mul,
-                         int queue_mode, int index_inc, int nviews, const ExtractView* vt_dev, bool vec_all);
+                         QueueMode queue_mode, int index_inc, int nviews, const ExtractView* vt_dev, bool vec_all);
 int launch_pack_u16(hipStream_t s, const float* in, unsigned short* out16, int64_t n, unsigned int* flag);
 int launch_make_isotropic(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc);
 // phantom generator (phantom.hip)

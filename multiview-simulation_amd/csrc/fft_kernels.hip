@@ -429,11 +429,12 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     double* red = reinterpret_cast<double*>(lds + NR * LP + M);              // NW doubles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2* wbuf = lds + wave * LW * LP;
-    // FUSE: behind the 32 doubles of `red`: two append counters, then one P1Scratch per wave
-    unsigned int* qctr = reinterpret_cast<unsigned int*>(red + 32);
+    // FUSE: behind the 32 doubles of `red`: the append counter (64 bits) and the two refusal counters, then one P1Scratch per wave
+    unsigned long long* qctr = reinterpret_cast<unsigned long long*>(red + 32);
+    unsigned int* qovf = reinterpret_cast<unsigned int*>(red + 33);
     constexpr size_t SCR_OFF = ((size_t)(NR * LP + M) * sizeof(float2) + 34 * sizeof(double) + 15) & ~(size_t)15;
     P1Scratch* scratch = reinterpret_cast<P1Scratch*>(reinterpret_cast<char*>(lds) + SCR_OFF);
-    if (FUSE && tid == 0) { qctr[0] = 0u; qctr[1] = 0u; }
+    if (FUSE && tid == 0) { *qctr = 0ull; qovf[0] = 0u; qovf[1] = 0u; }
     for (int i = tid; i < M; i += T) tw[i] = twg[i];
     const long long row0 = (long long)blockIdx.x * NR + wave * LW;           // output rows (y < ny, z < nz)
 
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
         const double corr = f.scal[1];
         P1Args pa;
         pa.mul = f.mul; pa.mulf = (float)f.mul; pa.k0 = f.k0; pa.k1 = f.k1; pa.stream = f.stream;
-        pa.seg = f.queue + (unsigned long long)blockIdx.x * f.segcap; pa.segcap = f.segcap; pa.nq = &qctr[0]; pa.nqs = &qctr[1];
+        pa.seg = f.queue + (unsigned long long)blockIdx.x * f.segcap; pa.segcap = f.segcap; pa.ctr = qctr; pa.ovf = qovf;
         const int nq4 = nx >> 2;
         for (int j = 0; j < LW; ++j) {
             const long long row = row0 + j;
@@ -561,10 +562,7 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
             }
         }
         __syncthreads();
-        if (tid == 0 && f.noise) {                                           // no queue without noise (qcount is null then)
-            f.qcount[2 * blockIdx.x] = qctr[0];
-            f.qcount[2 * blockIdx.x + 1] = qctr[1];
-        }
+        if (tid == 0 && f.noise) p1_publish(f.qcount + (size_t)QCOUNT_WORDS * blockIdx.x, *qctr, qovf);   // no queue without noise (qcount is null then)
         return;
     }
     double acc = 0.0;
@@ -1580,7 +1578,7 @@ size_t fused_tail_queue_bytes(const int64_t dim[3], const int64_t kdim[3], int i
     long long blocks = 0;
     unsigned int segcap = 0;
     if (!fused_tail_geometry(dim, kdim, inc, con_wanted, opt, &blocks, &segcap)) return 0;
-    const size_t counts = ((size_t)2 * blocks * sizeof(unsigned int) + 255) & ~(size_t)255;
+    const size_t counts = ((size_t)QCOUNT_WORDS * blocks * sizeof(unsigned int) + 255) & ~(size_t)255;
     return counts + (size_t)blocks * segcap * sizeof(PItem);
 }
 
@@ -2006,7 +2004,7 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
             fz.acq_every = tail->con_adj ? tail->inc : 1; fz.idx_zstride = zstride; fz.noise = tail->noise ? 1 : 0;
             fz.mul = tail->mul; fz.k0 = (uint32_t)tail->seed; fz.k1 = (uint32_t)(tail->seed >> 32); fz.stream = tail->stream;
             if (tail->noise) {
-                const size_t counts = ((size_t)2 * fblocks * sizeof(unsigned int) + 255) & ~(size_t)255;
+                const size_t counts = ((size_t)QCOUNT_WORDS * fblocks * sizeof(unsigned int) + 255) & ~(size_t)255;
                 if (ctx->pqueue.bytes < counts + (size_t)fblocks * fsegcap * sizeof(PItem)) {
                     set_error("fused tail: queue workspace not reserved");
                     return MVSIM_EINVAL;

@@ -1,6 +1,8 @@
 // Streaming kernels of the per-view path (gfx950, wave64): rotate, attenuate, sum/adjust,
 // slice extraction + Poisson, makeIsotropic, weight image.  All are HBM-bound; design notes and
 // algorithmic bytes per voxel are in DESIGN.md.
+#include <vector>
+
 #include "common.h"
 #include "poisson_dev.h"
 
@@ -817,14 +819,15 @@ __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict
         in = e.in; out = e.out; scal = e.scal; k0 = e.k0; k1 = e.k1; stream = e.stream;
         queue = reinterpret_cast<PItem*>(e.queue); qcount = e.qcount;
     }
-    __shared__ unsigned int nq, nqs;
+    __shared__ unsigned long long qctr;
+    __shared__ unsigned int qovf[2];
     __shared__ P1Scratch scratch[4];
-    if (threadIdx.x == 0) { nq = 0u; nqs = 0u; }
+    if (threadIdx.x == 0) { qctr = 0ull; qovf[0] = 0u; qovf[1] = 0u; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     P1Args pa;
     pa.mul = mul; pa.mulf = (float)mul; pa.k0 = k0; pa.k1 = k1; pa.stream = stream;
-    pa.seg = queue + (unsigned long long)blockIdx.x * segcap; pa.segcap = segcap; pa.nq = &nq; pa.nqs = &nqs;
+    pa.seg = queue + (unsigned long long)blockIdx.x * segcap; pa.segcap = segcap; pa.ctr = &qctr; pa.ovf = qovf;
     double corr = 1.0;
     if (ADJUST) corr = scal[1];
     const long long total4 = plane4 * nzo;
@@ -860,8 +863,8 @@ __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        qcount[2 * blockIdx.x] = nq;
-        qcount[2 * blockIdx.x + 1] = nqs;
+        p1_publish(qcount + (size_t)QCOUNT_WORDS * blockIdx.x, qctr, qovf);
+        if (blockIdx.x == 0) p1_publish_header(qcount, gridDim.x, segcap);
     }
 }
 
@@ -885,14 +888,15 @@ __global__ __launch_bounds__(256) void k_extract_noise2_any(const float* __restr
         in = e.in; out = e.out; scal = e.scal; k0 = e.k0; k1 = e.k1; stream = e.stream;
         queue = reinterpret_cast<PItem*>(e.queue); qcount = e.qcount;
     }
-    __shared__ unsigned int nq, nqs;
+    __shared__ unsigned long long qctr;
+    __shared__ unsigned int qovf[2];
     __shared__ P1Scratch scratch[4];
-    if (threadIdx.x == 0) { nq = 0u; nqs = 0u; }
+    if (threadIdx.x == 0) { qctr = 0ull; qovf[0] = 0u; qovf[1] = 0u; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     P1Args pa;
     pa.mul = mul; pa.mulf = (float)mul; pa.k0 = k0; pa.k1 = k1; pa.stream = stream;
-    pa.seg = queue + (unsigned long long)blockIdx.x * segcap; pa.segcap = segcap; pa.nq = &nq; pa.nqs = &nqs;
+    pa.seg = queue + (unsigned long long)blockIdx.x * segcap; pa.segcap = segcap; pa.ctr = &qctr; pa.ovf = qovf;
     double corr = 1.0;
     if (ADJUST) corr = scal[1];
     const long long slots = slots_per_plane * nzo;        // wave slots: 64 groups each
@@ -928,8 +932,8 @@ __global__ __launch_bounds__(256) void k_extract_noise2_any(const float* __restr
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        qcount[2 * blockIdx.x] = nq;
-        qcount[2 * blockIdx.x + 1] = nqs;
+        p1_publish(qcount + (size_t)QCOUNT_WORDS * blockIdx.x, qctr, qovf);
+        if (blockIdx.x == 0) p1_publish_header(qcount, gridDim.x, segcap);
     }
 }
 
@@ -946,59 +950,155 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job, const E
     resolve_segment_body(job, (long long)blockIdx.x, (int)threadIdx.x, &ticket);
 }
 
+// Queues whose segments hold a SHARE of their blocks' voxels (poisson_queue_share < 16): the voxels a full segment refused, sampled
+// where they stand.  A kernel of its own so that this divergent fp64 code costs neither phase 1 nor the resolver a register; its blocks
+// return at once unless the resolver has recorded a refusal in the queue's header -- on the bench's volumes, always.
+constexpr int REFUSED_BLOCKS = 2048;
+constexpr unsigned int REFUSED_LIST = 4096;                // positions the block gathers before it samples them (16 KB of LDS)
+__global__ __launch_bounds__(256) void k_poisson_refused(ResolveJob job, int segments, unsigned int full_items, unsigned int* hint,
+                                                         const ExtractView* __restrict__ vt)
+{
+    if (vt) {
+        const ExtractView e = vt[blockIdx.y];
+        job.out = e.out; job.qcount = e.qcount; job.k0 = e.k0; job.k1 = e.k1; job.stream = e.stream;
+    }
+    if (job.qcount[QCOUNT_HEADER + 2] == 0u) return;                 // no block of this view was refused anything (the resolver's word)
+    __shared__ unsigned int list[REFUSED_LIST];
+    __shared__ unsigned int count;
+    const int t = (int)threadIdx.x;
+    if (t == 0) count = 0u;
+    __syncthreads();
+    // refused voxels are a few per cent of a block's voxels, scattered: sampled where the walk finds them, one lane in twenty would work.
+    // So the walk only gathers positions, and the list is sampled whenever another trip (1024 candidates) might not fit: all lanes busy.
+    auto flush = [&]() {
+        __syncthreads();                                              // the list is complete
+        const unsigned int m = count;
+        for (unsigned int i = (unsigned int)t; i < m; i += 256u) {
+            const unsigned int o = list[i];
+            job.out[o] = resolve_in_place(-job.out[o], job, resolve_index_of(job, o));
+        }
+        __syncthreads();                                              // every lane has read `count` and its entries
+        if (t == 0) count = 0u;
+        __syncthreads();
+    };
+    unsigned int need = 0u;                                           // sixteenths of its voxels the fullest of this block's segments had pending
+    for (int seg = (int)blockIdx.x; seg < segments; seg += (int)gridDim.x) {
+        const unsigned int* qc = job.qcount + (size_t)QCOUNT_WORDS * seg;
+        if (qc[2] == 0u) continue;                                    // block-uniform
+        const unsigned int sixteenths = (unsigned int)((16ull * (qc[0] + qc[1] + qc[2]) + full_items - 1u) / full_items);
+        need = sixteenths > need ? sixteenths : need;
+        for (long long trip = 0;; ++trip) {
+            if (!refused_collect(job, seg, trip, t, segments, list, &count)) break;      // block-uniform
+            __syncthreads();
+            const unsigned int gathered = count;                      // the same for every lane: read between two barriers
+            __syncthreads();
+            if (gathered + 1024u > REFUSED_LIST) flush();             // the next trip adds up to 1024 positions
+        }
+    }
+    flush();
+    // what a context on the automatic share builds its next queue with (api.cpp: queue_mode_next reads the word without synchronising)
+    if (t == 0 && hint && need != 0u) __hip_atomic_fetch_max(hint, need > 16u ? 16u : need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
                            double mul, uint64_t seed, uint32_t stream, long long plane, int idx_inc, uint64_t index_offset)
 {
     const ResolveJob job{out, reinterpret_cast<const PItem*>(queue_items), qcount, segcap, mul, (uint32_t)seed, (uint32_t)(seed >> 32), stream,
-                         (unsigned int)plane, (unsigned int)idx_inc, (unsigned long long)index_offset};
+                         (unsigned int)plane, (unsigned int)idx_inc, (unsigned long long)index_offset, 0, 0, 0};     // full segments: no refusals
     hipLaunchKernelGGL(k_poisson_resolve, dim3(segments), dim3(256), 0, s, job, (const ExtractView*)nullptr);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
 
 // Work-queue geometry for n_out output voxels: `blocks` blocks of 256 lanes x 4 voxels walk the volume with a
-// grid stride; each owns a segment that can hold all of its voxels (16 B per output voxel of HBM workspace).
-constexpr int POISSON_MAX_BLOCKS = 256 * 64;
-static void poisson_geometry(int64_t n_out, int* blocks, unsigned int* segcap)
+// grid stride; each owns a segment of `share` sixteenths of its voxels (16: every voxel, 16 B per output voxel of HBM
+// workspace and no refusals; less: what does not fit is sampled in place by phase 1, poisson_dev.h).
+constexpr size_t QCOUNT_BYTES = (size_t)QCOUNT_HEADER * sizeof(unsigned int) + 256;    // the [counts][header] in front of the segments
+static_assert(QCOUNT_BYTES % 256 == 0, "the segments start 16-byte aligned");
+
+// the share a queue of n_out voxels is built with.  Auto: what the context has learned its views need, from QUEUE_SHARE_START sixteenths up
+// (at 512^3 and the bench's SNR the sphere phantom's fullest block has 14 % of its voxels pending, that of a volume without an empty voxel
+// 68 %: profiles/r05_queue_share.txt), but small queues (<= 64 MiB at full size: up to 160^3 acquired
+// voxels) are not worth the extra launch that looks for refused voxels
+static int share_for(long long n_out, int share)
+{
+    if (share >= QUEUE_SHARE_AUTO) {
+        const int learned = share - QUEUE_SHARE_AUTO;
+        return n_out <= (4ll << 20) ? 16 : (learned >= 16 ? 16 : (learned > QUEUE_SHARE_START ? learned : QUEUE_SHARE_START));
+    }
+    return share >= 16 ? 16 : (share < 1 ? 1 : share);
+}
+
+static unsigned int segment_share(long long worst, int share)
+{
+    if (share >= 16) return (unsigned int)worst;
+    long long c = (worst * (share < 1 ? 1 : share) + 15) / 16;
+    c = (c + 63) & ~63ll;                                   // at least one wave of items, whole waves after that
+    return (unsigned int)(c < worst ? c : worst);
+}
+
+static void poisson_geometry(int64_t n_out, int share, int* blocks, unsigned int* segcap)
 {
     long long want = (n_out / 4 + 255) / 256;
     const int b = (int)(want < 1 ? 1 : (want > POISSON_MAX_BLOCKS ? POISSON_MAX_BLOCKS : want));
     const long long iters = (n_out / 4 + (long long)b * 256 - 1) / ((long long)b * 256);
     *blocks = b;
-    *segcap = (unsigned int)(iters * 1024);       // every voxel of the block: the squeeze accepts only ~35 % at lambda = 10
+    *segcap = segment_share(iters * 1024, share);   // worst case every voxel of the block: the squeeze accepts only ~35 % at lambda = 10
 }
 
-size_t poisson_queue_bytes(int64_t n_out, unsigned long long* capacity)
+static size_t poisson_queue_bytes(int64_t n_out, int share)
 {
     int blocks;
     unsigned int segcap;
-    poisson_geometry(n_out, &blocks, &segcap);
-    if (capacity) *capacity = (unsigned long long)blocks * segcap;
-    return (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);   // [counts][segments]
+    poisson_geometry(n_out, share, &blocks, &segcap);
+    return QCOUNT_BYTES + (size_t)blocks * segcap * sizeof(PItem);   // [counts][segments]
 }
 
 // The same for k_extract_noise2_any: a wave slot is 64 Philox groups of ONE plane (a plane of `plane` voxels that starts anywhere
 // inside a group touches up to plane / 4 + 1 of them, rounded up to whole slots), `blocks` blocks of four waves walk the slots with a
-// grid stride, and a block's segment holds every voxel of its trips.
-static void poisson_geometry_any(long long plane, long long nzo, int* blocks, unsigned int* segcap, long long* slots_per_plane)
+// grid stride, and a block's segment holds `share` sixteenths of the voxels of its trips.
+static void poisson_geometry_any(long long plane, long long nzo, int share, int* blocks, unsigned int* segcap, long long* slots_per_plane)
 {
     const long long spp = ((plane + 3) / 4 + 1 + 63) / 64;
     const long long slots = spp * nzo;
     long long want = (slots + 3) / 4;
     const int b = (int)(want < 1 ? 1 : (want > POISSON_MAX_BLOCKS ? POISSON_MAX_BLOCKS : want));
     const long long trips = (slots + (long long)b * 4 - 1) / ((long long)b * 4);
-    *blocks = b; *segcap = (unsigned int)(trips * 1024); *slots_per_plane = spp;
+    *blocks = b; *segcap = segment_share(trips * 1024, share); *slots_per_plane = spp;
 }
 
-size_t poisson_queue_bytes_planes(long long plane, long long nzo)
+// bytes of queue workspace for nzo acquired planes of `plane` voxels, whichever of the two kernels takes them
+size_t poisson_queue_bytes_planes(long long plane, long long nzo, int share)
 {
     int blocks;
     unsigned int segcap;
     long long spp;
-    poisson_geometry_any(plane, nzo, &blocks, &segcap, &spp);
-    const size_t any = (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int) + (size_t)blocks * segcap * sizeof(PItem);
-    const size_t vec = poisson_queue_bytes(plane * nzo, nullptr);
+    share = share_for(plane * nzo, share);
+    poisson_geometry_any(plane, nzo, share, &blocks, &segcap, &spp);
+    const size_t any = QCOUNT_BYTES + (size_t)blocks * segcap * sizeof(PItem);
+    const size_t vec = poisson_queue_bytes(plane * nzo, share);
     return any > vec ? any : vec;
+}
+
+// What the last two-launch sampler that used this workspace queued (mvsim_get_queue_stats): {items a segment holds, bright items,
+// inversion items, voxels refused and sampled in place, pending voxels of the fullest block}.  The caller has synchronised the stream.
+int poisson_queue_read_stats(const void* queue_ws, size_t bytes, long long stats[5])
+{
+    stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = 0;
+    if (!queue_ws || bytes < QCOUNT_BYTES) return MVSIM_OK;           // not a queue of the two-launch sampler
+    std::vector<unsigned int> h((size_t)QCOUNT_HEADER + 2);
+    MVSIM_HIP(hipMemcpy(h.data(), queue_ws, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    const unsigned int blocks = h[QCOUNT_HEADER] <= (unsigned int)POISSON_MAX_BLOCKS ? h[QCOUNT_HEADER] : 0u;
+    stats[0] = h[(size_t)QCOUNT_HEADER + 1];
+    stats[1] = stats[2] = stats[3] = stats[4] = 0;
+    for (unsigned int b = 0; b < blocks; ++b) {
+        const long long f = h[(size_t)QCOUNT_WORDS * b], k = h[(size_t)QCOUNT_WORDS * b + 1], r = h[(size_t)QCOUNT_WORDS * b + 2];
+        stats[1] += f;
+        stats[2] += k;
+        stats[3] += r;
+        if (f + k + r > stats[4]) stats[4] = f + k + r;     // what the fullest block had to settle: the segment size that refuses nothing
+    }
+    return MVSIM_OK;
 }
 
 // nviews > 0: the same launch for `nviews` views whose inputs, outputs, [sum, factor] slots, RNG keys and queue workspaces come from
@@ -1006,7 +1106,7 @@ size_t poisson_queue_bytes_planes(long long plane, long long nzo)
 // queue_ws arguments unused)
 static int launch_extract_impl(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                                const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                               uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc,
+                               uint32_t stream, uint64_t index_offset, void* queue_ws, QueueMode queue_mode, int index_inc,
                                int nviews, const ExtractView* vt, bool vec_all)
 {
     // index_inc: plane stride of the RNG counter when it differs from the plane stride of the reads (a compact input
@@ -1017,11 +1117,12 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
     // phase 1 hands a slot's RNG counters across lanes as 32-bit offsets from lane 0's (poisson_phase1): a slot that straddles
     // two acquired planes must not see them 2^32 voxels apart
     // ... and a work item carries its output position in 32 bits
-    const bool use_queue = queue_mode != 0 && (long long)(index_inc - 1) * plane < (1ll << 31) && plane * ((dim[2] - 1) / inc + 1) < (1ll << 32) &&
+    const bool use_queue = queue_mode.share != 0 && (long long)(index_inc - 1) * plane < (1ll << 31) && plane * ((dim[2] - 1) / inc + 1) < (1ll << 32) &&
                            plane < (1ll << 32);
     const long long nzo = (dim[2] - 1) / inc + 1;
     const long long total = plane * nzo;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int qshare = share_for(total, queue_mode.share);
     const bool vec = (plane % 4 == 0) && (index_offset % 4 == 0) &&
                      (nviews > 0 ? vec_all : ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0));
     if (vec) {
@@ -1033,9 +1134,11 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
         if (noise && (queue_ws || nviews > 0) && use_queue) {
             int qblocks;
             unsigned int segcap;
-            poisson_geometry(total, &qblocks, &segcap);
+            unsigned int full_items;
+            poisson_geometry(total, 16, &qblocks, &full_items);
+            poisson_geometry(total, qshare, &qblocks, &segcap);
             unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
-            PItem* queue = queue_ws ? reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int)) : nullptr;
+            PItem* queue = queue_ws ? reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + QCOUNT_BYTES) : nullptr;
             if (adjust) {
                 hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
                                    scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, vt);
@@ -1044,8 +1147,11 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
                                    scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, vt);
             }
             const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream, (unsigned int)plane, (unsigned int)index_inc,
-                                  (unsigned long long)index_offset};
+                                  (unsigned long long)index_offset, qshare >= 16 ? 0 : 1, total / 4, 0};
             hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks, gy), dim3(256), 0, s, rjob, vt);
+            if (rjob.walk != 0)
+                hipLaunchKernelGGL(k_poisson_refused, dim3(qblocks < REFUSED_BLOCKS ? qblocks : REFUSED_BLOCKS, gy), dim3(256), 0, s, rjob, qblocks,
+                                   full_items, queue_mode.hint, vt);
         }
         else if (adjust && noise) MVSIM_LAUNCH_EX4(true, true);
         else if (adjust) MVSIM_LAUNCH_EX4(true, false);
@@ -1060,9 +1166,11 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
         int qblocks;
         unsigned int segcap;
         long long spp;
-        poisson_geometry_any(plane, nzo, &qblocks, &segcap, &spp);
+        unsigned int full_items;
+        poisson_geometry_any(plane, nzo, 16, &qblocks, &full_items, &spp);
+        poisson_geometry_any(plane, nzo, qshare, &qblocks, &segcap, &spp);
         unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
-        PItem* queue = queue_ws ? reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int)) : nullptr;
+        PItem* queue = queue_ws ? reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + QCOUNT_BYTES) : nullptr;
         if (adjust)
             hipLaunchKernelGGL((k_extract_noise2_any<true>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, min_value,
                                mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, spp, vt);
@@ -1070,8 +1178,11 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
             hipLaunchKernelGGL((k_extract_noise2_any<false>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, min_value,
                                mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, spp, vt);
         const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream, (unsigned int)plane, (unsigned int)index_inc,
-                              (unsigned long long)index_offset};
+                              (unsigned long long)index_offset, qshare >= 16 ? 0 : 2, spp * nzo, spp};
         hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks, gy), dim3(256), 0, s, rjob, vt);
+        if (rjob.walk != 0)
+            hipLaunchKernelGGL(k_poisson_refused, dim3(qblocks < REFUSED_BLOCKS ? qblocks : REFUSED_BLOCKS, gy), dim3(256), 0, s, rjob, qblocks,
+                               full_items, queue_mode.hint, vt);
         MVSIM_HIP(hipGetLastError());
         return MVSIM_OK;
     }
@@ -1091,7 +1202,7 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
 
 int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim[3], int inc, bool adjust,
                    const double* scal, float min_value, bool noise, double mul, uint64_t seed,
-                   uint32_t stream, uint64_t index_offset, void* queue_ws, int queue_mode, int index_inc)
+                   uint32_t stream, uint64_t index_offset, void* queue_ws, QueueMode queue_mode, int index_inc)
 {
     return launch_extract_impl(s, in, out, dim, inc, adjust, scal, min_value, noise, mul, seed, stream, index_offset, queue_ws, queue_mode,
                                index_inc, 0, nullptr, false);
@@ -1101,11 +1212,11 @@ int launch_extract(hipStream_t s, const float* in, float* out, const int64_t dim
 void poisson_queue_split(void* queue_ws, void** queue_items, unsigned int** qcount)
 {
     *qcount = reinterpret_cast<unsigned int*>(queue_ws);
-    *queue_items = reinterpret_cast<char*>(queue_ws) + (size_t)2 * POISSON_MAX_BLOCKS * sizeof(unsigned int);
+    *queue_items = reinterpret_cast<char*>(queue_ws) + QCOUNT_BYTES;
 }
 
 int launch_extract_views(hipStream_t s, const int64_t dim[3], int inc, bool adjust, float min_value, bool noise, double mul,
-                         int queue_mode, int index_inc, int nviews, const ExtractView* vt_dev, bool vec_all)
+                         QueueMode queue_mode, int index_inc, int nviews, const ExtractView* vt_dev, bool vec_all)
 {
     return launch_extract_impl(s, nullptr, nullptr, dim, inc, adjust, nullptr, min_value, noise, mul, 0, 0, 0, nullptr, queue_mode, index_inc,
                                nviews, vt_dev, vec_all);

@@ -436,10 +436,50 @@ struct P1Args {                   // wave-uniform
     float mulf;
     uint32_t k0, k1, stream;
     PItem* seg;                   // this block's queue segment
-    unsigned int segcap;
-    unsigned int* nq;             // LDS append counters of the block: bright items (front), inversion items (back)
-    unsigned int* nqs;
+    unsigned int segcap;          // items it holds: all of the block's voxels, or a share of them (poisson_queue_share)
+    unsigned long long* ctr;      // LDS append counter of the block: low word bright items (front), high word inversion items (back)
+    unsigned int* ovf;            // LDS: appends refused because the segment was full ([0] bright, [1] inversion)
 };
+
+// The count array in front of a queue's segments: per block three words -- items at the front, items at the back, voxels that found
+// the segment full -- for up to POISSON_MAX_BLOCKS blocks, then a header the first block of phase 1 writes: {blocks, items per segment}
+// (what mvsim_get_queue_stats reads) and the resolver completes: {.., .., 1 if any block refused a voxel} (what k_poisson_refused reads).
+constexpr int QCOUNT_WORDS = 3;
+constexpr int POISSON_MAX_BLOCKS = 256 * 64;
+constexpr int QCOUNT_HEADER = QCOUNT_WORDS * POISSON_MAX_BLOCKS;        // word index of the header
+// What phase 1 leaves in the output of a voxel its full segment refused: the NEGATED voxel value (v > 0 for every voxel that has
+// anything to sample, counts are >= 0: a negative output cannot be a result).  k_poisson_refused walks the voxels of every block
+// whose third count word is non-zero once more and samples those voxels where they stand (resolve_refused).
+
+// One LDS atomic hands out the slot AND says whether the segment still has room.  Both words only grow, so once
+// "front + back < segcap" fails for an append it fails for every later one: the accepted fronts and backs are prefixes
+// [0, F) and (segcap - 1 - B, segcap - 1], and two accepted appends never meet (the later one saw the earlier one's word).
+__device__ __forceinline__ bool p1_slot(const P1Args& a, bool back, unsigned int& pos)
+{
+    const unsigned long long old = atomicAdd(a.ctr, back ? (1ull << 32) : 1ull);
+    const unsigned int f = (unsigned int)old, b = (unsigned int)(old >> 32);
+    if (f + b >= a.segcap) {
+        atomicAdd(&a.ovf[back ? 1 : 0], 1u);
+        return false;
+    }
+    pos = back ? a.segcap - 1u - b : f;
+    return true;
+}
+
+// end of a block's phase 1: what the resolver will find in the segment, and how many voxels were sampled in place
+__device__ __forceinline__ void p1_publish_header(unsigned int* qcount_base, unsigned int blocks, unsigned int segcap)
+{
+    qcount_base[QCOUNT_HEADER] = blocks;
+    qcount_base[QCOUNT_HEADER + 1] = segcap;
+    qcount_base[QCOUNT_HEADER + 2] = 0u;                    // set by the resolver, the kernel after this one
+}
+
+__device__ __forceinline__ void p1_publish(unsigned int* qcount, unsigned long long ctr, const unsigned int* ovf)
+{
+    qcount[0] = (unsigned int)ctr - ovf[0];
+    qcount[1] = (unsigned int)(ctr >> 32) - ovf[1];
+    qcount[2] = ovf[0] + ovf[1];
+}
 
 __device__ __forceinline__ void p1_wave_order()
 {
@@ -494,7 +534,7 @@ __device__ __forceinline__ void p1_push(PItem* slot, unsigned long long out, flo
 // (MVSIM_EXP_NOPHILOX / _NOSMALLPUSH / _NOBRIGHT: instruction-attribution builds of tools/attribute_valu.sh -- each removes one
 // part of the work and with it the correctness of the counts; never defined in the product build.)
 __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, unsigned long long index4, unsigned long long out4,
-                                               const P1Args& a, P1Scratch* ws, int lane, float ov[4])
+                                                     const P1Args& a, P1Scratch* ws, int lane, float ov[4])
 {
     int cls[4];
     bool small_any = false;
@@ -522,8 +562,9 @@ __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, un
                 const uint32_t thr = (uint32_t)(fmaxf(tf, 0.f) * 4294967296.0f);
 #ifndef MVSIM_EXP_NOSMALLPUSH
                 if (!(w[c] < thr)) {
-                    const unsigned int pos = atomicAdd(a.nqs, 1u);
-                    p1_push(a.seg + (a.segcap - 1u - pos), out4 + (unsigned long long)c, vv[c], w[c], 0u);
+                    unsigned int pos;
+                    if (p1_slot(a, true, pos)) p1_push(a.seg + pos, out4 + (unsigned long long)c, vv[c], w[c], 0u);
+                    else ov[c] = -vv[c];
                 }
 #else
                 if (!(w[c] < thr)) ov[c] = 1.f;
@@ -584,10 +625,11 @@ __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, un
                 if (ok) {
                     if (e) res.y = k; else res.x = k;
                 } else {
-                    // the segment holds every voxel of the block (worst case: all pending), so this cannot overflow.
                     // (Measured: one LDS atomic per lane is cheaper here than a ballot-aggregated append.)
-                    const unsigned int pos = atomicAdd(a.nq, 1u);
-                    p1_push(a.seg + pos, out_base + 4u * owner + first + (unsigned long long)e, v, w0, w1);
+                    unsigned int pos;
+                    if (p1_slot(a, false, pos)) p1_push(a.seg + pos, out_base + 4u * owner + first + (unsigned long long)e, v, w0, w1);
+                    else if (e) res.y = -v;                   // refused: the resolver finds it by its sign
+                    else res.x = -v;
                 }
             }
         }
@@ -618,12 +660,76 @@ struct ResolveJob {
     unsigned int        plane;
     unsigned int        idx_inc;
     unsigned long long  index_offset;
+    // how phase 1 walked the volume, for the voxels a full segment refused: 0 = its segments hold every voxel of their blocks
+    // (nothing is ever refused: the fused tail, share 16), 1 = k_extract4_noise2 (walk_n = float4 groups), 2 = k_extract_noise2_any
+    // (walk_n = wave slots, walk_spp = slots per plane)
+    int                 walk;
+    long long           walk_n;
+    long long           walk_spp;
 };
+
+// One voxel sampled where it stands, attempt by attempt from its own random words: what poisson_counter computes, in the
+// resolver's formulation.
+__device__ __forceinline__ float resolve_in_place(float v, const ResolveJob& j, unsigned long long index)
+{
+    const double lam = (double)v * j.mul;
+    if (lam < 10.0) {
+        const unsigned long long g = index >> 2;
+        const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), j.stream, 0u, j.k0, j.k1);
+        const uint32_t c = (uint32_t)index & 3u;
+        return poisson_small(lam, c == 0u ? r.x : (c == 1u ? r.y : (c == 2u ? r.z : r.w)));
+    }
+    const unsigned long long pr = index >> 1;
+    const Philox4 r = philox4x32_10((uint32_t)pr, (uint32_t)(pr >> 32), j.stream, 1u, j.k0, j.k1);
+    uint32_t w0 = (index & 1ull) ? r.z : r.x, w1 = (index & 1ull) ? r.w : r.y;
+    float val = 0.f;
+#pragma unroll 1
+    for (uint32_t att = 0u;; ++att) {
+        if (att >= kPtrsMaxAttempts) return (float)(long long)lam;
+        if (att != 0u) ptrs_retry_words(index, att, j.k0, j.k1, j.stream, w0, w1);
+        if (ptrs_step_words(lam, w0, w1, val)) return val;
+    }
+}
+
+// RNG counter of output element o (see ResolveJob)
+__device__ __forceinline__ unsigned long long resolve_index_of(const ResolveJob& j, unsigned long long o)
+{
+    const unsigned long long kpl = j.idx_inc == 1u ? 0ull : o / j.plane;
+    return j.index_offset + o + kpl * (unsigned long long)(j.idx_inc - 1u) * j.plane;
+}
+
+// The voxels phase-1 block `segment` was refused a queue slot for (its segment, sized for a share of its voxels, was full): the same
+// walk as that block's, one trip of it (`trip`: 1024 candidate voxels), looking for the negated values it left behind.  Their output
+// positions go to the block's LDS list (k_poisson_refused samples them from there, every lane busy).  Returns false past the walk's end.
+__device__ __forceinline__ bool refused_collect(const ResolveJob& j, long long segment, long long trip, int t, long long grid,
+                                                unsigned int* list, unsigned int* count)
+{
+    const bool vec = j.walk == 1;
+    const long long first = vec ? segment * 256 + trip * grid * 256 : segment * 4 + trip * grid * 4;   // block-uniform
+    if (first >= j.walk_n) return false;
+    const long long u = first + (vec ? t : (t >> 6));
+    if (u >= j.walk_n) return true;
+    long long p0 = 4 * u, lo = 0, hi = 4;                                // output position of component 0, valid components [lo, hi)
+    if (!vec) {
+        const long long k = u / j.walk_spp, jb = u - k * j.walk_spp;
+        const unsigned long long ibase = j.index_offset + (unsigned long long)(k * j.idx_inc) * (unsigned long long)j.plane;
+        const unsigned long long g = (ibase >> 2) + (unsigned long long)(jb * 64 + (t & 63));
+        const long long i0 = (long long)(4ull * g - ibase);
+        lo = i0 < 0 ? -i0 : 0;
+        hi = (long long)j.plane - i0 < 4 ? (long long)j.plane - i0 : 4;
+        p0 = k * (long long)j.plane + i0;
+    }
+    for (long long c = lo; c < hi; ++c)
+        if (j.out[p0 + c] < 0.f) list[atomicAdd(count, 1u)] = (unsigned int)(p0 + c);
+    return true;
+}
 
 // One queue segment resolved by the 256 lanes of a block (k_poisson_resolve: kernels.hip).
 __device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long long segment, int t, unsigned int* ticket)
 {
-    const unsigned int n = j.qcount[2 * segment], ns = j.qcount[2 * segment + 1];
+    const unsigned int n = j.qcount[QCOUNT_WORDS * segment], ns = j.qcount[QCOUNT_WORDS * segment + 1];
+    // a block that was refused queue slots says so in the header: k_poisson_refused, the next kernel, reads that one word
+    if (t == 0 && j.walk != 0 && j.qcount[QCOUNT_WORDS * segment + 2] != 0u) const_cast<unsigned int*>(j.qcount)[QCOUNT_HEADER + 2] = 1u;
     const PItem* __restrict__ seg = j.queue + (unsigned long long)segment * j.segcap;
     // inversion items (0 < lambda < 10 that the shortcut of phase 1 could not settle), from the back
     for (unsigned int i = (unsigned int)t; i < ns; i += 256u) {

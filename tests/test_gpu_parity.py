@@ -247,6 +247,87 @@ def test_poisson_counts_bit_exact_over_the_lambda_range(ctx, orc, lo, hi):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("shape,inc", [((24, 64, 64), 1), ((25, 61, 63), 1), ((25, 61, 63), 3), ((31, 64, 64), 2)])
+def test_poisson_queue_share_keeps_the_counts(ctx, orc, shape, inc):
+    """Option poisson_queue_share: a work queue whose per-block segments hold 1/16 of the block's voxels instead of all of them.  What a
+    full segment refuses is marked in the output and sampled where it stands by k_poisson_refused: same (voxel, attempt) arithmetic, so the
+    counts equal the oracle's and the full queue's, voxel for voxel -- on volumes built to overflow it (every voxel pending in the
+    inversion regime; every voxel bright at lambda ~ 10, where the attempt-0 squeeze settles about a third), through the 16-byte kernel
+    (64 x 64 planes) and the group-by-group one (63 x 61).  The statistics say the path was really taken."""
+    rng = np.random.default_rng(5 + inc)
+    mul = orc.poisson_mul(25.0)
+    lam = np.empty(shape)
+    lam[: shape[0] // 3] = rng.uniform(1.5, 9.5, size=lam[: shape[0] // 3].shape)             # inversion regime, never the shortcut
+    lam[shape[0] // 3: 2 * shape[0] // 3] = rng.uniform(10.0, 14.0, size=lam[shape[0] // 3: 2 * shape[0] // 3].shape)
+    lam[2 * shape[0] // 3:] = 10.0 ** rng.uniform(-2, 4, size=lam[2 * shape[0] // 3:].shape)
+    v = (lam / mul).astype(np.float32)
+    v[1, ::5, ::3] = 0.0
+    want = orc.extract_slices_counter(v, inc, 25.0, SEED, 3)
+    stats = {}
+    try:
+        for share in (16, 1, 4):
+            ctx.set_option("poisson_queue_share", share)
+            got = ctx.extract_slices(v, inc, 25.0, SEED, 3)
+            assert np.array_equal(got, want), share
+            stats[share] = ctx.queue_stats()
+    finally:
+        ctx.set_option("poisson_queue_share", "auto")
+    full, tight = stats[16], stats[1]
+    assert full["refused"] == 0 and full["bright"] + full["inversion"] > 0.3 * want.size
+    assert tight["refused"] > 0 and tight["segment_items"] * 8 <= full["segment_items"]
+    # every pending voxel is either in the queue or refused: the two builds settle the same voxels
+    assert tight["bright"] + tight["inversion"] + tight["refused"] == full["bright"] + full["inversion"]
+    assert stats[4]["refused"] > 0 and stats[4]["refused"] < tight["refused"]
+
+
+def test_poisson_queue_grows_to_what_the_views_need(mvs):
+    """The automatic share: a context starts its queue at 5 sixteenths of the full size (queues above 64 MiB), a view whose blocks have more
+    pending than that still gets the right counts -- the third kernel samples what was refused --, leaves what it would have needed in a
+    page-locked word, and the context's NEXT view is given that much: no refusals from then on.  A volume of 5 M voxels with every voxel
+    at lambda ~ 11 (about two thirds of them wait for the resolver) against the same counts from a full-size queue."""
+    rng = np.random.default_rng(11)
+    v = (rng.uniform(10.5, 11.5, size=(160, 176, 176)) / 124.99999999999997).astype(np.float32)
+    with mvs.Context(0) as c:
+        c.set_option("poisson_queue_share", 16)
+        want = c.extract_slices(v, 1, 25.0, 99, 1)
+        full = c.queue_stats()
+    assert full["refused"] == 0 and full["bright"] > 0.5 * v.size
+    with mvs.Context(0) as c:                                      # a fresh context: nothing learned yet
+        first = c.extract_slices(v, 1, 25.0, 99, 1)
+        st1 = c.queue_stats()
+        second = c.extract_slices(v, 1, 25.0, 99, 1)
+        st2 = c.queue_stats()
+    assert np.array_equal(first, want) and np.array_equal(second, want)
+    assert st1["refused"] > 0 and st1["segment_items"] * 16 == 5 * full["segment_items"] and st1["bytes"] < 0.4 * full["bytes"]
+    assert st2["refused"] == 0 and st1["segment_items"] < st2["segment_items"] <= full["segment_items"]
+    assert st2["segment_items"] >= st2["fullest_block"] == full["fullest_block"]
+
+
+def test_poisson_queue_share_in_whole_views(ctx, synth):
+    """The same through the view pipeline, one view at a time and stacked: shares 1 and 16 give identical acquisitions (the queue's size
+    is invisible in the result), for a plane size that is a multiple of four voxels and one that is not."""
+    for n in (48, 45):
+        gt = synth.sphere_phantom(n) + np.float32(0.5)             # no empty voxel: every voxel of the view is bright at this SNR
+        psf = synth.gaussian_psf(7)
+        ps = [ctx.view_params(axis=0, degrees=d, delta=0.01, min_value=0.0, target_average=1.0, inc=2, snr=14.0, seed=7 + d, stream=i)
+              for i, d in enumerate((0, 90, 135))]
+        res = {}
+        try:
+            for share in (16, 1):
+                ctx.set_option("poisson_queue_share", share)
+                seq = [ctx.simulate_view(gt, psf.copy(), p)["acq"] for p in ps]
+                stacked = ctx.simulate_views(gt, [psf.copy() for _ in ps], ps)
+                for a, b in zip(seq, stacked):
+                    assert np.array_equal(a, b)
+                res[share] = seq
+                if share == 1:
+                    assert ctx.queue_stats()["refused"] > 0
+        finally:
+            ctx.set_option("poisson_queue_share", "auto")
+        for a, b in zip(res[16], res[1]):
+            assert np.array_equal(a, b)
+
+
 def test_poisson_process_in_place_and_offsets(ctx, orc):
     rng = np.random.default_rng(8)
     img = rng.random((40, 50), dtype=np.float32) * 2
