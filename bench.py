@@ -34,7 +34,8 @@ Rank 0 prints ONE JSON line (schema in the task contract) including
                   as_reference (the reference's threading) and all_cores
   value_dense  -- top level, beside `value`: the same workload without a single empty voxel (= no_empty_space.value)
   no_empty_space -- N = 1: the serial leg again on the phantom + 1e-6 (nothing for the exact zero-row fast paths to skip)
-  poisson_queue -- the sampler's work queue after the timed steps: GiB held (and at full size), what a view queued, what full segments refused
+  poisson_queue -- the sampler's work queue after the timed steps: GiB held, what a view queued, its fullest block; `auto_share`: the same steps
+                  with the queue sized from what the views need (option poisson_queue_share=auto): GiB and Mvoxel/s
   end_to_end   -- N = 1: the same views with page-locked HOST buffers in and out (PCIe-inclusive; never `value`); acquisitions cross as
                   uint16 counts, the float32 transfer is timed beside it
   size_1024    -- N = 1: one 1024^3 view, same stage timings and roofline keys, its own PMC traffic record.  N > 1: `--views-total` 1024^3
@@ -105,6 +106,7 @@ def parse_args():
     ap.add_argument("--no-tiled-1024", action="store_true",
                     help="N > 1 data path only: skip the `tiled_1024` sub-record (BASELINE configs[3]: every 1024^3 view cut into N z slabs)")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the `no_empty_space` sub-record (N = 1 only)")
+    ap.add_argument("--no-compact-queue-leg", action="store_true", help="skip `poisson_queue.auto_share` (N = 1 only)")
     ap.add_argument("--no-main-iteration", action="store_true",
                     help="skip the `main_iteration` sub-record (N = 1 only): whole iterations of the reference's view loop, device-resident")
     ap.add_argument("--cpu-slab", type=int, default=64, help="z extent of the CPU-baseline sample slab")
@@ -1089,6 +1091,28 @@ def main():
         del keep
         set_overlap(not args.serial)
 
+    compact_queue = None
+    if rank == 0 and not multi and my_views and args.snr >= 0 and queue_stats and not args.no_compact_queue_leg:
+        # The same K steps (library defaults) with the sampler's work queue on its automatic share (option poisson_queue_share=auto): segments
+        # of 5 sixteenths of their blocks' voxels at first, more once a view has needed more; the appends check for room, a third kernel
+        # looks for refused voxels.  What the smaller queue costs in time, next to what it saves in memory.
+        for c in ctxs:
+            c.synchronize()
+            c.set_option("poisson_queue_share", "auto")
+            c.release_caches()                                  # the queue is only ever grown: start it again
+        step(); step(); sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt = time.perf_counter() - t1
+        q = ctx.queue_stats()
+        compact_queue = {"value": total_views * args.steps / dt * nvox / 1e6, "unit": "Mvoxel/s", "ms_per_step": dt / args.steps * 1e3,
+                         "gib": round(q["bytes"] / 2 ** 30, 3), "segment_items": q["segment_items"], "refused_voxels": q["refused"],
+                         "note": "poisson_queue_share=auto; counts identical to the default's (tests/test_gpu_parity.py)"}
+        for c in ctxs:
+            c.set_option("poisson_queue_share", 16)
+
     if rank == 0 and args.rehearse_multi:
         # the rehearsal's own check: both ground-truth buffers still hold the phantom, the views produced counts
         assert all(torch.equal(b, gt_bufs[0]) for b in gt_bufs) and float(gt_bufs[0].max()) > 0 and float(acq[-1].max()) > 0
@@ -1137,12 +1161,13 @@ def main():
         if no_empty:
             out["no_empty_space"] = no_empty
         if queue_stats:
-            # the Poisson work queue of this context: per-block segments sized for a share of the block's voxels (automatic: from 5
-            # sixteenths up, growing to what the views need; every voxel would be 16 B per acquired voxel: 2.25 GiB here), what the last view queued, and
-            # what its full segments refused (sampled in place by a third kernel: same counts, slower -- zero on this workload)
+            # the Poisson work queue of this context: per-block segments that hold every voxel of their blocks (16 B per acquired
+            # voxel), what the last view queued, the fullest block; `auto_share`: the same steps with segments sized from what the views need
             q = queue_stats
-            out["poisson_queue"] = {"gib": round(q["bytes"] / 2 ** 30, 3), "segment_items": q["segment_items"], "queued_share_of_voxels": round((q["bright"] + q["inversion"]) / (n * n * nzo), 4),
+            out["poisson_queue"] = {"share": "16/16 (default: every voxel of a block fits its segment)", "gib": round(q["bytes"] / 2 ** 30, 3), "segment_items": q["segment_items"], "queued_share_of_voxels": round((q["bright"] + q["inversion"]) / (n * n * nzo), 4),
                                     "fullest_block_pending": q["fullest_block"], "refused_voxels": q["refused"]}
+            if compact_queue:
+                out["poisson_queue"]["auto_share"] = compact_queue
         if stage:
             kernel_sha = build.source_sha()
             traffic, note = load_traffic(n, args.psf, args.inc, len(ctxs), args.conv_method, kernel_sha)

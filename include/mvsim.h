@@ -331,9 +331,10 @@ int mvsim_get_plane_stats(mvsim_ctx* ctx, int64_t stats[3]);
  * bright items (lambda >= 10) and inversion items (lambda < 10) the context's last sampled view queued -- the first view of a stacked
  * call --, voxels its full segments refused (a third kernel samples them where they stand: same counts, slower), pending voxels (queued
  * or refused) of its fullest block: the segment size that refuses nothing}.
- * Option "poisson_queue_share" = 1..16 fixes the sixteenths of a block's voxels its segment holds (16: 16 bytes per acquired voxel,
- * nothing is ever refused).  "auto", the default: 16 for queues of up to 64 MiB; otherwise 5 at first, and after a view whose segments
- * refused voxels the context's later views get what that view would have needed plus one sixteenth.  Counts are the same for every share.
+ * Option "poisson_queue_share" = 1..16 fixes the sixteenths of a block's voxels its segment holds (16, the default: 16 bytes per
+ * acquired voxel, nothing is ever refused, the fastest).  "auto": 16 for queues of up to 64 MiB; otherwise 5 at first, and after a view
+ * whose segments refused voxels the context's later views get what that view would have needed plus one sixteenth (memory for ~2 % of
+ * a 512^3 view's time).  Counts are the same for every share.
  * Synchronises the context.  (Zeros after a view that did not go through the two-launch sampler: options "poisson_queue=0", "fuse_tail=1".) */
 int mvsim_get_queue_stats(mvsim_ctx* ctx, int64_t stats[6]);
 int mvsim_enable_timing(mvsim_ctx* ctx, int enable);

@@ -153,7 +153,8 @@ class Context:
 
     def set_option(self, name: str, value) -> None:
         """Run-time switch of this context (mvsim_set_option): fft_zpass, fft_backend, fft_pad, fused_rotate,
-        poisson_queue, early_sum, graph, fuse_tail, psf_overlap, tail_overlap, attenuate, broadcast."""
+        poisson_queue, poisson_queue_share, early_sum, graph, fuse_tail, psf_overlap, tail_overlap, attenuate, broadcast, view_batch,
+        view_lanes, acq_transfer, host_threads (include/mvsim.h and DESIGN.md list them with their values)."""
         if isinstance(value, bool):
             value = "1" if value else "0"
         _lib.check(self._L.mvsim_set_option(self._h, name.encode(), str(value).encode()))

@@ -113,11 +113,12 @@ struct Options {
                                        // fp64 products (float outputs differ from the serial walk by one ulp on < 1e-6 of the voxels)
     int     poisson_queue = 1;         // 1: two-launch Poisson (streaming kernel with wave-level compaction + work-queue
                                        // resolver, production), 0: one kernel
-    int     poisson_queue_share = 0;   // sixteenths of a block's voxels its queue segment holds.  16: every voxel, 16 B per acquired voxel
-                                       // (2.25 GiB at 512^3, 34 GB at 2048^2 x 512), nothing ever refused; less: what a full segment refuses is
-                                       // sampled where it stands by a third kernel, same counts (k_poisson_refused).  0 = auto: 16 for queues of
-                                       // up to 64 MiB (not worth the third launch), else 5 (0.70 GiB at 512^3) and growing to what the
-                                       // context's views turn out to need (the phantom: 3, a volume without an empty voxel: 12)
+    int     poisson_queue_share = 16;  // sixteenths of a block's voxels its queue segment holds.  16 (default): every voxel, 16 B per acquired
+                                       // voxel (2.25 GiB at 512^3, 34 GB at 2048^2 x 512), nothing is ever refused and phase 1 appends without
+                                       // looking.  1..15: smaller segments; the appends check for room (+0.03 ms per 512^3 view) and what a full
+                                       // segment refuses is sampled where it stands by a third kernel, same counts (k_poisson_refused).  0 =
+                                       // "auto": 16 for queues of up to 64 MiB, else 5 (0.70 GiB at 512^3) and growing to what the context's
+                                       // views turn out to need (the phantom: 3, a volume without an empty voxel: 12)
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
     int     exp = 0;                   // experiment bits for A/B runs on one box (tools/): 1 = z pass tiles in plain grid order, 2 = k_zconv_strided wherever its
                                        // geometry allows (without the cost rule of zconv_strided_chunk)

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
                 if (acquired) {
                     float ov[4] = {vv[0], vv[1], vv[2], vv[3]};
                     if (f.noise)
-                        poisson_phase1(vv, valid, idx_row + 4ull * (unsigned long long)q, acq_row + 4ull * (unsigned long long)q, pa,
+                        poisson_phase1<false>(vv, valid, idx_row + 4ull * (unsigned long long)q, acq_row + 4ull * (unsigned long long)q, pa,
                                        &scratch[wave], lane, ov);
                     if (valid) *reinterpret_cast<float4*>(f.acq + acq_row + 4 * q) = make_float4(ov[0], ov[1], ov[2], ov[3]);
                 }

@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void k_extract4(const float* __restrict__ in, 
 //                      every lane starts with real work -- the divergent fp64 code (logs, divisions) no longer
 //                      runs once per voxel slot with 1-in-7 lanes active.
 // Same arithmetic per (voxel, attempt) as poisson_counter: bit-identical counts.
-template <bool ADJUST>
+template <bool ADJUST, bool CHECKED>
 __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict__ in, float* __restrict__ out,
                                                          long long plane4, long long nzo, int inc, int idx_inc,
                                                          const double* __restrict__ scal, float min_value, double mul,
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict
         }
         const float vv[4] = {v.x, v.y, v.z, v.w};
         float ov[4];
-        poisson_phase1(vv, valid, index_offset + 4ull * (unsigned long long)idx4, 4ull * (unsigned long long)o, pa, &scratch[wave], lane, ov);
+        poisson_phase1<CHECKED>(vv, valid, index_offset + 4ull * (unsigned long long)idx4, 4ull * (unsigned long long)o, pa, &scratch[wave], lane, ov);
         if (valid) out4[o] = make_float4(ov[0], ov[1], ov[2], ov[3]);
     }
     __syncthreads();
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void k_extract4_noise2(const float* __restrict
 // that fall inside the plane (scalar loads and stores under a mask; the others enter phase 1 as zeros, which it ignores) --, and the
 // 64 lanes of a wave take 64 consecutive groups of the SAME plane, so that a wave's outputs stay consecutive (what phase 1's pair
 // compaction assumes).  Same arithmetic per (voxel, attempt) as every other form: bit-identical counts.
-template <bool ADJUST>
+template <bool ADJUST, bool CHECKED>
 __global__ __launch_bounds__(256) void k_extract_noise2_any(const float* __restrict__ in, float* __restrict__ out,
                                                             long long plane, long long nzo, int inc, int idx_inc,
                                                             const double* __restrict__ scal, float min_value, double mul,
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(256) void k_extract_noise2_any(const float* __restr
         float ov[4];
         // (output position of component 0; negative for a plane's first group when the plane starts inside it -- the valid components
         // land at non-negative positions all the same, in 64-bit wrap-around arithmetic)
-        poisson_phase1(vv, any, 4ull * g, (unsigned long long)(k * plane + i0), pa, &scratch[wave], lane, ov);
+        poisson_phase1<CHECKED>(vv, any, 4ull * g, (unsigned long long)(k * plane + i0), pa, &scratch[wave], lane, ov);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const long long i = i0 + c;
@@ -1139,13 +1139,15 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
             poisson_geometry(total, qshare, &qblocks, &segcap);
             unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
             PItem* queue = queue_ws ? reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + QCOUNT_BYTES) : nullptr;
-            if (adjust) {
-                hipLaunchKernelGGL((k_extract4_noise2<true>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
-                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, vt);
-            } else {
-                hipLaunchKernelGGL((k_extract4_noise2<false>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc,
-                                   scal, min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, vt);
-            }
+#define MVSIM_LAUNCH_N2(A, C)                                                                                                     \
+    hipLaunchKernelGGL((k_extract4_noise2<A, C>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane / 4, nzo, inc, index_inc, scal, \
+                       min_value, mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, vt)
+            const bool checked = qshare < 16;                 // segments that can fill up: the appends look before they write
+            if (adjust && checked) MVSIM_LAUNCH_N2(true, true);
+            else if (adjust) MVSIM_LAUNCH_N2(true, false);
+            else if (checked) MVSIM_LAUNCH_N2(false, true);
+            else MVSIM_LAUNCH_N2(false, false);
+#undef MVSIM_LAUNCH_N2
             const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream, (unsigned int)plane, (unsigned int)index_inc,
                                   (unsigned long long)index_offset, qshare >= 16 ? 0 : 1, total / 4, 0};
             hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks, gy), dim3(256), 0, s, rjob, vt);
@@ -1171,12 +1173,15 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
         poisson_geometry_any(plane, nzo, qshare, &qblocks, &segcap, &spp);
         unsigned int* qcount = reinterpret_cast<unsigned int*>(queue_ws);
         PItem* queue = queue_ws ? reinterpret_cast<PItem*>(reinterpret_cast<char*>(queue_ws) + QCOUNT_BYTES) : nullptr;
-        if (adjust)
-            hipLaunchKernelGGL((k_extract_noise2_any<true>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, min_value,
-                               mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, spp, vt);
-        else
-            hipLaunchKernelGGL((k_extract_noise2_any<false>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, min_value,
-                               mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, spp, vt);
+#define MVSIM_LAUNCH_ANY(A, C)                                                                                                       \
+    hipLaunchKernelGGL((k_extract_noise2_any<A, C>), dim3(qblocks, gy), dim3(256), 0, s, in, out, plane, nzo, inc, index_inc, scal, min_value, \
+                       mul, k0, k1, stream, (unsigned long long)index_offset, queue, qcount, segcap, spp, vt)
+        const bool checked = qshare < 16;
+        if (adjust && checked) MVSIM_LAUNCH_ANY(true, true);
+        else if (adjust) MVSIM_LAUNCH_ANY(true, false);
+        else if (checked) MVSIM_LAUNCH_ANY(false, true);
+        else MVSIM_LAUNCH_ANY(false, false);
+#undef MVSIM_LAUNCH_ANY
         const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream, (unsigned int)plane, (unsigned int)index_inc,
                               (unsigned long long)index_offset, qshare >= 16 ? 0 : 2, spp * nzo, spp};
         hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks, gy), dim3(256), 0, s, rjob, vt);

@@ -454,8 +454,17 @@ constexpr int QCOUNT_HEADER = QCOUNT_WORDS * POISSON_MAX_BLOCKS;        // word 
 // One LDS atomic hands out the slot AND says whether the segment still has room.  Both words only grow, so once
 // "front + back < segcap" fails for an append it fails for every later one: the accepted fronts and backs are prefixes
 // [0, F) and (segcap - 1 - B, segcap - 1], and two accepted appends never meet (the later one saw the earlier one's word).
+// CHECKED == false: the segment holds every voxel of the block, nothing can be refused, and the append is the one 32-bit LDS atomic on
+// its half of the counter that it has always been (the check costs phase 1 ~310 vector instructions per wave, 11 %: the default queue
+// is the full one).
+template <bool CHECKED>
 __device__ __forceinline__ bool p1_slot(const P1Args& a, bool back, unsigned int& pos)
 {
+    if (!CHECKED) {
+        const unsigned int old = atomicAdd(reinterpret_cast<unsigned int*>(a.ctr) + (back ? 1 : 0), 1u);
+        pos = back ? a.segcap - 1u - old : old;
+        return true;
+    }
     const unsigned long long old = atomicAdd(a.ctr, back ? (1ull << 32) : 1ull);
     const unsigned int f = (unsigned int)old, b = (unsigned int)(old >> 32);
     if (f + b >= a.segcap) {
@@ -533,8 +542,9 @@ __device__ __forceinline__ void p1_push(PItem* slot, unsigned long long out, flo
 
 // (MVSIM_EXP_NOPHILOX / _NOSMALLPUSH / _NOBRIGHT: instruction-attribution builds of tools/attribute_valu.sh -- each removes one
 // part of the work and with it the correctness of the counts; never defined in the product build.)
+template <bool CHECKED>
 __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, unsigned long long index4, unsigned long long out4,
-                                                     const P1Args& a, P1Scratch* ws, int lane, float ov[4])
+                                               const P1Args& a, P1Scratch* ws, int lane, float ov[4])
 {
     int cls[4];
     bool small_any = false;
@@ -563,7 +573,7 @@ __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, un
 #ifndef MVSIM_EXP_NOSMALLPUSH
                 if (!(w[c] < thr)) {
                     unsigned int pos;
-                    if (p1_slot(a, true, pos)) p1_push(a.seg + pos, out4 + (unsigned long long)c, vv[c], w[c], 0u);
+                    if (p1_slot<CHECKED>(a, true, pos)) p1_push(a.seg + pos, out4 + (unsigned long long)c, vv[c], w[c], 0u);
                     else ov[c] = -vv[c];
                 }
 #else
@@ -627,7 +637,7 @@ __device__ __forceinline__ void poisson_phase1(const float vv[4], bool valid, un
                 } else {
                     // (Measured: one LDS atomic per lane is cheaper here than a ballot-aggregated append.)
                     unsigned int pos;
-                    if (p1_slot(a, false, pos)) p1_push(a.seg + pos, out_base + 4u * owner + first + (unsigned long long)e, v, w0, w1);
+                    if (p1_slot<CHECKED>(a, false, pos)) p1_push(a.seg + pos, out_base + 4u * owner + first + (unsigned long long)e, v, w0, w1);
                     else if (e) res.y = -v;                   // refused: the resolver finds it by its sign
                     else res.x = -v;
                 }

@@ -271,7 +271,7 @@ def test_poisson_queue_share_keeps_the_counts(ctx, orc, shape, inc):
             assert np.array_equal(got, want), share
             stats[share] = ctx.queue_stats()
     finally:
-        ctx.set_option("poisson_queue_share", "auto")
+        ctx.set_option("poisson_queue_share", 16)
     full, tight = stats[16], stats[1]
     assert full["refused"] == 0 and full["bright"] + full["inversion"] > 0.3 * want.size
     assert tight["refused"] > 0 and tight["segment_items"] * 8 <= full["segment_items"]
@@ -281,18 +281,18 @@ def test_poisson_queue_share_keeps_the_counts(ctx, orc, shape, inc):
 
 
 def test_poisson_queue_grows_to_what_the_views_need(mvs):
-    """The automatic share: a context starts its queue at 5 sixteenths of the full size (queues above 64 MiB), a view whose blocks have more
+    """Option poisson_queue_share=auto: a context starts its queue at 5 sixteenths of the full size (queues above 64 MiB), a view whose blocks have more
     pending than that still gets the right counts -- the third kernel samples what was refused --, leaves what it would have needed in a
     page-locked word, and the context's NEXT view is given that much: no refusals from then on.  A volume of 5 M voxels with every voxel
     at lambda ~ 11 (about two thirds of them wait for the resolver) against the same counts from a full-size queue."""
     rng = np.random.default_rng(11)
     v = (rng.uniform(10.5, 11.5, size=(160, 176, 176)) / 124.99999999999997).astype(np.float32)
     with mvs.Context(0) as c:
-        c.set_option("poisson_queue_share", 16)
-        want = c.extract_slices(v, 1, 25.0, 99, 1)
+        want = c.extract_slices(v, 1, 25.0, 99, 1)                  # the default: every voxel of a block fits its segment
         full = c.queue_stats()
     assert full["refused"] == 0 and full["bright"] > 0.5 * v.size
     with mvs.Context(0) as c:                                      # a fresh context: nothing learned yet
+        c.set_option("poisson_queue_share", "auto")
         first = c.extract_slices(v, 1, 25.0, 99, 1)
         st1 = c.queue_stats()
         second = c.extract_slices(v, 1, 25.0, 99, 1)
@@ -323,7 +323,7 @@ def test_poisson_queue_share_in_whole_views(ctx, synth):
                 if share == 1:
                     assert ctx.queue_stats()["refused"] > 0
         finally:
-            ctx.set_option("poisson_queue_share", "auto")
+            ctx.set_option("poisson_queue_share", 16)
         for a, b in zip(res[16], res[1]):
             assert np.array_equal(a, b)
 

@@ -8,7 +8,7 @@ fi
 i=0
 for o in "$@"; do
   i=$((i+1))
-  MVSIM_OPTIONS="$o" python bench.py --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams > gpurun_out/ab_$i.log 2>&1 || { tail -5 gpurun_out/ab_$i.log; exit 1; }
+  MVSIM_OPTIONS="$o" python bench.py --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-compact-queue-leg > gpurun_out/ab_$i.log 2>&1 || { tail -5 gpurun_out/ab_$i.log; exit 1; }
   python - "$o" gpurun_out/ab_$i.log <<'PY'
 import json, sys
 for l in open(sys.argv[2]):

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
 # --serial: the library's default overlaps off, one kernel at a time, so that per-kernel durations add up to the stage times
-BENCH="bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg --no-main-iteration --no-small-views"
+BENCH="bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg --no-main-iteration --no-small-views --no-compact-queue-leg"
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o run -- python3 $BENCH --steps 1 --warmup 1 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o run -- python3 $BENCH --steps 1 --warmup 1 > $O/write.log 2>&1
 python3 tools/pmc_traffic.py $O/fetch $O/write 16 --json $O/traffic.json > $O/pmc_hbm_traffic.txt
@@ -34,7 +34,7 @@ echo "counters done"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $O/sq -o run -- python3 $BENCH --steps 1 --warmup 1 > $O/sq.log 2>&1
 python3 tools/pmc_sq_report.py $O/sq > $O/sq_counters.txt
 # the whole iteration of main's loop (mvsim_simulate_iteration_dev): the rotate-back kernels and makeIsotropic
-rocprofv3 --kernel-trace --stats -d $O/trace_it -o run -- python3 bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg --no-small-views > $O/trace_it.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace_it -o run -- python3 bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg --no-small-views --no-compact-queue-leg > $O/trace_it.log 2>&1
 python3 tools/kstats.py $O/trace_it 24 $O/main_iteration_kernel_stats.csv > $O/main_iteration_kernel_stats.txt
 echo "iteration trace done"
 # HBM traffic of the views of BASELINE configs[3] and configs[4]: same two counter passes, one view at a time
@@ -48,6 +48,7 @@ echo "iteration trace done"
   done
 } > $O/other_sizes_traffic.txt 2>/dev/null
 python3 tools/small_views.py c0 ref 256 64 lanes=1,4 > $O/small_views.txt 2>/dev/null
+python3 tools/queue_share.py 512 > $O/queue_share.txt 2>/dev/null
 {
   python3 tools/view_time.py 128 128 128 15 15 15 1
   python3 tools/view_time.py 289 289 289 51 51 51 3
