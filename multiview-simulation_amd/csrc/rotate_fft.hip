@@ -44,7 +44,8 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
     extern __shared__ __align__(16) float2 lds[];
     float2* rowbuf = lds;                                         // [2][G * U][LP]
     float2* tw = lds + 2 * G * U * LP;                            // [M]
-    RowGeoF* geo = reinterpret_cast<RowGeoF*>(tw + M + (M & 1));  // 16-byte aligned: 2 U LP + M (+1) float2 is a multiple of 2
+    float2* twx_l = tw + M + (M & 1);                             // [M + 1] (+1): the post-processing twiddles, read by every row of the plane
+    RowGeoF* geo = reinterpret_cast<RowGeoF*>(twx_l + (M + 1) + ((M + 1) & 1));  // 16-byte aligned: every part above is a multiple of 2 float2
     int* bclass = reinterpret_cast<int*>(geo + GEO_CHUNK_F);
     // [2][G][16 waves]: bit u set = the wave's 64 columns of row u of that batch hold a non-zero value (see flush_round)
     unsigned int* wmask = reinterpret_cast<unsigned int*>(bclass + GEO_CHUNK_F / U);
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
     const int pos_l = (active && x >= 1 && x <= p.halo_l) ? Px - x : -1;
     const int gap_lo = nx + p.halo_r, gap_len = Px - p.halo_l - gap_lo;
     for (int i = x; i < M; i += (int)blockDim.x) tw[i] = p.twg[i];
+    for (int i = x; i <= M; i += (int)blockDim.x) twx_l[i] = p.twx[i];
 
     // one row, owned by the calling wave: transform, post-process to the half spectrum, store (k_fft_x_r2c's arithmetic)
     auto transform_store = [&](float2* wbuf, int y) {
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
                 const float2 zk = wbuf[k];
                 const float2 zm = cconj(wbuf[k == 0 ? 0 : M - k]);
                 const float2 sm = cadd(zk, zm), d = csub(zk, zm);
-                const float2 wd = cmul(p.twx[k], d);
+                const float2 wd = cmul(twx_l[k], d);
                 const float2 t = make_float2(wd.y, -wd.x);
                 lo[h] = cadd(sm, t);
                 hi[h] = cconj(csub(sm, t));
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
                 const float2 zk = wbuf[k == M ? 0 : k];
                 const float2 zm = cconj(wbuf[k == 0 ? 0 : M - k]);
                 const float2 sm = cadd(zk, zm), d = csub(zk, zm);
-                const float2 wd = cmul(p.twx[k], d);
+                const float2 wd = cmul(twx_l[k], d);
                 drow[k] = cadd(sm, make_float2(wd.y, -wd.x));
             } else {
                 drow[M + 1 + (u - nmid)] = make_float2(0.f, 0.f);
@@ -376,7 +378,7 @@ static int launch_rot_fftx_t(mvsim_ctx* ctx, const RotFftArgs& a, bool write_out
     constexpr int M = PLAN::len;
     const int waves = (a.nx + 63) / 64;
     const int G = waves > 8 ? 2 : 1;
-    const size_t lds = (size_t)(2 * G * UF * (M + 1) + M + (M & 1)) * sizeof(float2) + (size_t)geo_chunk_f(G) * sizeof(RowGeoF) +
+    const size_t lds = (size_t)(2 * G * UF * (M + 1) + M + (M & 1) + (M + 1) + ((M + 1) & 1)) * sizeof(float2) + (size_t)geo_chunk_f(G) * sizeof(RowGeoF) +
                        (size_t)(geo_chunk_f(G) / UF) * sizeof(int) + (size_t)(2 * G * 16 + 4) * sizeof(unsigned int);
     if (lds > 160 * 1024) { set_error("fused rotate + x transform: %zu bytes of LDS", lds); return MVSIM_EINVAL; }
     dim3 grid((unsigned)((a.nz + 7) / 8 * 8)), block((unsigned)(waves * 64));
