@@ -144,6 +144,8 @@ void k_fft_lines(LinesArgs p)
                 const int sn = map_src(p.lmap, n);
                 if (sn >= 0) v[it] = *reinterpret_cast<const float4*>(sbase + sn * p.src_es);
             } else if (n < p.gap_lo || n >= p.gap_hi) {
+                // (the compiler waits for the tile's FIRST row before it requests the second -- the merge of loaded and zero registers behind
+                // this branch costs it a register copy --; without the branch, all rows requested at once, passes B and D measured the same)
                 const int sn = p.src_mirror ? map_src(p.lmap, n) : n;
                 v[it] = *reinterpret_cast<const float4*>(sbase + line_off(sn, p.src_es, p.src_blk));
             }
@@ -435,7 +437,13 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     constexpr size_t SCR_OFF = ((size_t)(NR * LP + M) * sizeof(float2) + 34 * sizeof(double) + 15) & ~(size_t)15;
     P1Scratch* scratch = reinterpret_cast<P1Scratch*>(reinterpret_cast<char*>(lds) + SCR_OFF);
     if (FUSE && tid == 0) { *qctr = 0ull; qovf[0] = 0u; qovf[1] = 0u; }
-    for (int i = tid; i < M; i += T) tw[i] = twg[i];
+    // Every global load of the wave -- its share of the transform's twiddle table, the plane flags of its rows, the rows themselves and
+    // the post-processing twiddles of its items -- is requested before anything waits: requested where they are used, they made a chain
+    // of five dependent round trips to the caches in a block that lives for a few microseconds.
+    constexpr int TWN = (M + T - 1) / T;
+    float2 twreg[TWN];
+#pragma unroll
+    for (int n = 0; n < TWN; ++n) { const int i = tid + n * T; twreg[n] = i < M ? twg[i] : make_float2(0.f, 0.f); }
     const long long row0 = (long long)blockIdx.x * NR + wave * LW;           // output rows (y < ny, z < nz)
 
     // Pre-process in symmetric pairs.  With A = X[k], B = conj X[M-k], s = A + B, d = A - B, t = i w_P^{-k} d:
@@ -447,25 +455,37 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
     constexpr int ITEMS = LW * HQ;
     constexpr int HIT = (ITEMS + 63) / 64;
     long long offs[LW];
+    int rowflag[LW];                                  // the plane flag of each of the wave's rows, all requested before the first is looked at
+    int zrow_[LW];
 #pragma unroll
     for (int j = 0; j < LW; ++j) {
         const long long row = row0 + j;
-        offs[j] = -1;
-        if (row < rows) {
-            const unsigned urow = (unsigned)row;      // rows = Ny*Nz < 2^31
-            const int z = (int)(urow / (unsigned)ny), y = (int)(urow - (unsigned)z * (unsigned)ny);
-            offs[j] = ((long long)z * py + y) * hxp;
-            // a row of an empty plane is a row of zeros -- not read (nobody wrote it), transformed to zeros
-            if (em.flags && em.flags[__builtin_amdgcn_readfirstlane(z) * em.stride] == 0) offs[j] = -1;   // (a wave's rows are wave-uniform: scalar load)
-        }
+        const bool live = row < rows;
+        const unsigned urow = live ? (unsigned)row : 0u;             // rows = Ny*Nz < 2^31
+        const int z = (int)(urow / (unsigned)ny), y = (int)(urow - (unsigned)z * (unsigned)ny);
+        offs[j] = live ? ((long long)z * py + y) * hxp : -1;
+        zrow_[j] = __builtin_amdgcn_readfirstlane(z);                // (a wave's rows are wave-uniform)
+        rowflag[j] = 1;
     }
+    if (em.flags) {
+        // scalar loads without a branch between them: they leave together
+#pragma unroll
+        for (int j = 0; j < LW; ++j) rowflag[j] = em.flags[zrow_[j] * em.stride];
+    }
+    // a row of an empty plane is a row of zeros -- not read (nobody wrote it), transformed to zeros
+#pragma unroll
+    for (int j = 0; j < LW; ++j)
+        if (rowflag[j] == 0) offs[j] = -1;
     // every row of this wave lies in an empty plane (wave-uniform): nothing to read or transform, its outputs are zeros
     bool wave_empty = !FUSE && em.flags != nullptr;
 #pragma unroll
     for (int j = 0; j < LW; ++j) wave_empty = wave_empty && (offs[j] < 0);
+    constexpr int NMID = M - 4 * HQ + 1;             // middle elements not covered by the pairs (k = M/2 when M % 4 == 0)
+    static_assert(LW * NMID <= 64, "one lane per middle element");
     if (!wave_empty) {
-    float4 xa[HIT];
-    float2 xb0[HIT], xb1[HIT];
+    float4 xa[HIT], xw[HIT];                          // X[2q], X[2q+1] and the twiddles w^{2q}, w^{2q+1} of the item
+    Pair16 xb[HIT];                                   // X[M-2q-1], X[M-2q]: adjacent too, one 16-byte load at 8-byte alignment
+    bool live_item[HIT];
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
         const int e = lane + it * 64;
@@ -473,15 +493,29 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
         long long off = -1;
 #pragma unroll
         for (int jj = 0; jj < LW; ++jj) off = (j == jj) ? offs[jj] : off;
-        xa[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        xb0[it] = xb1[it] = make_float2(0.f, 0.f);
-        if (off >= 0 && e < ITEMS) {
-            const float2* __restrict__ sp = srcc + off;
-            xa[it] = *reinterpret_cast<const float4*>(sp + 2 * q);   // X[2q], X[2q+1]
-            xb0[it] = sp[M - 2 * q];                                   // X[M-2q]
-            xb1[it] = sp[M - 2 * q - 1];                               // X[M-2q-1] (the compiler merges the pair into one 16-byte load)
-        }
+        // no branch around the loads (a merge of loaded and zero registers behind one made the compiler wait for the data at once): a
+        // dead item -- a row of an empty plane, a lane beyond the items -- reads the first elements of the buffer and is zeroed below
+        const bool item = off >= 0 && e < ITEMS;
+        live_item[it] = item;
+        const int ql = item ? q : 0;
+        const float2* __restrict__ sp = srcc + (item ? off : 0);
+        xw[it] = *reinterpret_cast<const float4*>(twx + 2 * (e < ITEMS ? q : 0));
+        xa[it] = *reinterpret_cast<const float4*>(sp + 2 * ql);      // X[2q], X[2q+1]
+        xb[it] = *reinterpret_cast<const Pair16*>(sp + M - 2 * ql - 1);
     }
+    // ... and the middle elements, one per lane
+    const int mj = lane / NMID, mk = 2 * HQ + (lane - mj * NMID);
+    const bool mid = lane < LW * NMID && mk < M;
+    long long moff = -1;
+#pragma unroll
+    for (int jj = 0; jj < LW; ++jj) moff = (mj == jj) ? offs[jj] : moff;
+    const bool mid_row = mid && moff >= 0;
+    const int mkl = mid_row ? mk : 0;                                 // (no branch around these loads either)
+    const float2* __restrict__ msp = srcc + (mid_row ? moff : 0);
+    const float2 ma = msp[mkl], mb = msp[M - mkl], mw = twx[mkl];
+    // the transform's twiddles go to LDS now that everything is under way (the barrier below covers them)
+#pragma unroll
+    for (int n = 0; n < TWN; ++n) { const int i = tid + n * T; if (i < M) tw[i] = twreg[n]; }
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
         const int e = lane + it * 64;
@@ -491,34 +525,31 @@ __global__ __launch_bounds__(CfgX<PLAN::len>::T) void k_fft_x_c2r(const float2* 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = 2 * q + h;
-                const float2 a = h == 0 ? make_float2(xa[it].x, xa[it].y) : make_float2(xa[it].z, xa[it].w);
-                const float2 b = cconj(h == 0 ? xb0[it] : xb1[it]);
+                float2 a = h == 0 ? make_float2(xa[it].x, xa[it].y) : make_float2(xa[it].z, xa[it].w);
+                float2 b = cconj(h == 0 ? make_float2(xb[it].c, xb[it].d) : make_float2(xb[it].a, xb[it].b));
+                if (!live_item[it]) { a = make_float2(0.f, 0.f); b = make_float2(0.f, 0.f); }
                 const float2 sm = cadd(a, b), d = csub(a, b);
-                const float2 wd = cmul(cconj(twx[k]), d);                  // w^{-k} d
+                const float2 wk = h == 0 ? make_float2(xw[it].x, xw[it].y) : make_float2(xw[it].z, xw[it].w);
+                const float2 wd = cmul(cconj(wk), d);                       // w^{-k} d
                 const float2 t = make_float2(-wd.y, wd.x);                  // i w^{-k} d
                 zrow[k] = cconj(cadd(sm, t));                               // dead rows were loaded as zeros
                 if (k > 0) zrow[M - k] = csub(sm, t);
             }
         }
     }
-    // middle elements not covered by the pairs (k = M/2 when M % 4 == 0): generic, straight from HBM
-    constexpr int NMID = M - 4 * HQ + 1;
-    for (int e = lane; e < LW * NMID; e += 64) {
-        const int j = e / NMID, k = 2 * HQ + (e - j * NMID);
-        if (k >= M) continue;
-        long long off = -1;
-#pragma unroll
-        for (int jj = 0; jj < LW; ++jj) off = (j == jj) ? offs[jj] : off;
+    if (mid) {
         float2 zk = make_float2(0.f, 0.f);
-        if (off >= 0) {
-            const float2* __restrict__ sp = srcc + off;
-            const float2 a = sp[k], b = cconj(sp[M - k]);
+        if (mid_row) {
+            const float2 a = ma, b = cconj(mb);
             const float2 sm = cadd(a, b), d = csub(a, b);
-            const float2 wd = cmul(cconj(twx[k]), d);
+            const float2 wd = cmul(cconj(mw), d);
             zk = cconj(cadd(sm, make_float2(-wd.y, wd.x)));
         }
-        wbuf[j * LP + k] = zk;
+        wbuf[mj * LP + mk] = zk;
     }
+    } else {
+#pragma unroll
+        for (int n = 0; n < TWN; ++n) { const int i = tid + n * T; if (i < M) tw[i] = twreg[n]; }
     }
     __syncthreads();                                  // twiddle table complete (rows are wave-private)
     if (!wave_empty) PLAN::template run<LW>(wbuf, tw, lane);
@@ -787,6 +818,18 @@ __device__ __forceinline__ bool zconv_tile(const ZConvArgs& p, int& chunk, int& 
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// The z pass loads its tile without a branch around any load: behind `if (row wanted) v = load` the compiler merges the loaded registers
+// with the zeros of the other path, pays for that with a register copy -- and a wait for the tile's FIRST row before the second is
+// requested (and again before the sum's weights): two extra trips to memory in a block that lives for 12 us.  A row that is not wanted
+// (padding, past the end, an empty plane -- nobody wrote it) reads the tile's column in the first plane instead (a cache hit) and is cleared
+// with this mask; an AND, not a select -- a select whose operand is a load is turned back into the branch.
+__device__ __forceinline__ float4 zconv_keep4(float4 t, bool keep)
+{
+    const unsigned int m = keep ? 0xFFFFFFFFu : 0u;
+    return make_float4(__uint_as_float(__float_as_uint(t.x) & m), __uint_as_float(__float_as_uint(t.y) & m),
+                       __uint_as_float(__float_as_uint(t.z) & m), __uint_as_float(__float_as_uint(t.w) & m));
+}
+
 constexpr int TNIT = 64 / ZRPI;                       // kzp <= 64 rows of taps
 
 // One block per tile = (z chunk, 16-column group, row ky): grid (chunks, Hxp/16, Py) -- the chunks of a column are
@@ -872,18 +915,17 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv(ZConvArgs p)
 #pragma unroll
     for (int it = 0; it < ZNIT; ++it) {
         const int r = (tid / ZLPR) + it * ZRPI;
-        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r >= padf && r < rows && ((rowbits[it] >> (tid / ZLPR)) & 1u)) {
-            int z = p.z_out0 + zc0 + (r - padf) - hl;
-            if ((unsigned)z >= (unsigned)p.nz_global) z = mirror_index(z, p.nz_global);
-            v[it] = *reinterpret_cast<const float4*>(p.src + (long long)(z - p.z_in0) * p.zs + scol + c2);
-        }
+        const bool want = r >= padf && r < rows && ((rowbits[it] >> (tid / ZLPR)) & 1u);
+        int z = p.z_out0 + zc0 + (r - padf) - hl;
+        if ((unsigned)z >= (unsigned)p.nz_global) z = mirror_index(z, p.nz_global);
+        const long long zo = want ? (long long)(z - p.z_in0) * p.zs : 0ll;
+        v[it] = zconv_keep4(*reinterpret_cast<const float4*>(p.src + zo + scol + c2), want);
     }
 #pragma unroll
     for (int it = 0; it < TNIT; ++it) {
         const int r = (tid / ZLPR) + it * ZRPI;
-        tv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < p.kz) tv[it] = *reinterpret_cast<const float4*>(p.taps + (long long)r * p.zs + tcol + c2);
+        const bool want = r < p.kz;
+        tv[it] = zconv_keep4(*reinterpret_cast<const float4*>(p.taps + (long long)(want ? r : 0) * p.zs + tcol + c2), want);
     }
     // the sum's weights travel with the tile (requested in the epilogue they cost a block 1-4 k cycles of exposed latency: clock stamps)
     double2 wxa = make_double2(0.0, 0.0), wyb = make_double2(0.0, 0.0);
@@ -1065,18 +1107,17 @@ __global__ __launch_bounds__(ZT, ZBLOCKS_PER_CU) void k_zconv_strided(ZConvArgs 
 #pragma unroll
     for (int it = 0; it < ZNIT; ++it) {
         const int r = (tid / ZLPR) + it * ZRPI;
-        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r >= padf && r < rows && ((rowbits[it] >> (tid / ZLPR)) & 1u)) {
-            int z = p.z_out0 + zc0 + (r - padf) - hl;
-            if ((unsigned)z >= (unsigned)p.nz_global) z = mirror_index(z, p.nz_global);
-            v[it] = *reinterpret_cast<const float4*>(p.src + (long long)(z - p.z_in0) * p.zs + scol + c2);
-        }
+        const bool want = r >= padf && r < rows && ((rowbits[it] >> (tid / ZLPR)) & 1u);
+        int z = p.z_out0 + zc0 + (r - padf) - hl;
+        if ((unsigned)z >= (unsigned)p.nz_global) z = mirror_index(z, p.nz_global);
+        const long long zo = want ? (long long)(z - p.z_in0) * p.zs : 0ll;
+        v[it] = zconv_keep4(*reinterpret_cast<const float4*>(p.src + zo + scol + c2), want);
     }
 #pragma unroll
     for (int it = 0; it < TNIT; ++it) {
         const int r = (tid / ZLPR) + it * ZRPI;
-        tv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < p.kz) tv[it] = *reinterpret_cast<const float4*>(p.taps + (long long)r * p.zs + tcol + c2);
+        const bool want = r < p.kz;
+        tv[it] = zconv_keep4(*reinterpret_cast<const float4*>(p.taps + (long long)(want ? r : 0) * p.zs + tcol + c2), want);
     }
     // the sum's weights travel with the tile (requested in the epilogue they cost a block 1-4 k cycles of exposed latency: clock stamps)
     double2 wxa = make_double2(0.0, 0.0), wyb = make_double2(0.0, 0.0);
