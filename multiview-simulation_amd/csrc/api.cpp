@@ -68,8 +68,8 @@ int parse_option(Options& o, const char* name, const char* value)
     }
     if (n == "early_sum") return flag(&o.early_sum);
     if (n == "zconv_strided") return flag(&o.zconv_strided);
-    if (n == "exp") {                                  // A/B bits of tools/ and the tests (common.h): 0 .. 3
-        if (v.size() != 1 || v[0] < '0' || v[0] > '3') return MVSIM_EINVAL;
+    if (n == "exp") {                                  // A/B bits of tools/ and the tests (common.h): 0 .. 7
+        if (v.size() != 1 || v[0] < '0' || v[0] > '7') return MVSIM_EINVAL;
         o.exp = v[0] - '0';
         return MVSIM_OK;
     }
@@ -625,6 +625,7 @@ int mvsim_release_caches(mvsim_ctx* ctx)
     ctx->vol_a.release(); ctx->vol_b.release(); ctx->vol_c.release(); ctx->out_buf.release();
     ctx->pqueue.release(); ctx->psf_dev.release(); ctx->view_tab.release(); ctx->sync_u16.release(); ctx->stencil_psf.release(); ctx->sphere_list.release(); ctx->weight_img.release(); ctx->weight_dim[0] = 0; ctx->plane_flags.release();
     ctx->host_gt.release(); ctx->host_rot.release(); ctx->host_att.release(); ctx->host_con.release();
+    if (ctx->sync_u16_host) { (void)hipHostFree(ctx->sync_u16_host); ctx->sync_u16_host = nullptr; ctx->sync_u16_host_bytes = 0; }
     return MVSIM_OK;
 }
 
@@ -1244,10 +1245,21 @@ static int views_enqueue_batched(mvsim_ctx* ctx, const float* gt, const int64_t 
     }
     // Tools.normImage of the V PSFs (in place, Q5) and their copy into the upload block: one host thread per view -- a 51^3 stack is 0.13 ms of
     // summation and division, and nothing reaches the GPU before the last of them is done
-    HostPool::get().run(V, host_threads_of(ctx), [&](int v) {
+    //  -- unless two views name the same (or overlapping) PSF memory, e.g. `[psf] * 8`: n sequential calls normalise that buffer n
+    // times one after the other, and so does this: in view order on the calling thread, each view taking the taps as they are at its turn
+    auto psf_stage = [&](int v) {
         psf_normalise_host(psf_host[v], k3);
         std::memcpy(hp + off_p + (size_t)v * k3 * sizeof(float), psf_host[v], (size_t)k3 * sizeof(float));
-    });
+    };
+    bool psf_aliased = false;
+    for (int v = 0; v < V && !psf_aliased; ++v)
+        for (int w = v + 1; w < V; ++w) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(psf_host[v]), b = reinterpret_cast<uintptr_t>(psf_host[w]);
+            const uintptr_t len = (uintptr_t)k3 * sizeof(float);
+            if (a < b + len && b < a + len) { psf_aliased = true; break; }
+        }
+    if (psf_aliased) for (int v = 0; v < V; ++v) psf_stage(v);
+    else HostPool::get().run(V, host_threads_of(ctx), psf_stage);
     MVSIM_HIP(hipMemcpyAsync(dp, hp, up_bytes, hipMemcpyHostToDevice, ctx->stream));
     MVSIM_HIP(hipEventRecord(ctx->pinned.ev[slot], ctx->stream));
     ctx->pinned.busy[slot] = true;
@@ -1326,12 +1338,14 @@ int mvsim_simulate_views_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[
         return MVSIM_OK;
     }
     while ((int)ctx->lanes.size() < nl) {
-        mvsim_ctx* lane = nullptr;
-        MVSIM_TRY(mvsim_create(ctx->device, &lane));
-        lane->is_lane = true;
-        ctx->lanes.push_back(lane);
+        // the event first: lanes and lane_done grow together or not at all
         hipEvent_t e = nullptr;
         MVSIM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        mvsim_ctx* lane = nullptr;
+        const int lrc = mvsim_create(ctx->device, &lane);
+        if (lrc != MVSIM_OK) { (void)hipEventDestroy(e); return lrc; }
+        lane->is_lane = true;
+        ctx->lanes.push_back(lane);
         ctx->lane_done.push_back(e);
     }
     if (!ctx->ev_lane_fork) MVSIM_HIP(hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming));
@@ -1990,26 +2004,28 @@ int mvsim_simulate_views(mvsim_ctx* ctx, const float* gt_host, const int64_t dim
     std::vector<char> as16((size_t)n_views, 0);
     for (int v = 0; v < n_views; ++v) { as16[(size_t)v] = (ctx->opt.acq_u16 != 0 && params[v].snr >= 0.0f) ? 1 : 0; any16 = any16 || as16[(size_t)v]; }
     if (any16) {
-        MVSIM_TRY(ctx->async_u16[0].reserve(u16_bytes));
-        if (ctx->async_u16_host_bytes[0] < u16_bytes) {
-            if (ctx->async_u16_host[0]) { (void)hipHostFree(ctx->async_u16_host[0]); ctx->async_u16_host[0] = nullptr; ctx->async_u16_host_bytes[0] = 0; }
-            MVSIM_HIP(hipHostMalloc(&ctx->async_u16_host[0], u16_bytes, hipHostMallocDefault));
-            ctx->async_u16_host_bytes[0] = u16_bytes;
+        // the synchronous staging pair (down_counts' own): mvsim_destroy / mvsim_release_caches free it whether or not the pipelined
+        // entry points ever set their slots up (the async slots leaked from a context that only came through here)
+        MVSIM_TRY(ctx->sync_u16.reserve(u16_bytes));
+        if (ctx->sync_u16_host_bytes < u16_bytes) {
+            if (ctx->sync_u16_host) { (void)hipHostFree(ctx->sync_u16_host); ctx->sync_u16_host = nullptr; ctx->sync_u16_host_bytes = 0; }
+            MVSIM_HIP(hipHostMalloc(&ctx->sync_u16_host, u16_bytes, hipHostMallocDefault));
+            ctx->sync_u16_host_bytes = u16_bytes;
         }
-        char* d16 = ctx->async_u16[0].as<char>();
+        char* d16 = ctx->sync_u16.as<char>();
         MVSIM_HIP(hipMemsetAsync(d16 + flags_at, 0, (size_t)n_views * sizeof(unsigned int), ctx->stream));
         for (int v = 0; v < n_views; ++v)
             if (as16[(size_t)v])
                 MVSIM_TRY(launch_pack_u16(ctx->stream, outs[(size_t)v].acq, reinterpret_cast<unsigned short*>(d16 + off16[(size_t)v]), cnt[(size_t)v],
                                           reinterpret_cast<unsigned int*>(d16 + flags_at) + v));
-        MVSIM_HIP(hipMemcpyAsync(ctx->async_u16_host[0], d16, u16_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MVSIM_HIP(hipMemcpyAsync(ctx->sync_u16_host, d16, u16_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
     for (int v = 0; v < n_views; ++v)
         if (!as16[(size_t)v])
             MVSIM_HIP(hipMemcpyAsync(acq_host[v], outs[(size_t)v].acq, (size_t)cnt[(size_t)v] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
     if (any16) {
-        const char* h16 = reinterpret_cast<const char*>(ctx->async_u16_host[0]);
+        const char* h16 = reinterpret_cast<const char*>(ctx->sync_u16_host);
         const unsigned int* flags = reinterpret_cast<const unsigned int*>(h16 + flags_at);
         struct Job { const unsigned short* src; float* dst; long long n; };
         std::vector<Job> jobs;

@@ -64,6 +64,7 @@ struct LinesArgs {
     const double2* wx;
     const double2* wy;
     double*       sum_partial;
+    int           pair_tiles;       // 8-column tiles: the two tiles of a 128-byte line on one XCD (see k_fft_lines; option `pair_tiles`, default 1)
 };
 
 #ifndef MVSIM_ZBS
@@ -110,7 +111,22 @@ void k_fft_lines(LinesArgs p)
     const int r0 = tid / LPR;
     float2* wbuf = buf + wave * LW * LP;    // the lines this wave transforms
     // all global loads of the tile are issued before anything waits
-    const int by = (int)blockIdx.y >= p.outer_skip_lo ? (int)blockIdx.y + p.outer_skip_len : (int)blockIdx.y;
+    // Which tile this block takes.  Tiles of 8 columns (the long lines: L > 576) move 64-BYTE row segments, i.e. two neighbouring tiles
+    // share every 128-byte line they read and write.  In plain grid order those two blocks have consecutive ids, which the dispatcher
+    // hands to DIFFERENT XCDs: both L2s fetch the whole line for their half (measured at 1024^3, profiles/r05_pmc_hbm_traffic_1024.txt
+    // and tools/microbench/fetch_calib.hip: passes B and D read 2.0-2.1 x the bytes they need, TCC_EA0_RDREQ_128B = 2 per line, every
+    // half-line write misses).  So the pair goes to ONE XCD, one directly behind the other in that XCD's dispatch order (ids b and
+    // b + 8): the second half hits the line the first one brought in, and the two half-line writes meet in one L2 before they leave.
+    int tile_x = (int)blockIdx.x, tile_o = (int)blockIdx.y;
+    if constexpr (NL * sizeof(float2) < 128) {
+        const unsigned nt = gridDim.x, total = nt * gridDim.y, b = blockIdx.y * nt + blockIdx.x;
+        if ((nt & 1u) == 0 && b < (total & ~15u) && p.pair_tiles) {
+            const unsigned xcd = b & 7u, slot = b >> 3;
+            const unsigned lin = ((((slot >> 1) << 3) + xcd) << 1) | (slot & 1u);
+            tile_x = (int)(lin % nt); tile_o = (int)(lin / nt);
+        }
+    }
+    const int by = tile_o >= p.outer_skip_lo ? tile_o + p.outer_skip_len : tile_o;
     if (p.nzflags) {
         // block-uniform (one scalar load): nothing of an empty plane is read, transformed or stored -- its readers skip it on the
         // same flags.  Pass B: flags of the input planes; pass D: the dilated flags (a plane of the z pass's output is empty iff
@@ -120,10 +136,10 @@ void k_fft_lines(LinesArgs p)
     auto outer_off = [&](long long outer, long long oblk) {
         return oblk ? (long long)(by >> ZBS) * oblk + (long long)(by & (ZB - 1)) * outer : (long long)by * outer;
     };
-    const float2* sbase = p.src + outer_off(p.src_outer, p.src_oblk) + (long long)blockIdx.x * NL + c2;
+    const float2* sbase = p.src + outer_off(p.src_outer, p.src_oblk) + (long long)tile_x * NL + c2;
     float4 vp[MODE == CONVZ ? NIT : 1];
     if (MODE == CONVZ) {
-        const float2* tbase = p.taps + outer_off(p.taps_outer, p.taps_oblk) + (long long)blockIdx.x * NL + c2;
+        const float2* tbase = p.taps + outer_off(p.taps_outer, p.taps_oblk) + (long long)tile_x * NL + c2;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int n = r0 + it * ROWS;
@@ -185,13 +201,13 @@ void k_fft_lines(LinesArgs p)
         // x PSF spectrum, conjugate, transform again (inverse = conj FFT conj).  The spectrum is stored tile-major
         // (each line contiguous), so the wave that owns a line streams its spectrum line straight into the first
         // radix pass of the second transform: no barrier, no extra trip through LDS.
-        const float2* gl = p.spec + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * NL + (long long)wave * LW) * L;
+        const float2* gl = p.spec + (((long long)tile_o * gridDim.x + tile_x) * NL + (long long)wave * LW) * L;
         PLAN::template run_op<LW>(wbuf, tw, lane, LoadMulConj{gl, L});
     }
     if constexpr (MODE == CONVZ) PLAN::template run_op<LW>(wbuf, tw, lane, LoadMulConjReg<IT1, R1>{ps});
     if (MODE == FWD && p.dst_tile_major) {
         // wave-private store: every line of the tile contiguous (consumed by LoadMulConj above)
-        float2* gl = p.dst + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * NL + (long long)wave * LW) * L;
+        float2* gl = p.dst + (((long long)tile_o * gridDim.x + tile_x) * NL + (long long)wave * LW) * L;
 #pragma unroll
         for (int j = 0; j < LW; ++j)
             for (int n2 = lane * 2; n2 < L; n2 += 128) {
@@ -201,7 +217,7 @@ void k_fft_lines(LinesArgs p)
         return;
     }
     __syncthreads();
-    float2* dbase = p.dst + outer_off(p.dst_outer, p.dst_oblk) + (long long)blockIdx.x * NL + c2;
+    float2* dbase = p.dst + outer_off(p.dst_outer, p.dst_oblk) + (long long)tile_x * NL + c2;
     const int nstore = p.store_limit > 0 ? p.store_limit : L;
     float2 sa = make_float2(0.f, 0.f), sb = make_float2(0.f, 0.f);       // CONVZ: this thread's share of its two lines' sums over z
 #pragma unroll
@@ -227,14 +243,14 @@ void k_fft_lines(LinesArgs p)
             if (tid < NL) {
                 double sre = 0.0, sim = 0.0;
                 for (int r = 0; r < ROWS; ++r) { const float2 q = red[r * NL + tid]; sre += (double)q.x; sim += (double)q.y; }
-                const double2 a = p.wx[(int)blockIdx.x * NL + tid], b = p.wy[by];
+                const double2 a = p.wx[tile_x * NL + tid], b = p.wy[by];
                 const double wr = a.x * b.x - a.y * b.y, wi = a.x * b.y + a.y * b.x;
                 t = sre * wr - sim * wi;                  // Re( s * W )
             }
             if (wave == 0) {
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-                if (lane == 0) p.sum_partial[(long long)blockIdx.y * gridDim.x + blockIdx.x] = t;
+                if (lane == 0) p.sum_partial[(long long)tile_o * gridDim.x + tile_x] = t;
             }
         }
     }
@@ -1442,8 +1458,10 @@ static int c2r_rows_per_block(int M)
     return 0;
 }
 
-static int launch_lines(mvsim_ctx* s, int L, int mode, bool sparse, const LinesArgs& a, int tiles, int nouter)
+static int launch_lines(mvsim_ctx* s, int L, int mode, bool sparse, const LinesArgs& a0, int tiles, int nouter)
 {
+    LinesArgs a = a0;
+    a.pair_tiles = (s->opt.exp & 4) ? 0 : 1;              // exp bit 4: 8-column tiles in plain grid order (A/B, tools/ab_env.sh)
     switch (L) {
 #define X(LL, ...) \
     case LL: return launch_lines_t<Plan<LL, __VA_ARGS__>>(s, mode, sparse, a, tiles, nouter);

@@ -70,13 +70,21 @@ def hourglass_psf(k: int = 63, sigma=(2.5, 2.5, 10.0), tilt_deg: float = 20.0) -
 
 
 def measured_like_psf(k: int = 51) -> np.ndarray:
-    """Stand-in for the reference's shipped PSF stacks (`Angle<k>.tif`: 51^3 float32, peak 0.99 at the centre, sigma about
-    (2.0, 2.2, 6.7) px, ~4 % of the voxels non-zero, not separable): a tilted hour-glass, scaled to peak 0.99 and
-    clipped to zero below 0.5 % of the peak like a background-subtracted measurement.  The GPL data files themselves
-    are not part of this repository."""
-    g = hourglass_psf(k, sigma=(2.0, 2.2, 6.7), tilt_deg=8.0)
-    g = g * np.float32(0.99 / g.max())
-    g[g < 0.005 * 0.99] = 0.0
+    """Stand-in for the reference's shipped PSF stacks (`src/main/resources/Angle<k>.tif`, loaded at
+    SimulateMultiViewDataset.java:579).  What those 18 files are is recorded -- as facts, not pixels -- in
+    `tests/golden/psf_tiff_facts.json` (8 distinct 51^3 float32 stacks, peak 0.99 at (25, 25, 25), minimum 0, fp64 sums 205 .. 303,
+    3.1 .. 4.6 % of the voxels non-zero, second-moment widths sigma_x 1.85 .. 2.15, sigma_y 2.02 .. 2.34, sigma_z 6.41 .. 7.22 px,
+    0.900 .. 0.954 of their energy in the best separable approximation).  A single Gaussian of those widths sums to ~450: the measured
+    stacks have a sharp core on a wide, tilted, not separable skirt.  Hence two tilted hour-glass terms -- a core of sigma (1.2, 1.3,
+    3.5) carrying 77 % of the peak and a skirt of (2.4, 2.6, 8.0), both tilted 10 degrees in the y-z plane --, scaled to peak 0.99 and
+    clipped to zero below 0.5 % of the peak like a background-subtracted measurement: sigma (2.15, 2.28, 6.53), sum 235, 3.3 % non-zero,
+    rank-1 energy 0.940 at k = 51 -- every figure inside the range of the real stacks (checked by
+    tests/test_host_logic.py::test_reference_psf_stacks_through_tiffio).  The GPL data files themselves are not part of this repository."""
+    core = hourglass_psf(k, sigma=(1.2, 1.3, 3.5), tilt_deg=10.0).astype(np.float64)
+    skirt = hourglass_psf(k, sigma=(2.4, 2.6, 8.0), tilt_deg=10.0).astype(np.float64)
+    g = 0.766 * core + (1.0 - 0.766) * skirt
+    g = (g * (0.99 / g.max())).astype(np.float32)
+    g[g < np.float32(0.005 * 0.99)] = 0.0
     return np.ascontiguousarray(g, dtype=np.float32)
 
 

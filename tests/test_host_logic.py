@@ -3,6 +3,7 @@ import ctypes
 import importlib
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -156,6 +157,51 @@ def test_tiff_reader_and_imagej_writer_round_trip(mvs, synth, tmp_path):
     plane_f = str(tmp_path / "plane.tif")
     mvs.Tools.save(psf[7], plane_f)                                              # 2-D image -> single-plane TIFF
     assert np.array_equal(mvs.Tools.open(plane_f)[0], psf[7])
+
+
+def test_reference_psf_stacks_through_tiffio(synth):
+    """The only data the reference holds for the path: the 18 measured PSF stacks `src/main/resources/Angle*.tif`, loaded through
+    `Tools.open(file, true)` = read + makeSquare (Tools.java:297-349) at SimulateMultiViewDataset.java:579.  The files are GPL data
+    and stay in /root/reference; `tests/golden/psf_tiff_facts.json` holds FACTS about them derived through this repository's reader
+    (`tests/golden/make_psf_tiff_facts.py`).  Where the reference is present (the build container) every fact is re-derived from the
+    files and must equal the JSON -- including that `tiffio.save_tiff` reproduces all 18 files BYTE FOR BYTE from the decoded pixels
+    and the description's display range (the writer = Tools.save, Tools.java:88-105) and that an independent numpy decode agrees with
+    `tiffio.open_tiff`.  Everywhere (the GPU box has no /root/reference) the JSON must be self-consistent, and the synthetic stand-in
+    the tests use instead of the files must lie inside the range the real stacks span."""
+    import json
+    gold = os.path.join(ROOT, "tests", "golden")
+    rec = json.load(open(os.path.join(gold, "psf_tiff_facts.json")))
+    files = rec["files"]
+    assert len(files) == 18 and rec["distinct_contents"] == len(rec["identical_pixel_groups"]) == 8
+    assert sorted(n for g in rec["identical_pixel_groups"] for n in g) == sorted(files)
+    for g in rec["identical_pixel_groups"]:
+        assert len({files[n]["pixels_sha256"] for n in g}) == 1
+    assert len({f["pixels_sha256"] for f in files.values()}) == 8
+    for name, f in files.items():
+        assert f["dims_xyz"] == [51, 51, 51] and f["byte_order"] == "big" and f["ifds"] == 51, name
+        assert f["peak_index_xyz"] == [25, 25, 25] and f["max"] == float(np.float32(0.99)) and f["min"] == 0.0, name   # peak at K/2 (SURVEY A.3)
+        assert f["independent_decode_equal"] and f["save_tiff_reproduces_file"] and f["make_square_is_identity"], name
+        # ImageJ's stack layout: header 8 + first IFD (2 + 11 * 12 + 4) + description, then the planes back to back
+        desc = "".join(f"{k}={f['description'][k]}\n" for k in ("ImageJ", "images", "slices", "loop", "min", "max"))
+        assert f["first_strip_offset"] == 8 + 138 + len(desc) + 1, name
+        assert f["file_bytes"] == f["first_strip_offset"] + 51 * 51 * 51 * 4 + 50 * 138, name
+    r, s = rec["ranges_over_the_files"], rec["stand_in"]
+    for key, vals in (("sum_f64", [f["sum_f64"] for f in files.values()]), ("rank1_energy", [f["rank1_energy"] for f in files.values()])):
+        assert r[key] == [min(vals), max(vals)]
+    # the stand-in the tests, the bench's `small_views` leg and the examples run on, against the real stacks
+    g = synth.measured_like_psf(51)
+    sys.path.insert(0, gold)
+    facts = importlib.import_module("make_psf_tiff_facts")
+    sig = facts._sigmas(g)
+    assert g.max() == np.float32(0.99) and g.min() == 0.0 and np.unravel_index(np.argmax(g), g.shape) == (25, 25, 25)
+    assert abs(float(g.sum(dtype=np.float64)) - s["sum_f64"]) < 1e-6 * s["sum_f64"]
+    assert r["sum_f64"][0] <= s["sum_f64"] <= r["sum_f64"][1]
+    assert r["nonzero_share"][0] <= np.count_nonzero(g) / g.size <= r["nonzero_share"][1]
+    assert r["rank1_energy"][0] <= facts._rank1_energy(g) <= r["rank1_energy"][1]
+    for ax, key in enumerate(("sigma_x", "sigma_y", "sigma_z")):
+        assert r[key][0] * 0.99 <= sig[ax] <= r[key][1] * 1.01, (key, sig[ax], r[key])
+    if os.path.isdir(facts.REF_DIR):
+        assert json.loads(json.dumps(facts.collect())) == rec          # every fact again, from the reference's own files
 
 
 def test_tiff_reader_little_endian_multi_strip_and_rejections(mvs, tmp_path):
