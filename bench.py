@@ -920,6 +920,16 @@ def dry_run_launch(args, world: int, rank: int) -> None:
         dist.destroy_process_group()
 
 
+
+def ordered_line(out: dict) -> str:
+    """The bench line with what a reader of the first 200 characters needs in front: value, unit, value_dense, the whole view's and the
+    dominant stage's fraction of the HBM roofline on algorithmic bytes (VERDICT r5 next #9); everything else in its usual order."""
+    roof = out.get("roofline") or {}
+    lead = {"value": out.get("value"), "unit": out.get("unit"), "value_dense": out.get("value_dense"),
+            "whole_view_frac": (roof.get("whole_view") or {}).get("frac"), "roofline_frac": roof.get("frac")}
+    lead = {k: (round(v, 4) if isinstance(v, float) and k.endswith("frac") else v) for k, v in lead.items()}
+    return json.dumps({**lead, **{k: v for k, v in out.items() if k not in lead}})
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1234,7 +1244,7 @@ def main():
 
         def give_up():
             out["legs_failed"] = "the legs behind the line of record did not finish within 600 s (a rank lost inside a collective?)"
-            print(json.dumps(out), flush=True)
+            print(ordered_line(out), flush=True)
             os._exit(4)
         watchdog = threading.Timer(600.0, give_up)
         watchdog.daemon = True
@@ -1308,7 +1318,7 @@ def main():
                                        "sample": f"failed: {e!r}"}
         if legs_error:
             out["legs_failed"] = legs_error
-        print(json.dumps(out), flush=True)
+        print(ordered_line(out), flush=True)
 
     if legs_error and world > 1:
         sys.stderr.write(f"bench.py: a leg behind the line of record failed ({legs_error}); ending the job\n")

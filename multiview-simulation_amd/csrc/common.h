@@ -17,6 +17,21 @@
 
 #include "../../include/mvsim.h"
 
+// Attribution switches (tools/attribute_flags.sh, attribute_valu.sh, attribution_run.sh: builds that compile a part of a kernel's work
+// OUT -- and with it the correctness of the results -- to see what that part costs; the figures are in profiles/r04_attribution.txt).
+// They exist only in a build that defines MVSIM_DEV_ATTRIBUTION, which multiview-simulation_amd/build.py never does: in the product
+// build none of the names below can be defined, whatever MVSIM_EXTRA_CFLAGS carries.
+#ifndef MVSIM_DEV_ATTRIBUTION
+#undef MVSIM_EXP_ROTFFT_NOFFT
+#undef MVSIM_EXP_ROTFFT_NOBLEND
+#undef MVSIM_EXP_NOEXACT
+#undef MVSIM_EXP_NOPHILOX
+#undef MVSIM_EXP_NOSMALLPUSH
+#undef MVSIM_EXP_NOBRIGHT
+#undef MVSIM_P1_F64
+#undef MVSIM_EXP_NLZ
+#endif
+
 namespace mvsim {
 
 void set_error(const char* fmt, ...);

@@ -84,6 +84,7 @@ def lib():
         L.orc_axis_rotation.argtypes = [_i64p, C.c_int, C.c_int, _f64p]
         L.orc_affine_invert.argtypes = [_f64p, _f64p]
         L.orc_rotate_around_axis.argtypes = [_f32p, _i64p, C.c_int, C.c_int, _f32p]
+        L.orc_rotate_around_axis_planes.argtypes = [_f32p, _i64p, C.c_int, C.c_int, C.c_int64, C.c_int64, _f32p]
         L.orc_attenuate3d.argtypes = [_f32p, _i64p, C.c_double, _f32p]
         L.orc_sum_image.argtypes = [_f32p, C.c_int64]
         L.orc_sum_image.restype = C.c_double
@@ -98,6 +99,7 @@ def lib():
         L.orc_extract_nz.restype = C.c_int64
         L.orc_extract_slices_ref.argtypes = [_f32p, _i64p, C.c_int, C.c_float, C.POINTER(JRandomState), _f32p]
         L.orc_extract_slices_counter.argtypes = [_f32p, _i64p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _f32p]
+        L.orc_extract_slices_counter_window.argtypes = [_f32p, _i64p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_int64, _f32p]
         L.orc_isotropic_nz.argtypes = [C.c_int64, C.c_int]
         L.orc_isotropic_nz.restype = C.c_int64
         L.orc_make_isotropic.argtypes = [_f32p, _i64p, C.c_int, _f32p]
@@ -215,6 +217,17 @@ def rotate_around_axis(vol, axis: int, degrees: int) -> np.ndarray:
     rc = lib().orc_rotate_around_axis(_p(v), _dim(v), axis, degrees, _p(out))
     if rc:
         raise ValueError("rotate_around_axis: invalid axis")
+    return out
+
+
+def rotate_around_axis_planes(vol, axis: int, degrees: int, z0: int, nzp: int) -> np.ndarray:
+    """Planes z0 .. z0 + nzp - 1 of rotate_around_axis(vol, axis, degrees): the reference's cursor loop (SMVD:119-132) over those
+    output voxels only -- for parity at sizes where the whole volume would take the single-threaded restatement minutes."""
+    v = _vol(vol)
+    out = np.empty((nzp,) + v.shape[1:], np.float32)
+    rc = lib().orc_rotate_around_axis_planes(_p(v), _dim(v), axis, degrees, int(z0), int(nzp), _p(out))
+    if rc:
+        raise ValueError("rotate_around_axis_planes: invalid axis or plane range")
     return out
 
 
@@ -369,6 +382,18 @@ def extract_slices_counter(vol, inc: int, snr: float, seed: int, stream: int = 0
     nz, ny, nx = v.shape
     out = np.empty((extract_nz(nz, inc), ny, nx), dtype=np.float32)
     lib().orc_extract_slices_counter(_p(v), _dim(v), inc, snr, seed & 0xFFFFFFFFFFFFFFFF, stream, _p(out))
+    return out
+
+
+def extract_slices_counter_window(win, inc: int, snr: float, seed: int, stream: int, z0: int) -> np.ndarray:
+    """extract_slices_counter on the planes z0 .. z0 + len(win) - 1 of a larger volume (z0 a multiple of inc): the counters are the
+    source indices in the FULL volume, the result the planes z0 // inc ... of the whole view's acquisition."""
+    v = _vol(win)
+    nz, ny, nx = v.shape
+    out = np.empty((extract_nz(nz, inc), ny, nx), dtype=np.float32)
+    rc = lib().orc_extract_slices_counter_window(_p(v), _dim(v), inc, snr, seed & 0xFFFFFFFFFFFFFFFF, stream, int(z0), _p(out))
+    if rc:
+        raise ValueError("extract_slices_counter_window: inc < 1 or z0 is not a plane extractSlices reads")
     return out
 
 

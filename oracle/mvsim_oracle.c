@@ -384,24 +384,32 @@ int  orc_max_threads(void)
 #endif
 }
 
-/* SMVD:104-135 */
-int orc_rotate_around_axis(const float* in, const int64_t dim[3], int axis, int degrees, float* out)
+/* SMVD:104-135, output planes z0 .. z0 + nzp - 1 only (out holds nzp planes): the cursor loop visits every output voxel
+ * independently (SMVD:119-132), so a range of planes of the full result is that loop over those planes -- what the full-size
+ * parity tests compare with planes downloaded from the device. */
+int orc_rotate_around_axis_planes(const float* in, const int64_t dim[3], int axis, int degrees, int64_t z0, int64_t nzp, float* out)
 {
-    if (axis < 0 || axis > 2) return -1;
+    if (axis < 0 || axis > 2 || z0 < 0 || nzp < 0 || z0 + nzp > dim[2]) return -1;
     double m[12], a[12];
     orc_axis_rotation(dim, axis, degrees, m);
     orc_affine_invert(m, a);
 #pragma omp parallel for schedule(static) if (g_parallel)
-    for (int64_t z = 0; z < dim[2]; ++z)
+    for (int64_t z = z0; z < z0 + nzp; ++z)
         for (int64_t y = 0; y < dim[1]; ++y)
             for (int64_t x = 0; x < dim[0]; ++x) {
                 const double l0 = (double)x, l1 = (double)y, l2 = (double)z;
                 const double px = l0 * a[0] + l1 * a[1] + l2 * a[2] + a[3];
                 const double py = l0 * a[4] + l1 * a[5] + l2 * a[6] + a[7];
                 const double pz = l0 * a[8] + l1 * a[9] + l2 * a[10] + a[11];
-                out[x + dim[0] * (y + dim[1] * z)] = nlinear3(in, dim, tap_zero, px, py, pz);
+                out[x + dim[0] * (y + dim[1] * (z - z0))] = nlinear3(in, dim, tap_zero, px, py, pz);
             }
     return 0;
+}
+
+/* SMVD:104-135 */
+int orc_rotate_around_axis(const float* in, const int64_t dim[3], int axis, int degrees, float* out)
+{
+    return orc_rotate_around_axis_planes(in, dim, axis, degrees, 0, dim[2], out);
 }
 
 /* SMVD:318-364.  Q1: the loop runs dimension(0) steps along y. */
@@ -578,10 +586,13 @@ int orc_extract_slices_ref(const float* in, const int64_t dim[3], int inc, float
     return 0;
 }
 
-int orc_extract_slices_counter(const float* in, const int64_t dim[3], int inc, float snr,
-                               uint64_t seed, uint32_t stream, float* out)
+/* The same on a WINDOW of the source volume: `in` holds the planes z0 .. z0 + dim[2] - 1 of a volume with planes of dim[0] x dim[1]
+ * voxels, z0 a plane extractSlices reads (z0 % inc == 0); the counters are the source indices in the FULL volume, so the counts are the
+ * planes z0 / inc ... of the whole view's acquisition (full-size parity tests download a window, not the volume). */
+int orc_extract_slices_counter_window(const float* in, const int64_t dim[3], int inc, float snr,
+                                      uint64_t seed, uint32_t stream, int64_t z0, float* out)
 {
-    if (inc < 1) return -1;
+    if (inc < 1 || z0 < 0 || z0 % inc != 0) return -1;
     const int64_t plane = dim[0] * dim[1];
     const double mul = orc_poisson_mul((double)snr);
     int64_t cz = 0;
@@ -591,12 +602,18 @@ int orc_extract_slices_counter(const float* in, const int64_t dim[3], int inc, f
         if (snr >= 0.0f) {
 #pragma omp parallel for schedule(static)
             for (int64_t i = 0; i < plane; ++i)
-                dst[i] = (float)orc_poisson_counter((double)src[i] * mul, seed, stream, (uint64_t)(plane * z + i));
+                dst[i] = (float)orc_poisson_counter((double)src[i] * mul, seed, stream, (uint64_t)(plane * (z + z0) + i));
         } else {
             memcpy(dst, src, (size_t)plane * sizeof(float));
         }
     }
     return 0;
+}
+
+int orc_extract_slices_counter(const float* in, const int64_t dim[3], int inc, float snr,
+                               uint64_t seed, uint32_t stream, float* out)
+{
+    return orc_extract_slices_counter_window(in, dim, inc, snr, seed, stream, 0, out);
 }
 
 /* SMVD:144-171 */

@@ -59,6 +59,8 @@ void orc_affine_invert(const double m[12], double minv[12]);
 
 /* ---- SMVD:104-135 rotateAroundAxis (zero-extended trilinear) ---- */
 int orc_rotate_around_axis(const float* in, const int64_t dim[3], int axis, int degrees, float* out);
+/* the same loop over the output planes z0 .. z0 + nzp - 1 only (out: nzp planes) */
+int orc_rotate_around_axis_planes(const float* in, const int64_t dim[3], int axis, int degrees, int64_t z0, int64_t nzp, float* out);
 
 /* ---- SMVD:318-364 attenuate3d ---- */
 int orc_attenuate3d(const float* in, const int64_t dim[3], double delta, float* out);
@@ -91,6 +93,9 @@ int orc_extract_slices_ref(const float* in, const int64_t dim[3], int inc, float
                            orc_jrandom* rnd, float* out);
 int orc_extract_slices_counter(const float* in, const int64_t dim[3], int inc, float snr,
                                uint64_t seed, uint32_t stream, float* out);
+/* counter mode on a window of planes z0 .. z0 + dim[2] - 1 of the source volume (z0 % inc == 0): counters = indices in the full volume */
+int orc_extract_slices_counter_window(const float* in, const int64_t dim[3], int inc, float snr,
+                                      uint64_t seed, uint32_t stream, int64_t z0, float* out);
 double orc_poisson_mul(double snr);                /* Tools:76 */
 
 /* ---- "next" items: SMVD:144-171 makeIsotropic, SMVD:280-316 computeWeightImage ---- */

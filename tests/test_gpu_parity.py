@@ -1004,7 +1004,7 @@ def _window_volume(nz, ny, nx):
     return vol
 
 
-def _large_view_properties(mvs, dims_xyz, kdims_zyx, inc, sigma, psf_raw=None):
+def _large_view_properties(mvs, dims_xyz, kdims_zyx, inc, sigma, psf_raw=None, oracle_samples=False):
     nx, ny, nz = dims_xyz
     synth = importlib.import_module("multiview-simulation_amd.synthetic")
     gt = _window_volume(nz, ny, nx)
@@ -1040,21 +1040,97 @@ def _large_view_properties(mvs, dims_xyz, kdims_zyx, inc, sigma, psf_raw=None):
             c.simulate_view_dev(d_gt, dims_xyz, psf.copy(), p2, d_acq2)
             b = c.download(d_acq2, (nzo, ny, nx))
             assert not np.array_equal(a, b) and abs(a.sum(dtype=np.float64) / b.sum(dtype=np.float64) - 1) < 1e-3
+            del b
+            if oracle_samples:
+                _large_view_oracle_samples(c, gt, d_gt, dims_xyz, psf, inc, 60, a, 3, d_acq2)
+                # the same volume on a low background with bright voxels next to the faces: no empty plane (the unflagged passes), and the
+                # mirror boundaries of the convolution act on content -- x and z at the z faces, x and y in the middle planes
+                gt += np.float32(0.03)
+                for zz, yy, xx in ((0, ny // 2, 1), (1, ny // 2 - 3, nx - 2), (nz - 1, ny // 2 + 2, 0), (nz // 2, 0, 2), (nz // 2 + 1, ny - 1, nx - 1)):
+                    gt[zz, yy, xx] += np.float32(4.0)
+                c.upload(d_gt, gt)
+                c.simulate_view_dev(d_gt, dims_xyz, psf.copy(), p1, d_acq)
+                _large_view_oracle_samples(c, gt, d_gt, dims_xyz, psf, inc, 60, c.download(d_acq, (nzo, ny, nx)), 3, d_acq2)
         finally:
             for d in (d_gt, d_acq, d_acq2):
                 c.dev_free(d)
 
 
+def _large_view_oracle_samples(c, gt, d_gt, dims_xyz, psf, inc, degrees, counts, counts_stream, d_acq):
+    """Oracle-checked voxels of a FULL-SIZE view (the way test_config4_as_stated... does it for configs[4]).
+    The same view without noise, `rot` and `att` kept on the device (the fused kernel writes them beside its spectrum rows):
+      rot, att   WHOLE planes at both faces and in the middle, bit for bit against the reference's loops restated over those planes
+                 (orc_rotate_around_axis_planes = SimulateMultiViewDataset.java:119-132 over the planes' voxels; attenuate3d :335-359 walks y
+                 inside a plane of constant z, so the planes' columns are complete);
+      con        the noise-free acquisition = Tools.adjustImage of the convolved planes k * inc (Tools.java:143-159, two roundings) at ~450
+                 voxels -- blocks at both x faces x both y faces and the middle rows, random and the brightest voxels of planes at the z = 0
+                 face, in the middle and at the last acquired plane -- against the exact fp64 direct sum over the downloaded `att` window
+                 (orc_convolve_direct_at: SimulateMultiViewDataset.java:253-264 as FFTConvolution defines it), <= 1e-5 of the range: a wrong tap
+                 weight or a wrong mirror at 1024-long lines fails here;
+      counts     two acquired planes in the bright middle of the volume, bit for bit on identical lambda: the oracle's counter sampler
+                 (second implementation) on the downloaded noise-free planes with the FULL volume's source indices."""
+    import oracle as orc
+    nx, ny, nz = dims_xyz
+    kz = psf.shape[0]
+    assert kz % 2 == 1
+    r = kz // 2
+    nzo = (nz - 1) // inc + 1
+    plane = nx * ny
+    d_rot, d_att = c.dev_alloc(plane * nz * 4), c.dev_alloc(plane * nz * 4)
+    try:
+        pn = c.view_params(degrees=degrees, delta=REF_DELTA, inc=inc, snr=-1.0, seed=SEED, stream=0, conv_method=1)
+        corr = c.simulate_view_dev(d_gt, dims_xyz, psf.copy(), pn, d_acq, rot_dptr=d_rot, att_dptr=d_att, want_corr=True)
+        nf = c.download(d_acq, (nzo, ny, nx))
+        scale = float(nf.max())
+        assert scale > 0 and corr > 0
+        rng = np.random.default_rng(11)
+        for z in sorted({0, 1, nz // 2, nz - 1, int(rng.integers(2, nz - 2))}):
+            want_rot = orc.rotate_around_axis_planes(gt, 0, degrees, z, 1)
+            assert np.array_equal(c.download(d_rot + z * plane * 4, (1, ny, nx)), want_rot), f"rot plane {z}"
+            assert np.array_equal(c.download(d_att + z * plane * 4, (1, ny, nx)), orc.attenuate3d(want_rot, REF_DELTA)), f"att plane {z}"
+        psf_n = psf.copy()
+        orc.norm_image(psf_n)
+        zm = (nz // 2) // inc * inc
+        zt = (nzo - 1) * inc
+        checked = 0
+        for zlo, zhi, zs in ((0, inc + r + 1, (0, inc)), (zm - r, zm + inc + r + 1, (zm, zm + inc)), (zt - r, nz, (zt,))):
+            win = c.download(d_att + zlo * plane * 4, (zhi - zlo, ny, nx))
+            for z in zs:
+                got_plane = nf[z // inc]
+                bright = np.argsort(got_plane.ravel())[-16:]
+                edge_y = np.concatenate([np.arange(3), np.arange(ny // 2 - 1, ny // 2 + 2), np.arange(ny - 3, ny)])       # 9 rows: both y faces, the middle
+                edge_x = np.concatenate([np.arange(3), np.arange(nx - 3, nx)])                                          # 6 columns: both x faces
+                ys = np.concatenate([np.repeat(edge_y, edge_x.size), rng.integers(0, ny, 24), bright // nx])
+                xs = np.concatenate([np.tile(edge_x, edge_y.size), rng.integers(0, nx, 24), bright % nx])
+                pos = np.unique(xs + nx * ys)
+                want = orc.convolve_direct_at(win, psf_n, pos + plane * (z - zlo))
+                want = (want.astype(np.float64) * corr).astype(np.float32) + np.float32(1e-4)       # Tools.adjustImage, two roundings
+                err = float(np.abs(got_plane.ravel()[pos] - want).max())
+                assert err <= CONV_TOL * scale, (z, err, scale)
+                checked += pos.size
+        assert checked >= 300
+        # counts on identical lambda: the two acquired planes zm, zm + inc
+        k0 = zm // inc
+        lam_win = np.zeros((inc + 1, ny, nx), np.float32)
+        lam_win[0], lam_win[inc] = nf[k0], nf[k0 + 1]
+        assert float(lam_win.max()) * 124.99999999999997 > 50.0                                      # the PTRS regime is populated
+        want_counts = orc.extract_slices_counter_window(lam_win, inc, 25.0, SEED, counts_stream, zm)
+        assert np.array_equal(counts[k0:k0 + 2], want_counts)
+    finally:
+        c.dev_free(d_rot)
+        c.dev_free(d_att)
+
+
 def test_config1_512_cubed_fused_view_with_rotation(mvs):
     """BASELINE configs[1]/[2] per view at full size: 512^3, 31^3 PSF, the FUSED view with a real rotation (60 degrees)."""
-    _large_view_properties(mvs, (512, 512, 512), (31, 31, 31), 1, (2.0, 2.2, 6.0))
+    _large_view_properties(mvs, (512, 512, 512), (31, 31, 31), 1, (2.0, 2.2, 6.0), oracle_samples=True)
 
 
 def test_config3_1024_cubed_anisotropic_psf_inc4(mvs):
     """BASELINE configs[3] as SURVEY 8(d) states it: 1024^3 volume, 31 x 31 x 63 Gaussian PSF with sigma = (2, 2.2, 12), 4x
     axial down-sampling -- one view fits one GPU, so the view runs untiled here (the slab-tiled form of the same PSF depth:
     test_view_slab_tiling_at_size_with_the_config3_psf)."""
-    _large_view_properties(mvs, (1024, 1024, 1024), (63, 31, 31), 4, (2.0, 2.2, 12.0))
+    _large_view_properties(mvs, (1024, 1024, 1024), (63, 31, 31), 4, (2.0, 2.2, 12.0), oracle_samples=True)
 
 
 def test_view_slab_tiling_at_size_with_the_config3_psf(mvs, synth):

@@ -299,6 +299,28 @@ def test_counter_stream_is_tiling_invariant(orc):
 
 
 # ------------------------------------------------------------------------------------------------ next items
+def test_plane_and_window_forms_equal_the_whole_volume(orc):
+    """The forms the full-size GPU parity tests use: a range of output planes of rotateAroundAxis (SMVD:119-132: independent output
+    voxels), attenuate3d on those planes (SMVD:335-359: the walk stays inside a plane of constant z) and the counter sampler on a
+    window of planes with the full volume's source indices -- each equal, bit for bit, to the same planes of the whole-volume call."""
+    rng = np.random.default_rng(5)
+    v = rng.random((21, 26, 23), dtype=np.float32)
+    for axis, deg in ((0, 60), (1, -33), (2, 15)):
+        full = orc.rotate_around_axis(v, axis, deg)
+        assert np.array_equal(orc.rotate_around_axis_planes(v, axis, deg, 6, 9), full[6:15])
+        assert np.array_equal(orc.rotate_around_axis_planes(v, axis, deg, 0, 21), full)
+    rot = orc.rotate_around_axis(v, 0, 60)
+    assert np.array_equal(orc.attenuate3d(rot[6:15], 0.01), orc.attenuate3d(rot, 0.01)[6:15])
+    with pytest.raises(ValueError):
+        orc.rotate_around_axis_planes(v, 0, 60, 15, 9)
+    lam = (rng.random((20, 8, 12), dtype=np.float32) * 40).astype(np.float32)
+    for inc in (1, 4):
+        whole = orc.extract_slices_counter(lam, inc, 25.0, 464232194, 2)
+        assert np.array_equal(orc.extract_slices_counter_window(lam[8:17], inc, 25.0, 464232194, 2, 8), whole[8 // inc:8 // inc + (8 // inc) + 1])
+    with pytest.raises(ValueError):
+        orc.extract_slices_counter_window(lam[3:9], 4, 25.0, 1, 0, 3)
+
+
 def test_make_isotropic_and_weights(orc):
     z = np.arange(5, dtype=np.float32)[:, None, None] * np.ones((1, 3, 4), np.float32)
     iso = orc.make_isotropic(z, 3)

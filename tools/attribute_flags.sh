@@ -3,7 +3,7 @@
 #   bash tools/attribute_flags.sh "-DMVSIM_EXP_ROTFFT_NOFFT" "-DMVSIM_EXP_ROTFFT_NOBLEND" "-DMVSIM_EXP_ROTFFT_NOFFT -DMVSIM_EXP_ROTFFT_NOBLEND" "-DMVSIM_ROTFFT_PREFETCH=4"
 set -e
 for f in "$@"; do
-  MVSIM_EXTRA_CFLAGS="$f" python -c "import importlib; b = importlib.import_module('multiview-simulation_amd.build'); b.build(force=True)"
+  MVSIM_EXTRA_CFLAGS="-DMVSIM_DEV_ATTRIBUTION $f" python -c "import importlib; b = importlib.import_module('multiview-simulation_amd.build'); b.build(force=True)"
   for r in 1 2; do
   python bench.py --serial --no-cpu-baseline --no-end-to-end --no-size-1024 --no-two-streams --no-dense-leg 2>/dev/null | python -c "
 import json,sys

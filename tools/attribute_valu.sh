@@ -1,7 +1,7 @@
 # VALU instructions per wave of the Poisson kernels for experiment builds: bash tools/attribute_valu.sh "<cflags 1>" "<cflags 2>" ...
 set -e
 for f in "$@"; do
-  MVSIM_EXTRA_CFLAGS="$f" python -c "import importlib; b = importlib.import_module('multiview-simulation_amd.build'); b.build(force=True)"
+  MVSIM_EXTRA_CFLAGS="-DMVSIM_DEV_ATTRIBUTION $f" python -c "import importlib; b = importlib.import_module('multiview-simulation_amd.build'); b.build(force=True)"
   echo "[$f]"
   bash tools/pmc_i.sh "" > gpurun_out/pi.txt 2>&1 || { tail -5 gpurun_out/pi.txt; exit 1; }
   grep -i "extract\|resolve" gpurun_out/pi.txt | cut -c1-40,88-200
