@@ -88,6 +88,10 @@ int  mvsim_download(mvsim_ctx* ctx, void* dst_host, const void* src_dev, size_t 
  * JNI shim hands them to Java as direct ByteBuffers).  Ordinary pageable buffers work everywhere too, just slower. */
 int  mvsim_host_alloc(mvsim_ctx* ctx, size_t bytes, void** hptr);
 int  mvsim_host_free(mvsim_ctx* ctx_or_null, void* hptr);
+/* Host-to-host copy on the library's host threads (option "host_threads"; ctx may be NULL): what the JNI shim uses between a Java heap
+ * array held with GetPrimitiveArrayCritical and a page-locked staging block -- the copies of the facade's Buffers.toBlock / toImg
+ * (SimulateMultiViewDataset.java:109,198: every operator returns a NEW ArrayImg).  Synchronous; overlapping ranges are moved in order. */
+int  mvsim_host_copy(mvsim_ctx* ctx_or_null, void* dst, const void* src, size_t bytes);
 /* byte-wise fill, asynchronous on the context stream (e.g. the zero canvas of the phantom generator) */
 int  mvsim_dev_memset(mvsim_ctx* ctx, void* dptr, int value, size_t bytes);
 
@@ -378,6 +382,10 @@ int mvsim_comm_allreduce_sum(mvsim_ctx* ctx, float* buf_dev, int64_t count);
 /* Sum over ranks of ONE double held on the host (in place; synchronises): the adjustImage sum of a view whose
  * z slabs live on different GPUs. */
 int mvsim_comm_allreduce_sum_f64(mvsim_ctx* ctx, double* value_host);
+/* The same sum for ONE double that lives on the DEVICE (in place, asynchronous, no host trip): enqueued on `hip_stream` (null: the
+ * context's stream), so a caller can order it behind the kernel that produces the value.  What mvsim_view_slab_dev runs between a
+ * slab's convolution and its adjust (SimulateMultiViewDataset.java:582: Tools.adjustImage needs the whole view's sum). */
+int mvsim_comm_allreduce_sum_f64_dev(mvsim_ctx* ctx, double* value_dev, void* hip_stream);
 int mvsim_comm_destroy(mvsim_ctx* ctx);
 /* view v of n_views belongs to rank v % nranks; returns how many views `rank` owns and writes
  * their indices (capacity max_out). */
@@ -416,6 +424,14 @@ int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t 
                                  double* slab_sum);
 int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim_view_params* params, int64_t z0,
                                int64_t z1, double total_sum, float* acq, int64_t* n_planes);
+/* The three steps above as ONE asynchronous call that never leaves the device: the slab's share of the sum stays in HBM, is reduced
+ * over the ranks in place by the communicator of `comm_ctx` (null: ctx's own; no communicator or one rank: nothing to reduce) ON
+ * ctx's stream, and adjust, extract and Poisson follow behind it.  The loop body tiled is SimulateMultiViewDataset.java:570-585.
+ * Same results as the three-step form (the reduction adds the same doubles; RCCL's order over ranks may differ from a host
+ * loop's in the last bit of the sum). */
+int mvsim_view_slab_dev(mvsim_ctx* ctx, mvsim_ctx* comm_ctx, const float* gt, const int64_t dim[3], float* psf_host,
+                        const int64_t kdim[3], const mvsim_view_params* params, int64_t z0, int64_t z1, float* acq,
+                        int64_t* n_planes);
 
 #ifdef __cplusplus
 }

@@ -317,6 +317,30 @@ JNIEXPORT void JNICALL JNI_FN(freePinned)(JNIEnv* env, jclass, jobject block)
     if (block) (void)mvsim_host_free(nullptr, env->GetDirectBufferAddress(block));
 }
 
+// Bulk copies between a Java float[] and a (page-locked) direct block on the library's host threads (mvsim_host_copy).  The array is
+// held with GetPrimitiveArrayCritical for the duration of the copy -- the worker threads touch plain memory, never the JNIEnv, and no
+// JNI call is made inside the critical region (JNI specification, "GetPrimitiveArrayCritical").  to_array == JNI_TRUE: block -> array
+// (Buffers.toImg's copy into the NEW ArrayImg every operator of the reference returns, SimulateMultiViewDataset.java:109,198: the
+// threads also take the array's first-touch page faults in parallel); JNI_FALSE: array -> block (Buffers.toBlock / toSlabs).
+JNIEXPORT void JNICALL JNI_FN(copyFloats)(JNIEnv* env, jclass, jlong h, jobject block, jlong block_off, jfloatArray array, jint array_off,
+                                          jint count, jboolean to_array)
+{
+    if (count == 0) return;
+    if (!array || count < 0 || array_off < 0 || block_off < 0 || (jlong)array_off + count > env->GetArrayLength(array)) {
+        throw_new(env, "java/lang/ArrayIndexOutOfBoundsException", "copyFloats: range outside the array");
+        return;
+    }
+    float* b = fptr(env, block, block_off + count, "copyFloats: range outside the block");
+    if (!b) return;
+    void* a = env->GetPrimitiveArrayCritical(array, nullptr);
+    if (!a) { throw_new(env, "java/lang/OutOfMemoryError", "copyFloats: GetPrimitiveArrayCritical"); return; }
+    float* arr = static_cast<float*>(a) + array_off;
+    const int rc = to_array ? mvsim_host_copy(ctx_of(h), arr, b + block_off, static_cast<size_t>(count) * sizeof(float))
+                            : mvsim_host_copy(ctx_of(h), b + block_off, arr, static_cast<size_t>(count) * sizeof(float));
+    env->ReleasePrimitiveArrayCritical(array, a, to_array ? 0 : JNI_ABORT);   // array -> block: nothing to write back
+    throw_for(env, rc);
+}
+
 JNIEXPORT jlong JNICALL JNI_FN(drawSpheres)(JNIEnv* env, jclass, jlong h, jobject img, jlongArray dim, jdouble min_value,
                                             jdouble max_value, jint scale, jboolean half_pixel_offset, jlongArray rnd_state)
 {

@@ -16,7 +16,9 @@ import net.imglib2.img.Img;
 import net.imglib2.img.array.ArrayImg;
 import net.imglib2.img.array.ArrayImgs;
 import net.imglib2.img.basictypeaccess.array.FloatArray;
+import net.imglib2.img.basictypeaccess.nio.FloatBufferAccess;
 import net.imglib2.type.numeric.real.FloatType;
+import net.imglib2.util.Fraction;
 import net.imglib2.view.Views;
 
 /**
@@ -29,6 +31,16 @@ import net.imglib2.view.Views;
  * {@code -Dmvsim.pool.bytes} (default 4 GiB) per thread a closed block is freed at once (mvsim_host_free).  The JVM never
  * frees NewDirectByteBuffer memory it did not allocate, so nothing here relies on the garbage collector; the pool itself
  * is emptied when the thread's native context goes away ({@link GpuContextPool}).
+ *
+ * What an operator RETURNS (round 6).  The reference's operators return a new ArrayImg (SimulateMultiViewDataset.java:109,198,235,256,
+ * 321), and so does the facade -- by default a heap-backed one, filled from the staging block by {@code MvsimNative.copyFloats}: the
+ * array is held with GetPrimitiveArrayCritical and the library's host threads copy (and take the fresh array's first-touch page
+ * faults) in parallel; one JVM thread needs 79 ms for a 512^3 image that way, 44 x the GPU time of the view it returns
+ * (profiles/r05_slab_copy.txt, r06_slab_copy.txt).  With {@code -Dmvsim.zero_copy=true} the returned image is an
+ * {@code ArrayImg<FloatType, FloatBufferAccess>} OVER the page-locked block itself: no copy at all; the block then belongs to the
+ * image and is freed (mvsim_host_free) by a {@link java.lang.ref.Cleaner} once the image is unreachable.  Every ImgLib2 accessor
+ * works on it; only code that unwraps {@code FloatArray} storage by hand does not -- hence opt-in.  Images of more than one block
+ * (> 2^28 floats) are always copied.
  */
 final class Buffers
 {
@@ -43,6 +55,12 @@ final class Buffers
 
 	/** floats per z-slab block of a large volume: one direct ByteBuffer holds at most 2^31 - 1 bytes */
 	static final long MAX_BLOCK_FLOATS = 1L << 28;
+
+	/** return images over the page-locked staging block instead of copying it into a heap array (see the class comment) */
+	static final boolean ZERO_COPY = Boolean.getBoolean( "mvsim.zero_copy" );
+	/** from this many floats up the bulk copies between heap arrays and blocks run on the native host threads */
+	static final long NATIVE_COPY_MIN = 1L << 20;
+	private static final java.lang.ref.Cleaner CLEANER = java.lang.ref.Cleaner.create();
 
 	static final class Block implements AutoCloseable
 	{
@@ -70,6 +88,47 @@ final class Buffers
 				recycle( this );
 			}
 		}
+
+		/** the block now belongs to an image that wraps it ({@link #wrap}): close() must not hand it back to the pool */
+		void detach()
+		{
+			open = false;
+		}
+	}
+
+	/** heap array <-> block, on the native host threads from {@link #NATIVE_COPY_MIN} floats up (else the JVM's own bulk copy) */
+	private static void copy( final Block blk, final long blockOff, final float[] a, final int arrayOff, final int n, final boolean toArray )
+	{
+		if ( n >= NATIVE_COPY_MIN && blk.pinned )
+		{
+			MvsimNative.copyFloats( GpuContextPool.get(), blk.floats, blockOff, a, arrayOff, n, toArray );
+			return;
+		}
+		final FloatBuffer b = blk.floats.duplicate();
+		b.position( ( int ) blockOff );
+		if ( toArray )
+			b.get( a, arrayOff, n );
+		else
+			b.put( a, arrayOff, n );
+	}
+
+	/**
+	 * An image OVER the block's first size(d) floats, no copy: the block belongs to the image from here on and is freed when the
+	 * image is unreachable.  The cleaning action holds the bytes, never the image.
+	 */
+	private static Img< FloatType > wrap( final Block blk, final long[] d )
+	{
+		final FloatBuffer fb = blk.floats.duplicate();
+		fb.rewind();
+		fb.limit( ( int ) size( d ) );
+		final ArrayImg< FloatType, FloatBufferAccess > img = new ArrayImg<>( new FloatBufferAccess( fb.slice(), true ), d, new Fraction() );
+		img.setLinkedType( new FloatType( img ) );
+		final ByteBuffer bytes = blk.bytes;
+		final boolean pinned = blk.pinned;
+		blk.detach();
+		if ( pinned )
+			CLEANER.register( img, () -> MvsimNative.freePinned( bytes ) );
+		return img;
 	}
 
 	private static final class Pool
@@ -146,7 +205,8 @@ final class Buffers
 		{
 			if ( rai instanceof ArrayImg && ( ( ArrayImg< ?, ? > ) rai ).update( null ) instanceof FloatArray )
 			{
-				b.put( ( ( FloatArray ) ( ( ArrayImg< ?, ? > ) rai ).update( null ) ).getCurrentStorageArray() );
+				final float[] a = ( ( FloatArray ) ( ( ArrayImg< ?, ? > ) rai ).update( null ) ).getCurrentStorageArray();
+				copy( blk, 0, a, 0, a.length, false );
 			}
 			else
 			{
@@ -232,9 +292,8 @@ final class Buffers
 				for ( int i = 0; i < s.nz.length; ++i )
 				{
 					final long n = plane * s.nz[ i ];
-					final FloatBuffer b = s.blocks.get( i ).floats;
-					b.put( a, ( int ) off, ( int ) n );           // off + n <= a.length < 2^31
-					b.rewind();
+					copy( s.blocks.get( i ), 0, a, ( int ) off, ( int ) n, false );       // off + n <= a.length < 2^31
+					s.blocks.get( i ).floats.rewind();
 					off += n;
 				}
 			}
@@ -267,25 +326,29 @@ final class Buffers
 		final long n = size( s.dim );
 		if ( n > Integer.MAX_VALUE )
 			throw new IllegalArgumentException( "an ArrayImg holds at most 2^31 - 1 voxels (the reference has the same limit)" );
+		if ( ZERO_COPY && s.blocks.size() == 1 )
+			return wrap( s.blocks.get( 0 ), s.dim );               // (s.close() then finds the block detached)
 		final float[] a = new float[ ( int ) n ];
 		final long plane = s.dim[ 0 ] * s.dim[ 1 ];
 		long off = 0;
 		for ( int i = 0; i < s.nz.length; ++i )
 		{
-			final FloatBuffer b = s.blocks.get( i ).floats;
-			b.rewind();
-			b.get( a, ( int ) off, ( int ) ( plane * s.nz[ i ] ) );
+			copy( s.blocks.get( i ), 0, a, ( int ) off, ( int ) ( plane * s.nz[ i ] ), true );
 			off += plane * s.nz[ i ];
 		}
 		return ArrayImgs.floats( a, s.dim );
 	}
 
-	/** a fresh ArrayImg holding the block's first size(d) floats (the block stays owned by the caller) */
+	/**
+	 * An ArrayImg holding the block's first size(d) floats: a fresh heap-backed one (the block stays owned by the caller), or, with
+	 * {@link #ZERO_COPY}, one over the block itself (the caller's close() of the block is then a no-op).
+	 */
 	static Img< FloatType > toImg( final Block blk, final long[] d )
 	{
+		if ( ZERO_COPY )
+			return wrap( blk, d );
 		final float[] a = new float[ ( int ) size( d ) ];
-		blk.floats.rewind();
-		blk.floats.get( a );
+		copy( blk, 0, a, 0, a.length, true );
 		return ArrayImgs.floats( a, d );
 	}
 

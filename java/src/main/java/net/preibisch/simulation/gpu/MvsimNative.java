@@ -44,6 +44,11 @@ final class MvsimNative
 	/** mvsim_host_alloc wrapped by NewDirectByteBuffer: a page-locked block (null if the allocation fails); freePinned releases it. */
 	static native java.nio.ByteBuffer allocPinned( long ctx, long bytes );
 	static native void freePinned( java.nio.ByteBuffer block );
+	/**
+	 * count floats between a direct FloatBuffer (from blockOffset) and a heap array (from arrayOffset) on the library's host threads
+	 * (mvsim_host_copy; the array is held with GetPrimitiveArrayCritical meanwhile).  toArray: block -> array, else array -> block.
+	 */
+	static native void copyFloats( long ctx, java.nio.FloatBuffer block, long blockOffset, float[] array, int arrayOffset, int count, boolean toArray );
 
 	/** drawSpheres (:436-522), in place; rndState[0] is the 48-bit java.util.Random state, advanced on return; returns the sphere count. */
 	static native long drawSpheres( long ctx, FloatBuffer img, long[] dim, double minValue, double maxValue, int scale,

@@ -569,6 +569,22 @@ class Context:
                                                       int(z1), float(total_sum), C.c_void_p(acq_dptr), C.byref(n)))
         return int(n.value)
 
+    def view_slab_dev(self, gt_dptr: int, dim_xyz, psf: np.ndarray, params: ViewParams, z0: int, z1: int, acq_dptr: int,
+                      comm_ctx: "Context | None" = None) -> int:
+        """One tiled view's slab in one asynchronous call, nothing through the host (mvsim_view_slab_dev): convolve, the slab sums
+        reduced in place on this context's stream by ``comm_ctx``'s communicator (default: this context's own, if it has one), adjust,
+        extract, Poisson.  Returns the number of acquired planes written to ``acq_dptr``."""
+        _check_inplace(psf, "psf")
+        n = C.c_int64()
+        _lib.check(self._L.mvsim_view_slab_dev(self._h, comm_ctx._h if comm_ctx is not None else None, C.c_void_p(gt_dptr),
+                                               (C.c_int64 * 3)(*dim_xyz), _ptr(psf), _dim(psf), C.byref(params), int(z0), int(z1),
+                                               C.c_void_p(acq_dptr), C.byref(n)))
+        return int(n.value)
+
+    def comm_allreduce_sum_f64_dev(self, value_dptr: int, stream: int = 0) -> None:
+        """In-place sum over the ranks of one DEVICE double, asynchronous on ``stream`` (0: the context's)."""
+        _lib.check(self._L.mvsim_comm_allreduce_sum_f64_dev(self._h, C.c_void_p(value_dptr), C.c_void_p(stream) if stream else None))
+
     def comm_allreduce_sum_f64(self, value: float) -> float:
         v = C.c_double(value)
         _lib.check(self._L.mvsim_comm_allreduce_sum_f64(self._h, C.byref(v)))

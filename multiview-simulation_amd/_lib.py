@@ -151,6 +151,9 @@ SIGNATURES = {
                                                C.POINTER(C.c_double)]),
     "mvsim_view_slab_finish_dev": (C.c_int, [_vp, _i64p, _vp, C.c_int64, C.c_int64, C.c_double, _vp,
                                              C.POINTER(C.c_int64)]),
+    "mvsim_view_slab_dev": (C.c_int, [_vp, _vp, _vp, _i64p, _vp, _i64p, _vp, C.c_int64, C.c_int64, _vp, C.POINTER(C.c_int64)]),
+    "mvsim_comm_allreduce_sum_f64_dev": (C.c_int, [_vp, _vp, _vp]),
+    "mvsim_host_copy": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "mvsim_comm_destroy": (C.c_int, [_vp]),
     "mvsim_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
     "mvsim_group_destroy": (C.c_int, [_vp]),

@@ -629,6 +629,26 @@ int mvsim_release_caches(mvsim_ctx* ctx)
     return MVSIM_OK;
 }
 
+// Host-to-host copy on the library's host threads (the JNI shim's bulk copies between a Java heap array and a page-locked staging
+// block: one JVM thread moves 0.54 GB in 16 ms into a live array and in 79 ms into a fresh one -- first-touch page faults --,
+// profiles/r05_slab_copy.txt; several threads fault and copy in parallel).  ctx may be null: the process-wide default thread count.
+int mvsim_host_copy(mvsim_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return MVSIM_OK;
+    if (!dst || !src) { set_error("invalid argument: host_copy with a null pointer"); return MVSIM_EINVAL; }
+    const size_t chunk = (size_t)4 << 20;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int threads = ctx ? host_threads_of(ctx) : (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+    if (bytes <= chunk || threads <= 1) { std::memmove(dst, src, bytes); return MVSIM_OK; }
+    const uintptr_t d = reinterpret_cast<uintptr_t>(dst), sr = reinterpret_cast<uintptr_t>(src);
+    if (d < sr + bytes && sr < d + bytes) { std::memmove(dst, src, bytes); return MVSIM_OK; }      // overlapping ranges: one ordered move
+    HostPool::get().run((int)((bytes + chunk - 1) / chunk), threads, [&](int c) {
+        const size_t a = (size_t)c * chunk, n = std::min(chunk, bytes - a);
+        std::memcpy(static_cast<char*>(dst) + a, static_cast<const char*>(src) + a, n);
+    });
+    return MVSIM_OK;
+}
+
 int mvsim_dev_alloc(mvsim_ctx* ctx, size_t bytes, void** dptr)
 {
     MVSIM_TRY(set_device(ctx));
@@ -1428,13 +1448,14 @@ int mvsim_slab_range(int64_t nz, int nranks, int rank, int64_t* z0, int64_t* z1)
     return MVSIM_OK;
 }
 
-int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host,
-                                 const int64_t kdim[3], const mvsim_view_params* p, int64_t z0, int64_t z1,
-                                 double* slab_sum)
+// rotate + attenuate the slab's planes and the halo the PSF reaches, convolve the slab; the slab's share of adjustImage's sum is left in
+// the context's scalar slot (device).  Nothing here waits for the device.
+static int slab_convolve_enqueue(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host,
+                                 const int64_t kdim[3], const mvsim_view_params* p, int64_t z0, int64_t z1)
 {
     MVSIM_TRY(set_device(ctx));
     MVSIM_TRY(check_dim(dim));
-    MVSIM_CHECK_ARG(gt && p && slab_sum, "null pointer");
+    MVSIM_CHECK_ARG(gt && p, "null pointer");
     MVSIM_CHECK_ARG(p->axis == 0, "slab tiling supports rotation about x (axis 0)");
     MVSIM_CHECK_ARG(dim[0] <= dim[1], "attenuate3d: Nx > Ny walks outside the interval in the reference");
     MVSIM_CHECK_ARG(0 <= z0 && z0 < z1 && z1 <= dim[2], "slab must satisfy 0 <= z0 < z1 <= Nz");
@@ -1451,35 +1472,55 @@ int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t 
         return MVSIM_EINVAL;
     }
     const size_t pbytes = (size_t)dim[0] * dim[1] * sizeof(float);
-    MVSIM_TRY(ctx->vol_b.reserve(pbytes * (size_t)(zb - za)));
     MVSIM_TRY(ctx->vol_a.reserve(pbytes * (size_t)(z1 - z0)));
     MVSIM_TRY(psf_prepare(ctx, psf_host, kdim, dim));
     double m[12];
     Affine inv;
     axis_rotation_host(dim, p->axis, p->degrees, m);
     affine_invert_host(m, inv.m);
-    bool fused = false;
-    MVSIM_TRY(launch_rotate_attenuate_planes(ctx->stream, gt, nullptr, ctx->vol_b.as<float>(), dim, inv, p->delta,
-                                             (int)za, (int)(zb - za), ctx->opt.fused_rotate == 2 ? 2 : 1, &fused));   // planes [za, zb) exist only fused
-    if (!fused) {
-        set_error("slab tiling needs the fused rotate+attenuate kernel");
-        return MVSIM_EINVAL;
+    // (round 6) the slab's planes through the fused rotate + attenuate + x-transform kernel, as an untiled view's: the attenuated planes
+    // never cross HBM (z_first = za, zb - za planes; F holds them from plane 0, where pass B of the slab's convolution expects them)
+    bool x_done = false;
+    MVSIM_TRY(rotate_attenuate_fftx(ctx, gt, nullptr, nullptr, dim, kdim, inv, p->delta, &x_done, nullptr, (int)za, (int)(zb - za)));
+    if (!x_done) {
+        MVSIM_TRY(ctx->vol_b.reserve(pbytes * (size_t)(zb - za)));
+        bool fused = false;
+        MVSIM_TRY(launch_rotate_attenuate_planes(ctx->stream, gt, nullptr, ctx->vol_b.as<float>(), dim, inv, p->delta,
+                                                 (int)za, (int)(zb - za), ctx->opt.fused_rotate == 2 ? 2 : 1, &fused));   // planes [za, zb) exist only fused
+        if (!fused) {
+            set_error("slab tiling needs the fused rotate+attenuate kernel");
+            return MVSIM_EINVAL;
+        }
     }
     const SlabRange slab{(int)za, (int)(zb - za), (int)z0, (int)(z1 - z0)};
     // a slab that starts at a multiple of the view's spacing convolves along z -- and sends through passes D and E -- only the planes
     // extractSlices reads, like an untiled compact view (the sum over ALL of the slab's planes comes from the z pass's input rows)
     ConvTail tail;
     tail.zstride = (p->inc > 1 && z0 % p->inc == 0) ? p->inc : 1;
+    tail.x_done = x_done;
     ctx->slab_z0 = ctx->slab_z1 = -1;
-    MVSIM_TRY(custom_fft_convolve_slab(ctx, ctx->vol_b.as<float>(), dim, ctx->psf_dev.as<float>(), kdim, P, slab,
+    MVSIM_TRY(custom_fft_convolve_slab(ctx, x_done ? nullptr : ctx->vol_b.as<float>(), dim, ctx->psf_dev.as<float>(), kdim, P, slab,
                                        ctx->vol_a.as<float>(), &tail));
     ctx->slab_z0 = z0; ctx->slab_z1 = z1; ctx->slab_zstride = tail.zstride;
+    return MVSIM_OK;
+}
+
+int mvsim_view_slab_convolve_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* psf_host,
+                                 const int64_t kdim[3], const mvsim_view_params* p, int64_t z0, int64_t z1,
+                                 double* slab_sum)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr && slab_sum != nullptr, "null pointer");
+    MVSIM_TRY(slab_convolve_enqueue(ctx, gt, dim, psf_host, kdim, p, z0, z1));
     double *partial, *scal;
     MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
     MVSIM_HIP(hipMemcpyAsync(slab_sum, scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));
     return MVSIM_OK;
 }
+
+// adjust with the sum the context's scalar slot holds (the view's, once reduced), extract, Poisson: the slab's acquired planes
+static int slab_finish_enqueue(mvsim_ctx* ctx, const int64_t dim[3], const mvsim_view_params* p, int64_t z0, int64_t z1, float* acq,
+                               int64_t* n_planes);
 
 int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim_view_params* p, int64_t z0,
                                int64_t z1, double total_sum, float* acq, int64_t* n_planes)
@@ -1497,6 +1538,15 @@ int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim
     MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
     MVSIM_HIP(hipMemcpyAsync(scal, &total_sum, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MVSIM_HIP(hipStreamSynchronize(ctx->stream));          // total_sum lives on the caller's stack
+    return slab_finish_enqueue(ctx, dim, p, z0, z1, acq, n_planes);
+}
+
+static int slab_finish_enqueue(mvsim_ctx* ctx, const int64_t dim[3], const mvsim_view_params* p, int64_t z0, int64_t z1, float* acq,
+                               int64_t* n_planes)
+{
+    const int64_t plane = dim[0] * dim[1];
+    double *partial, *scal;
+    MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
     MVSIM_TRY(launch_adjust_corr(ctx->stream, scal, nvox(dim), p->min_value, p->target_average));
     const int64_t k0 = (z0 + p->inc - 1) / p->inc, k1 = (z1 + p->inc - 1) / p->inc;     // acquired planes k: z0 <= k*inc < z1
     if (n_planes) *n_planes = k1 - k0;
@@ -1523,6 +1573,23 @@ int mvsim_view_slab_finish_dev(mvsim_ctx* ctx, const int64_t dim[3], const mvsim
     return launch_extract(ctx->stream, ctx->vol_a.as<float>() + plane * (first - z0), acq, ldim, p->inc, true, scal,
                           p->min_value, noise, mvsim_poisson_mul((double)p->snr), p->seed, p->stream,
                           (uint64_t)(first * plane), qws, qm);
+}
+
+// One tiled view's slab in ONE call, nothing through the host (round 6): the slab's share of adjustImage's sum stays on the device, is
+// reduced over the ranks in place -- on THIS context's stream, by the communicator of `comm_ctx` (null: this context's own; a context
+// without one, or a job of one rank, reduces nothing) -- and the adjusted, extracted, sampled planes follow behind it.  Asynchronous.
+int mvsim_view_slab_dev(mvsim_ctx* ctx, mvsim_ctx* comm_ctx, const float* gt, const int64_t dim[3], float* psf_host,
+                        const int64_t kdim[3], const mvsim_view_params* p, int64_t z0, int64_t z1, float* acq, int64_t* n_planes)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr && p != nullptr && acq != nullptr, "null pointer");
+    MVSIM_CHECK_ARG(p->inc >= 1, "inc must be >= 1");
+    MVSIM_TRY(slab_convolve_enqueue(ctx, gt, dim, psf_host, kdim, p, z0, z1));
+    double *partial, *scal;
+    MVSIM_TRY(scal_ptr(ctx, &partial, &scal));
+    mvsim_ctx* cc = comm_ctx ? comm_ctx : ctx;
+    MVSIM_CHECK_ARG(cc->device == ctx->device, "the communicator's context lives on another device");
+    MVSIM_TRY(comm_allreduce_f64_on_stream(cc, scal, ctx->stream));
+    return slab_finish_enqueue(ctx, dim, p, z0, z1, acq, n_planes);
 }
 
 // ---- host-buffer entry points (JNI boundary) ---------------------------------------------------------

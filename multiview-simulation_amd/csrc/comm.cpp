@@ -457,6 +457,14 @@ int mvsim_comm_allreduce_sum_f64(mvsim_ctx* ctx, double* value_host)
     return MVSIM_OK;
 }
 
+int mvsim_comm_allreduce_sum_f64_dev(mvsim_ctx* ctx, double* value_dev, void* hip_stream)
+{
+    MVSIM_CHECK_ARG(ctx != nullptr && value_dev != nullptr, "null pointer");
+    MVSIM_CHECK_ARG(ctx->comm != nullptr, "communicator not initialised");
+    MVSIM_HIP(hipSetDevice(ctx->device));
+    return mvsim::comm_allreduce_f64_on_stream(ctx, value_dev, hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream);
+}
+
 int mvsim_comm_destroy(mvsim_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return MVSIM_OK;
@@ -621,5 +629,14 @@ int mvsim_group_simulate_views(mvsim_group* g, float* const* psf_host, const int
 }  // extern "C"
 
 namespace mvsim {
+// the sum of one device-resident double over the ranks, in place, on the caller's stream (mvsim_view_slab_dev: the slab sums of a tiled
+// view).  A context without a communicator, or a job of one rank, has nothing to add.
+int comm_allreduce_f64_on_stream(mvsim_ctx* cc, double* value_dev, hipStream_t s)
+{
+    if (!cc || !cc->comm || cc->nranks <= 1) return MVSIM_OK;
+    MVSIM_NCCL(ncclAllReduce(value_dev, value_dev, 1, ncclDouble, ncclSum, (ncclComm_t)cc->comm, s));
+    return MVSIM_OK;
+}
+
 void comm_forget_range(mvsim_ctx* ctx, const void* p, size_t bytes) { peer_copy_forget(ctx, p, bytes); }
 }  // namespace mvsim

@@ -417,8 +417,10 @@ size_t fused_tail_queue_bytes(const int64_t dim[3], const int64_t kdim[3], int i
 // plane / idx_inc / index_offset: how the RNG counter of an output element follows from its position (ResolveJob)
 int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const unsigned int* qcount, int segments, unsigned int segcap,
                            double mul, uint64_t seed, uint32_t stream, long long plane, int idx_inc, uint64_t index_offset);
+int comm_allreduce_f64_on_stream(mvsim_ctx* cc, double* value_dev, hipStream_t s);      // comm.cpp
 int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, float* att_or_null, const int64_t dim[3],
-                          const int64_t kdim[3], const Affine& inv, double delta, bool* done, const int** plane_nz = nullptr);
+                          const int64_t kdim[3], const Affine& inv, double delta, bool* done, const int** plane_nz = nullptr,
+                          int z_first = 0, int nzl = -1);
 int fft_convolve(mvsim_ctx* ctx, const float* img_dev, const int64_t dim[3], const float* psf_dev,
                  const int64_t kdim[3], float* out_dev, ConvTail* tail);
 void fft_release(mvsim_ctx* ctx);

@@ -416,6 +416,7 @@ struct RotFftArgs {
     const float2* twg;          // plan twiddles of length M (see wpasses)
     const float2* twx;          // exp(-2 pi i k / Px), k = 0..Px
     int nx, ny, nz, steps;
+    int z_first, nzl;           // planes z_first .. z_first + nzl - 1 of the rotated volume are computed (a z slab; whole view: 0, nz); outputs are indexed from 0
     int hxp, py;
     int halo_r, halo_l;         // mirrored positions right of the row (kx / 2) and at the end of the padded row (kx - 1 - kx / 2)
     Affine a;

@@ -1688,8 +1688,10 @@ bool custom_fft_batchable(const mvsim_ctx* ctx, const int64_t dim[3], const int6
 // volume then never crosses HBM unless the caller asked for it.  *done = false: nothing was enqueued, the caller runs the
 // separate kernels.  On success the context's spectrum buffer F holds what pass A would have written for `att`, and the
 // convolution is told so through ConvTail::x_done.
+// z_first / nzl: the planes of the rotated volume to compute (a z slab of a tiled view: its own planes and the halo the PSF reaches;
+// nzl < 0: all of them).  F then holds those planes from index 0, as pass A leaves them for custom_fft_convolve_slab.
 int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, float* att_or_null, const int64_t dim[3],
-                          const int64_t kdim[3], const Affine& inv, double delta, bool* done, const int** plane_nz)
+                          const int64_t kdim[3], const Affine& inv, double delta, bool* done, const int** plane_nz, int z_first, int nzl)
 {
     using namespace fft;
     *done = false;
@@ -1701,6 +1703,8 @@ int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, f
     int64_t P[3];
     if (!custom_fft_sizes(dim, kdim, P, ctx->opt)) return MVSIM_OK;
     const int nx = (int)dim[0], ny = (int)dim[1], nz = (int)dim[2];
+    if (nzl < 0) { z_first = 0; nzl = nz; }
+    if (z_first < 0 || nzl < 1 || z_first + nzl > nz) return MVSIM_OK;
     const int kx = (int)kdim[0], ky = (int)kdim[1], kz = (int)kdim[2];
     const bool zdirect = ctx->opt.zpass == 2 ? false : kz <= 64;
     // pass B must be reading the mirrored halo rows from their mirror images (pass A then transforms the Ny rows of a plane
@@ -1710,12 +1714,12 @@ int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, f
     const int px = (int)P[0], py = (int)P[1], M = px / 2;
     if (!rot_fftx_has_plan(M)) return MVSIM_OK;
     // auto: from two waves per SIMD of columns up (below that the kernel is a handful of serial waves, like its parent)
-    if (ctx->opt.fused_fftx == 2 && (int64_t)nx * nz < 131072) return MVSIM_OK;
+    if (ctx->opt.fused_fftx == 2 && (int64_t)nx * nzl < 131072) return MVSIM_OK;
     const int tile_y = lines_per_tile(py);
     const int tw_max = tile_y > NLZ ? tile_y : NLZ;
     const int hxp = ((M + 1 + tw_max - 1) / tw_max) * tw_max;
     const int pyb = (py + ZB - 1) / ZB * ZB;
-    const size_t cbytes = (size_t)hxp * pyb * nz * sizeof(float2);     // the size custom_fft_convolve_slab reserves
+    const size_t cbytes = (size_t)hxp * pyb * nzl * sizeof(float2);    // the size custom_fft_convolve_slab reserves
     MVSIM_TRY(ctx->cfft_f.reserve(cbytes));
     MVSIM_TRY(ctx->cfft_g.reserve(cbytes));
     const float2 *tw_m, *tw_px;
@@ -1725,6 +1729,7 @@ int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, f
     a.in = gt; a.rot_out = rot_or_null; a.att_out = att_or_null; a.dst = ctx->cfft_f.as<float2>();
     a.twg = tw_m; a.twx = tw_px;
     a.nx = nx; a.ny = ny; a.nz = nz; a.steps = nx;                     // Q1: attenuate3d walks dimension(0) steps along y
+    a.z_first = z_first; a.nzl = nzl;
     a.hxp = hxp; a.py = py;
     a.halo_r = kx / 2; a.halo_l = kx - 1 - kx / 2;
     a.a = inv; a.delta = delta;
@@ -1732,7 +1737,7 @@ int rotate_attenuate_fftx(mvsim_ctx* ctx, const float* gt, float* rot_or_null, f
     // strings of the z pass): the last flagged view says how many planes were empty (a page-locked word the device writes, read here
     // without waiting -- a hint, nothing depends on its being current), and while that was none only every sixteenth view carries
     // flags, to notice when the data change.  Results are the same with and without flags.
-    bool want_flags = plane_nz && ctx->opt.skip_empty;
+    bool want_flags = plane_nz && ctx->opt.skip_empty && nzl == nz;     // (a slab keeps the unflagged passes)
     if (want_flags) {
         if (!ctx->empty_hint) {
             MVSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->empty_hint), 4 * sizeof(int), hipHostMallocDefault));
@@ -1919,7 +1924,8 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
         if (ymirror) { ma.y = DimMap{m.y.n, m.y.P, m.y.n, 0, 0, 0}; ma.enum_y = m.y.n; }   // and visits no other row
         if (tail && tail->x_done) {
             // the fused rotate + attenuate + x transform has left the spectrum of the attenuated rows in F already
-            if (!(zdirect && ymirror) || is_slab) { set_error("x_done without the geometry of the fused x transform"); return MVSIM_EINVAL; }
+            // (a slab's fused kernel has computed its nz_in input planes -- the slab and its halo -- and left them in F from plane 0)
+            if (!(zdirect && ymirror) || V != 1) { set_error("x_done without the geometry of the fused x transform"); return MVSIM_EINVAL; }
         } else {
             ev_begin(ctx, ST_PASS_A);
             MVSIM_TRY(launch_r2c(ctx, M, img, ma, F, tw_m, tw_px, hxp, zdirect ? (long long)(ymirror ? m.y.n : py) * nzs * V : rows_all));

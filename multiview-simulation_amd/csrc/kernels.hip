@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_pack_u16(const float* __restrict__ in, 
     uint4* __restrict__ out8 = reinterpret_cast<uint4*>(out16);
     auto cvt = [&](float v) -> unsigned int {
         const unsigned int u = (unsigned int)fminf(fmaxf(v, 0.f), 65535.f);
-        bad |= !((float)u == v);
+        bad |= __float_as_uint((float)u) != __float_as_uint(v);      // bit patterns: -0.0f does not pass for +0.0f
         return u;
     };
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += nthreads) {

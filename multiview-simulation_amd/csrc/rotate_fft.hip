@@ -59,13 +59,16 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
     // (measured 0.40 -> 0.36 ms at 512^3 on the sphere phantom).
     const int slab = (gridDim.x + 7) / 8;
     const int hs = slab / 2, jb = (int)(blockIdx.x / 8u), kb = (int)(blockIdx.x % 8u);
-    const int z = (hs > 0 && slab == 2 * hs) ? ((jb < hs) ? kb * hs + jb : (int)gridDim.x / 2 + kb * hs + (jb - hs))
-                                             : kb * slab + jb;
-    if (z >= nz) return;                                          // whole block: uniform
+    // zl: the plane's index in this launch (rows of `dst`, planes of rot_out / att_out, plane_nz); z: which plane of the rotated
+    // volume it is -- a z slab of a tiled view (mvsim_view_slab_*: planes z_first .. z_first + nzl - 1) computes its own planes only
+    const int zl = (hs > 0 && slab == 2 * hs) ? ((jb < hs) ? kb * hs + jb : (int)gridDim.x / 2 + kb * hs + (jb - hs))
+                                              : kb * slab + jb;
+    if (zl >= p.nzl) return;                                      // whole block: uniform
+    const int z = p.z_first + zl;
     const bool active = x < nx;
     const long long row = (long long)nx;
     const long long plane = row * ny;
-    const long long out_plane = plane * z;
+    const long long out_plane = plane * zl;
     const double l2 = (double)z;
     const char* __restrict__ in_b = reinterpret_cast<const char*>(p.in);
     const long long row_b = row * 4, plane_b = plane * 4;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
     // one row, owned by the calling wave: transform, post-process to the half spectrum, store (k_fft_x_r2c's arithmetic)
     auto transform_store = [&](float2* wbuf, int y) {
         PLAN::template run<1>(wbuf, tw, lane);
-        float2* __restrict__ drow = p.dst + ((long long)z * p.py + y) * p.hxp;
+        float2* __restrict__ drow = p.dst + ((long long)zl * p.py + y) * p.hxp;
         constexpr int HQ = M / 4;
 #pragma unroll 1
         for (int q = lane; q < HQ; q += 64) {
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
         }
     };
     auto zero_row = [&](int y) {                                  // the spectrum of a zero row
-        float4* __restrict__ drow = reinterpret_cast<float4*>(p.dst + ((long long)z * p.py + y) * p.hxp);
+        float4* __restrict__ drow = reinterpret_cast<float4*>(p.dst + ((long long)zl * p.py + y) * p.hxp);
         for (int i = lane; i < p.hxp / 2; i += 64) drow[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(1024) void k_rotate_attenuate_fftx(RotFftArgs p)
         __syncthreads();
         if (lane == 0 && plane_any != 0u) atomicOr(blk_any, 1u);
         __syncthreads();
-        if (x == 0) p.plane_nz[z] = (int)*blk_any;
+        if (x == 0) p.plane_nz[zl] = (int)*blk_any;
     }
     // rows the reference never visits (Ny > Nx): the attenuated image stays zero there; rot still has its values
     for (int yy = ny - 1 - steps; yy >= 0; --yy) {
@@ -381,7 +384,7 @@ static int launch_rot_fftx_t(mvsim_ctx* ctx, const RotFftArgs& a, bool write_out
     const size_t lds = (size_t)(2 * G * UF * (M + 1) + M + (M & 1) + (M + 1) + ((M + 1) & 1)) * sizeof(float2) + (size_t)geo_chunk_f(G) * sizeof(RowGeoF) +
                        (size_t)(geo_chunk_f(G) / UF) * sizeof(int) + (size_t)(2 * G * 16 + 4) * sizeof(unsigned int);
     if (lds > 160 * 1024) { set_error("fused rotate + x transform: %zu bytes of LDS", lds); return MVSIM_EINVAL; }
-    dim3 grid((unsigned)((a.nz + 7) / 8 * 8)), block((unsigned)(waves * 64));
+    dim3 grid((unsigned)((a.nzl + 7) / 8 * 8)), block((unsigned)(waves * 64));
 #define MVSIM_RF(W_, G_)                                                                                            \
     do {                                                                                                            \
         MVSIM_TRY(ensure_lds_attr(ctx, reinterpret_cast<const void*>(k_rotate_attenuate_fftx<PLAN, W_, G_>), lds)); \

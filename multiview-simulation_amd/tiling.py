@@ -61,6 +61,23 @@ class TiledView:
         k0, k1 = acquired_planes(z0, z1, inc)
         return k1 - k0
 
+    def run_on_device(self, gt_dptr: int, dim_xyz, psf, params, acq_dptr: int) -> dict:
+        """One tiled view through `mvsim_view_slab_dev` (round 6): the same three steps as ONE asynchronous call -- the slab's share of
+        the sum never leaves the device, the reduction runs on the compute context's stream through `comm_ctx`'s communicator, nothing
+        waits for the host.  Needs the C ABI's communicator (or a job of one rank); `run` remains for reductions the caller brings."""
+        if self._allreduce is not None and self.world > 1:
+            raise RuntimeError("run_on_device reduces through the C ABI's communicator; use run() with a caller-supplied reduction")
+        nz = int(dim_xyz[2])
+        z0, z1 = self.slab(nz)
+        got = self.ctx.view_slab_dev(gt_dptr, dim_xyz, psf, params, z0, z1, acq_dptr,
+                                     comm_ctx=self.comm_ctx if self.comm_ctx is not self.ctx else None)
+        k0, k1 = acquired_planes(z0, z1, int(params.inc))
+        if got != k1 - k0:
+            raise RuntimeError(f"rank {self.rank}: slab [{z0},{z1}) produced {got} planes, expected {k1 - k0}")
+        za, zb = halo_planes(nz, int(psf.shape[0]), z0, z1)
+        return {"z0": z0, "z1": z1, "k0": k0, "k1": k1, "planes_rotated": zb - za, "planes_owned": z1 - z0,
+                "convolve_ms": 0.0, "allreduce_ms": 0.0}
+
     def run(self, gt_dptr: int, dim_xyz, psf, params, acq_dptr: int) -> dict:
         """One tiled view.  `acq_dptr` receives this rank's acquired planes (acq_planes() of them, Nx * Ny floats each).
         Returns the slab's geometry and where the time went (host clocks; the first two steps end in a synchronisation by

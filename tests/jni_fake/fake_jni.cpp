@@ -41,6 +41,7 @@ struct State {
     std::string pending_class, pending_msg;
     bool pending = false;
     int violations = 0;             // JNI calls made with an exception pending (other than ExceptionCheck), or on wrong kinds
+    int critical = 0;               // open GetPrimitiveArrayCritical regions: no other JNI call may be made inside one
     std::string violation;
     Obj* make(Kind k)
     {
@@ -76,6 +77,7 @@ Obj* as(jobject o, Kind k, const char* what)
 void no_pending(const char* what)
 {
     if (g.pending) g.violate(what);
+    if (g.critical > 0) g.violate("a JNI call inside a GetPrimitiveArrayCritical region");
 }
 
 template <class T>
@@ -178,6 +180,24 @@ void JNIEnv_::SetDoubleArrayRegion(jdoubleArray array, jsize start, jsize len, c
     if (a && region_ok(a->doubles, start, len) && len) std::memcpy(a->doubles.data() + start, buf, sizeof(jdouble) * static_cast<size_t>(len));
 }
 
+void* JNIEnv_::GetPrimitiveArrayCritical(jarray array, jboolean* isCopy)
+{
+    no_pending("GetPrimitiveArrayCritical with an exception pending");
+    Obj* a = static_cast<Obj*>(static_cast<_jobject*>(array));
+    if (!a || a->kind != K_FLOATS) { g.violate("GetPrimitiveArrayCritical: not a float[] (the only kind the shim holds critically)"); return nullptr; }
+    if (isCopy) *isCopy = JNI_FALSE;
+    g.critical += 1;
+    return a->floats.data();
+}
+
+void JNIEnv_::ReleasePrimitiveArrayCritical(jarray array, void* carray, jint mode)
+{
+    Obj* a = static_cast<Obj*>(static_cast<_jobject*>(array));
+    if (!a || a->kind != K_FLOATS || carray != a->floats.data() || g.critical <= 0) { g.violate("ReleasePrimitiveArrayCritical without its Get"); return; }
+    (void)mode;                                             // the fake never copies: there is nothing to commit or abort
+    g.critical -= 1;
+}
+
 jobject JNIEnv_::NewDirectByteBuffer(void* address, jlong capacity)
 {
     no_pending("NewDirectByteBuffer with an exception pending");
@@ -216,6 +236,7 @@ JNIEXPORT void fake_reset(void)
     g.pending_msg.clear();
     g.violations = 0;
     g.violation.clear();
+    g.critical = 0;
 }
 
 JNIEXPORT void* fake_long_array(const int64_t* v, int n)
@@ -269,6 +290,16 @@ JNIEXPORT int fake_read_longs(void* array, int64_t* out, int n)
     std::memcpy(out, a->longs.data(), sizeof(int64_t) * static_cast<size_t>(n));
     return 0;
 }
+
+JNIEXPORT int fake_read_floats(void* array, float* out, int n)
+{
+    Obj* a = static_cast<Obj*>(static_cast<_jobject*>(array));
+    if (!a || a->kind != K_FLOATS || static_cast<size_t>(n) > a->floats.size()) return -1;
+    std::memcpy(out, a->floats.data(), sizeof(float) * static_cast<size_t>(n));
+    return 0;
+}
+
+JNIEXPORT int fake_critical_depth(void) { return g.critical; }
 
 JNIEXPORT int fake_read_doubles(void* array, double* out, int n)
 {

@@ -14,6 +14,8 @@
 #define JNICALL
 #define JNI_TRUE 1
 #define JNI_FALSE 0
+#define JNI_COMMIT 1
+#define JNI_ABORT 2
 
 typedef unsigned char jboolean;
 typedef int32_t       jint;
@@ -52,6 +54,8 @@ struct JNIEnv_ {
     void     SetLongArrayRegion(jlongArray array, jsize start, jsize len, const jlong* buf);
     void     GetFloatArrayRegion(jfloatArray array, jsize start, jsize len, jfloat* buf);
     void     SetDoubleArrayRegion(jdoubleArray array, jsize start, jsize len, const jdouble* buf);
+    void*    GetPrimitiveArrayCritical(jarray array, jboolean* isCopy);
+    void     ReleasePrimitiveArrayCritical(jarray array, void* carray, jint mode);
     jobject  NewDirectByteBuffer(void* address, jlong capacity);
     void*    GetDirectBufferAddress(jobject buf);
     jlong    GetDirectBufferCapacity(jobject buf);

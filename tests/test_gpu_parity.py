@@ -975,6 +975,48 @@ def test_view_slab_tiling_matches_the_whole_view(mvs, synth, n, kz, inc, nslabs)
             c.close()
 
 
+@pytest.mark.parametrize("n,kz,inc,nslabs", [(128, 15, 2, 2), (96, 9, 1, 3), (128, 31, 4, 1)])
+def test_view_slab_in_one_call_on_the_device(mvs, synth, n, kz, inc, nslabs):
+    """Round 6: `mvsim_view_slab_dev` -- convolve, reduce, finish as ONE asynchronous call whose slab sum never
+    leaves the device -- and the slab's planes through the fused rotate + attenuate + x-transform kernel (planes z_first .. of the
+    rotated volume).  With the slab's own sum as the total (a communicator of one rank adds nothing) the one call must equal the
+    three-step form bit for bit, with and without the fused kernel; a single slab that is the whole view must equal the untiled view."""
+    gt = synth.sphere_phantom(n)
+    psf = synth.gaussian_psf(7, 9, kz, sigma=(1.3, 1.5, max(1.0, kz / 5)))
+    dims = (n, n, n)
+    with mvs.Context(0) as c:
+        d_gt = _dev_volume(c, gt)
+        d_a, d_b = c.dev_alloc(n * n * n * 4), c.dev_alloc(n * n * n * 4)
+        try:
+            for noise in (False, True):
+                p = c.view_params(degrees=50, delta=0.01, inc=inc, snr=25.0 if noise else -1.0, seed=SEED, stream=5, conv_method=1)
+                for r in range(nslabs):
+                    z0, z1 = c.slab_range(n, nslabs, r)
+                    got = {}
+                    for fused in (0, 1):
+                        c.set_option("fused_fftx", fused)
+                        own = c.view_slab_convolve_dev(d_gt, dims, psf.copy(), p, z0, z1)
+                        k = c.view_slab_finish_dev(dims, p, z0, z1, own, d_a)
+                        three = c.download(d_a, (k, n, n))
+                        k1 = c.view_slab_dev(d_gt, dims, psf.copy(), p, z0, z1, d_b)
+                        assert k1 == k and k > 0
+                        one = c.download(d_b, (k, n, n))
+                        assert np.array_equal(one, three), (noise, r, fused)
+                        got[fused] = one
+                    assert np.array_equal(got[0], got[1]), (noise, r)       # the fused kernel leaves pass A's spectrum, bit for bit
+                    c.set_option("fused_fftx", "auto")
+                if nslabs == 1:
+                    ref = c.simulate_view(gt, psf.copy(), p, want=("acq",))["acq"]
+                    if noise:
+                        assert (got[1] != ref).mean() < 0.005
+                    else:
+                        assert rel_to_max(got[1], ref) <= 1e-6
+        finally:
+            c.set_option("fused_fftx", "auto")
+            for d in (d_gt, d_a, d_b):
+                c.dev_free(d)
+
+
 def test_view_slab_rejects_what_it_cannot_tile(ctx, synth):
     gt = synth.sphere_phantom(32)
     d = _dev_volume(ctx, gt)

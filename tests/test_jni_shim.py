@@ -33,6 +33,7 @@ SIGNATURES = {
     "axisRotation": (None, [ptr, i32, i32, ptr]),
     "allocPinned": (ptr, [i64, i64]),
     "freePinned": (None, [ptr]),
+    "copyFloats": (None, [i64, ptr, i64, ptr, i32, i32, u8]),
     "drawSpheres": (i64, [i64, ptr, ptr, f64, f64, i32, u8, ptr]),
     "splatSpheres": (None, [i64, ptr, ptr, ptr, ptr]),
     "normalizeWeights": (None, [i64, ptr, i64, f32]),
@@ -59,6 +60,7 @@ class FakeJvm:
         lib.fake_buffer_capacity.argtypes = [ptr]
         lib.fake_read_longs.argtypes = [ptr, C.POINTER(i64), C.c_int]
         lib.fake_read_doubles.argtypes = [ptr, C.POINTER(f64), C.c_int]
+        lib.fake_read_floats.argtypes = [ptr, C.POINTER(f32), C.c_int]
         lib.fake_take_exception.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
         lib.fake_violations.argtypes = [C.c_char_p, C.c_int]
         self.env = lib.fake_env()
@@ -107,6 +109,16 @@ class FakeJvm:
         out = (i64 * n)()
         assert self.lib.fake_read_longs(obj, out, n) == 0
         return list(out)
+
+    def float_array(self, array):
+        """A Java float[] holding a copy of `array`."""
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        return self.lib.fake_float_array(a.ctypes.data_as(C.POINTER(f32)), a.size)
+
+    def read_floats(self, obj, n):
+        out = np.empty(n, np.float32)
+        assert self.lib.fake_read_floats(obj, out.ctypes.data_as(C.POINTER(f32)), n) == 0
+        return out
 
     def read_doubles(self, obj, n):
         out = (f64 * n)()
@@ -170,6 +182,42 @@ def test_axis_rotation_fills_the_double_array_like_the_c_abi(vm, mvs):
     got = np.array(vm.read_doubles(m12, 12)).reshape(3, 4)
     assert np.array_equal(got, mvs.SimulateMultiViewDataset.axisRotation((40, 30, 20), 1, 35))
     assert np.allclose(got[:, :3] @ got[:, :3].T, np.eye(3), atol=1e-12)
+
+
+def test_copy_floats_between_heap_arrays_and_blocks(vm):
+    """MvsimNative.copyFloats (round 6): the facade's bulk copies between a Java float[] and a staging block on the library's host
+    threads.  The array is held with GetPrimitiveArrayCritical -- no JNI call inside the region (the fake counts that as a violation)
+    and the region is closed again --, ranges are checked before anything moves, 20 MB travel through the multi-threaded path
+    (4 MiB chunks), a few floats through the plain one."""
+    rng = np.random.default_rng(9)
+    n = 5_000_003
+    src = rng.random(n, dtype=np.float32)
+    block = src.copy()
+    arr = vm.float_array(np.zeros(n + 7, np.float32))
+    vm.call("copyFloats", 0, vm.float_buffer(block), 0, arr, 7, n, 1)                   # block -> array[7:]
+    assert vm.exception() is None and vm.lib.fake_critical_depth() == 0
+    got = vm.read_floats(arr, n + 7)
+    assert np.array_equal(got[7:], src) and not got[:7].any()
+    back = np.zeros(n, np.float32)
+    vm.call("copyFloats", 0, vm.float_buffer(back), 3, arr, 7 + 3, n - 3, 0)            # array[10:] -> block[3:]
+    assert vm.exception() is None and vm.lib.fake_critical_depth() == 0
+    assert np.array_equal(back[3:], src[3:]) and not back[:3].any()
+    small = vm.float_array(np.arange(10, dtype=np.float32))
+    blk = np.zeros(10, np.float32)
+    vm.call("copyFloats", 0, vm.float_buffer(blk), 2, small, 4, 5, 0)
+    assert vm.exception() is None and np.array_equal(blk, [0, 0, 4, 5, 6, 7, 8, 0, 0, 0])
+    vm.call("copyFloats", 0, vm.float_buffer(blk), 0, small, 0, 0, 1)                  # nothing to do
+    assert vm.exception() is None
+    # ranges: outside the array, outside the block, a heap buffer, a null array
+    vm.call("copyFloats", 0, vm.float_buffer(blk), 0, small, 6, 5, 1)
+    assert vm.exception() == ("java/lang/ArrayIndexOutOfBoundsException", "copyFloats: range outside the array")
+    vm.call("copyFloats", 0, vm.float_buffer(blk), 0, None, 0, 5, 1)
+    assert vm.exception() == ("java/lang/ArrayIndexOutOfBoundsException", "copyFloats: range outside the array")
+    vm.call("copyFloats", 0, vm.float_buffer(blk), 6, small, 0, 5, 1)
+    assert vm.exception() == (IAE, "copyFloats: range outside the block")
+    vm.call("copyFloats", 0, vm.heap_buffer(10), 0, small, 0, 5, 1)
+    assert vm.exception() == (IAE, "a direct FloatBuffer is required")
+    assert vm.lib.fake_critical_depth() == 0 and np.array_equal(vm.read_floats(small, 10), np.arange(10, dtype=np.float32))
 
 
 def test_wrong_arguments_become_illegal_argument_exceptions_before_any_copy(vm):
