@@ -734,31 +734,65 @@ __device__ __forceinline__ bool refused_collect(const ResolveJob& j, long long s
     return true;
 }
 
-// One queue segment resolved by the 256 lanes of a block (k_poisson_resolve: kernels.hip).
-__device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long long segment, int t, unsigned int* ticket)
+// S queue segments resolved by the 256 lanes of a block (k_poisson_resolve: kernels.hip).  The group's segments are first,
+// first + stride, ... (those below `segments`), and their items form ONE list: a lane that has resolved its item takes the next item
+// of the GROUP.  Round 6: with one segment per block (S = 1, rounds 2-5) a block's ~400 bright items were 1.6 items per lane -- a wave
+// ran two trips with every lane busy and then three more for the retries of its last items (each attempt is accepted with
+// probability 0.6-0.9, so the tail is 3-4 trips whatever the list's length): 40 % of its lane slots did work.  The tail is paid per
+// block, not per segment: S segments cost 2 S + 3 trips instead of 5 S.  Same arithmetic per (voxel, attempt): counts unchanged.
+template <int S>
+__device__ __forceinline__ void resolve_group_body(const ResolveJob& j, long long first, long long stride, long long segments, int t,
+                                                   unsigned int* ticket)
 {
-    const unsigned int n = j.qcount[QCOUNT_WORDS * segment], ns = j.qcount[QCOUNT_WORDS * segment + 1];
+    unsigned int cn[S], cs[S];                               // inclusive prefix counts over the group: bright items, inversion items
+    unsigned int n = 0u, ns = 0u;
+    bool refused = false;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+        const long long sg = first + (long long)m * stride;
+        if (sg < segments) {                                 // block-uniform
+            n += j.qcount[QCOUNT_WORDS * sg];
+            ns += j.qcount[QCOUNT_WORDS * sg + 1];
+            refused |= j.qcount[QCOUNT_WORDS * sg + 2] != 0u;
+        }
+        cn[m] = n; cs[m] = ns;
+    }
     // a block that was refused queue slots says so in the header: k_poisson_refused, the next kernel, reads that one word
-    if (t == 0 && j.walk != 0 && j.qcount[QCOUNT_WORDS * segment + 2] != 0u) const_cast<unsigned int*>(j.qcount)[QCOUNT_HEADER + 2] = 1u;
-    const PItem* __restrict__ seg = j.queue + (unsigned long long)segment * j.segcap;
-    // inversion items (0 < lambda < 10 that the shortcut of phase 1 could not settle), from the back
+    if (t == 0 && j.walk != 0 && refused) const_cast<unsigned int*>(j.qcount)[QCOUNT_HEADER + 2] = 1u;
+    // item i of the group's list: which segment, and where in it
+    auto locate = [&](const unsigned int* cum, unsigned int i, unsigned int& local) -> const PItem* {
+        unsigned int m = 0u, base = 0u;
+#pragma unroll
+        for (int q = 0; q + 1 < S; ++q)
+            if (i >= cum[q]) { m = (unsigned int)(q + 1); base = cum[q]; }
+        local = i - base;
+        return j.queue + (unsigned long long)(first + (long long)m * stride) * j.segcap;
+    };
+    // inversion items (0 < lambda < 10 that the shortcut of phase 1 could not settle), from the back of their segments
     for (unsigned int i = (unsigned int)t; i < ns; i += 256u) {
-        const PItem it = seg[j.segcap - 1u - i];
+        unsigned int local;
+        const PItem* __restrict__ seg = locate(cs, i, local);
+        const PItem it = seg[j.segcap - 1u - local];
         j.out[it.out] = poisson_small((double)it.v * j.mul, it.w0);     // w0: the voxel's word of its group block
     }
     // PTRS items.  A lane works on ONE ATTEMPT per trip and, the moment its item is resolved, takes the next item of the
-    // segment (LDS ticket): every trip has every lane on a live attempt, instead of the wave idling until its unluckiest
+    // group (LDS ticket): every trip has every lane on a live attempt, instead of the wave idling until its unluckiest
     // item -- retries come in geometrically distributed numbers -- has been accepted.  The loop ends when the tickets run
-    // out: each attempt succeeds with probability > 0.8 and the attempt count is capped, so every lane gets there.
+    // out: each attempt succeeds with probability > 0.6 and the attempt count is capped, so every lane gets there.
     if (t == 0) *ticket = 256u;
     __syncthreads();
     unsigned int i = (unsigned int)t;
     PItem it;
     it.out = 0u; it.v = 0.f; it.w0 = 0u; it.w1 = 0u;
     bool have = i < n;
-    if (have) it = seg[i];
+    if (have) { unsigned int local; const PItem* __restrict__ seg = locate(cn, i, local); it = seg[local]; }
+    // The words of the attempt a lane is about to evaluate always sit in it.w0 / it.w1: phase 1's words for attempt 0, and for a retry the
+    // words drawn at the END of the failed attempt.  (Rounds 2-5 chose between the two at the top of the loop, by `a == 0`; the compiler
+    // threaded that test through the back edges, and what came out was an outer loop over items with an INNER loop over the retries of
+    // one item -- lanes whose item was accepted waited for the wave's unluckiest item before any of them took a new one, the very thing
+    // the ticket is there to avoid.  Found in the ISA in round 6.)
     uint32_t a = 0u;
-    while (have) {
+    if (have) do {
         const double lam = (double)it.v * j.mul;
         float val = 0.f;
         bool done;
@@ -766,26 +800,23 @@ __device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long l
             val = (float)(long long)lam;
             done = true;
         } else {
-            uint32_t w0, w1;
-            if (a == 0u) {
-                w0 = it.w0;                                          // the words phase 1 drew for attempt 0
-                w1 = it.w1;
-            } else {
-                const unsigned int kpl = j.idx_inc == 1u ? 0u : it.out / j.plane;
-                const unsigned long long index = j.index_offset + (unsigned long long)it.out + (unsigned long long)kpl * (j.idx_inc - 1u) * j.plane;
-                ptrs_retry_words(index, a, j.k0, j.k1, j.stream, w0, w1);
-            }
-            done = ptrs_step_words(lam, w0, w1, val);
+            done = ptrs_step_words(lam, it.w0, it.w1, val);
         }
         if (done) {
             j.out[it.out] = val;
             i = atomicAdd(ticket, 1u);
             have = i < n;
-            if (have) { it = seg[i]; a = 0u; }
+            if (have) { unsigned int local; const PItem* __restrict__ seg = locate(cn, i, local); it = seg[local]; a = 0u; }
         } else {
             a += 1u;
+            const unsigned int kpl = j.idx_inc == 1u ? 0u : it.out / j.plane;
+            const unsigned long long index = j.index_offset + (unsigned long long)it.out + (unsigned long long)kpl * (j.idx_inc - 1u) * j.plane;
+            ptrs_retry_words(index, a, j.k0, j.k1, j.stream, it.w0, it.w1);
         }
-    }
+        // ONE latch: a convergent no-op the optimiser may not duplicate, so that the retry path cannot get a back edge of its own
+        // (on it `have` is known to be true, and the loop would be split into the nested form described above again)
+        __builtin_amdgcn_wave_barrier();
+    } while (have);
 }
 
 }  // namespace mvsim

@@ -1985,14 +1985,24 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
     import subprocess
     import sys
     bench = os.path.join(ROOT, "bench.py")
-    for extra in (["--broadcast", "scatter_allgather"], ["--broadcast", "ring", "--serial"], ["--broadcast", "peer_copy"], ["--broadcast", "pipelined"]):
+    # one form per run (--no-broadcast-ab: the line times --broadcast's form and nothing else), then the default: the line's own form and
+    # the other forms back to back in one invocation, the fastest reported (multi_gpu.broadcast_ab)
+    for extra in (["--broadcast", "scatter_allgather", "--no-broadcast-ab"], ["--broadcast", "ring", "--serial", "--no-broadcast-ab"],
+                  ["--broadcast", "peer_copy", "--no-broadcast-ab"], ["--broadcast", "pipelined", "--no-broadcast-ab"], []):
         r = subprocess.run([sys.executable, bench, "--rehearse-multi", "--size", "256", "--psf", "15", "--steps", "2", "--warmup", "1",
                             "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         assert "rehearsal" in d and d["value"] > 0 and "mvsim_comm_broadcast_volume" in d["config"]["collective"]
-        assert extra[1] in d["config"]["collective"]
+        if extra:
+            assert extra[1] in d["config"]["collective"] and "broadcast_ab" not in d["multi_gpu"]
+        else:
+            ab = d["multi_gpu"]["broadcast_ab"]
+            assert sorted(ab) == ["peer_copy", "pipelined", "scatter_allgather"] and all(rec["ms_per_step"] > 0 for rec in ab.values())
+            chosen = d["multi_gpu"]["broadcast_chosen"]
+            assert chosen in d["config"]["collective"] and abs(d["ms_per_step"] - ab[chosen]["ms_per_step"]) < 1e-3
+            assert ab[chosen]["ms_per_step"] == min(rec["ms_per_step"] for rec in ab.values())
         assert d["config"]["rccl"]["libmvsim"]["version_code"] > 0 and d["config"]["rccl"]["libmvsim"]["path"]
         assert ("off" in d["config"]["overlap"]) == ("--serial" in extra)
         # what makes a scaling run attributable: per-step broadcast / view times and every rank's own clock
@@ -2002,8 +2012,12 @@ def test_bench_rehearses_the_multi_gpu_data_path(tmp_path):
         # with their own broadcast, and BASELINE configs[3] -- every view cut into N z slabs, the sum reduced by the C ABI's collective
         big, tiled = d["size_512"], d["tiled_512"]
         assert big["value"] > 0 and big["multi_gpu"]["views_ms"] > 0 and "512^3" in big["workload"]
-        assert tiled["value"] > 0 and "mvsim_comm_allreduce_sum_f64" in tiled["reduction"] and "31x31x63" in tiled["workload"]
-        assert len(tiled["per_rank"]) == 1 and tiled["per_rank"][0]["planes_owned"] == 512 and tiled["per_rank"][0]["slab_convolve_ms_per_view"] > 0
+        # (the slab sum is reduced on the device inside mvsim_view_slab_dev since round 6; ranks that share a GPU fall back to the host form)
+        assert tiled["value"] > 0 and "31x31x63" in tiled["workload"]
+        assert "mvsim_view_slab_dev" in tiled["reduction"] or "mvsim_comm_allreduce_sum_f64" in tiled["reduction"]
+        # (one asynchronous call per view: the whole slab shows up in the wait behind it, finish_ms_per_view)
+        assert len(tiled["per_rank"]) == 1 and tiled["per_rank"][0]["planes_owned"] == 512 and "mvsim_view_slab_dev" in tiled["path"]
+        assert tiled["per_rank"][0]["slab_convolve_ms_per_view"] + tiled["per_rank"][0]["finish_ms_per_view"] > 0
 
 
 @pytest.mark.parametrize("shape,kshape,degrees,inc", [((40, 64, 64), (9, 5, 7), 33, 1),       # one wave per row batch

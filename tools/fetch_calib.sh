@@ -12,7 +12,7 @@ echo
 echo "## counters available that look at the L2's memory side"
 rocprofv3 -L 2>/dev/null | grep -o "TCC_EA0_[A-Z0-9_]*\|TCC_REQ[A-Z0-9_]*\|TCC_HIT[A-Z0-9_]*\|TCC_MISS[A-Z0-9_]*\|FETCH_SIZE\|WRITE_SIZE\|TCC_BUBBLE[A-Z0-9_]*\|TCC_READ[A-Z0-9_]*" | sort -u | tr '\n' ' '
 echo
-for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_READ_sum"; do
+for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_READ_sum"; do
   D=$O/$(echo $SET | tr ' ' '_')
   if rocprofv3 --pmc $SET -d $D -o run -- $B 1 > $D.log 2>&1; then
     echo "## --pmc $SET  (two launches per line of the plain run, in its order; value per launch)"

@@ -20,7 +20,12 @@ for kv in sys.argv[8:]:
         ctx.set_option(*kv.split("=", 1))
 # cheap compactly supported volume built on the host plane by plane
 w = lambda n: np.clip(1 - ((np.arange(n, dtype=np.float32) - (n - 1) / 2) / (0.3 * n)) ** 2, 0, None) ** 2
-if gt_kind == "phantom2x":
+if gt_kind in ("phantom", "dense"):          # the bench's 512^3 workload: the sphere phantom; dense = the same + 1e-6 in every voxel
+    assert nx == ny == nz
+    gt = synth.sphere_phantom(nx)
+    if gt_kind == "dense":
+        gt = gt + np.float32(1e-6)
+elif gt_kind == "phantom2x":
     assert nx == ny == nz and nx % 2 == 0
     gt = np.ascontiguousarray(synth.sphere_phantom(nx // 2).repeat(2, axis=0).repeat(2, axis=1).repeat(2, axis=2))
 else:
