@@ -62,12 +62,6 @@ int parse_option(Options& o, const char* name, const char* value)
         o.poisson_queue_share = k;
         return MVSIM_OK;
     }
-    if (n == "poisson_resolve_group") {                    // queue segments one resolver block takes as one list
-        if (v == "auto") { o.poisson_resolve_group = 0; return MVSIM_OK; }
-        if (v != "1" && v != "2" && v != "4" && v != "8") return MVSIM_EINVAL;
-        o.poisson_resolve_group = atoi(v.c_str());
-        return MVSIM_OK;
-    }
     if (n == "attenuate") {
         if (v == "serial") o.attenuate_scan = false; else if (v == "scan") o.attenuate_scan = true; else return MVSIM_EINVAL;
         return MVSIM_OK;
@@ -316,7 +310,7 @@ static int set_device(mvsim_ctx* ctx, bool keep_tail = false)
 // synchronising: a view whose segments refuse voxels still gives the right counts (slower), and the views after it get the larger queue.
 static int queue_mode_next(mvsim_ctx* ctx, QueueMode* qm)
 {
-    qm->share = 0; qm->hint = nullptr; qm->group = ctx->opt.poisson_resolve_group;
+    qm->share = 0; qm->hint = nullptr;
     if (ctx->opt.poisson_queue != 1) return MVSIM_OK;
     if (ctx->opt.poisson_queue_share > 0) { qm->share = ctx->opt.poisson_queue_share; return MVSIM_OK; }
     const unsigned int seen = *reinterpret_cast<volatile unsigned int*>(ctx->queue_hint);

@@ -134,7 +134,6 @@ struct Options {
                                        // segment refuses is sampled where it stands by a third kernel, same counts (k_poisson_refused).  0 =
                                        // "auto": 16 for queues of up to 64 MiB, else 5 (0.70 GiB at 512^3) and growing to what the context's
                                        // views turn out to need (the phantom: 3, a volume without an empty voxel: 12)
-    int     poisson_resolve_group = 0; // queue segments one resolver block takes as one list: 0 auto (RESOLVE_GROUP_DEFAULT), 1 / 2 / 4 / 8
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
     int     exp = 0;                   // experiment bits for A/B runs on one box (tools/): 1 = z pass tiles in plain grid order, 2 = k_zconv_strided wherever its
                                        // geometry allows (without the cost rule of zconv_strided_chunk), 4 = the 8-column tiles of the long y / z lines
@@ -175,10 +174,8 @@ struct Options {
 // max(QUEUE_SHARE_START, L) sixteenths, L being what this context's views have needed so far (api.cpp: queue_mode_next).
 constexpr int QUEUE_SHARE_AUTO = 32;
 constexpr int QUEUE_SHARE_START = 5;
-constexpr int RESOLVE_GROUP_DEFAULT = 4;   // queue segments a resolver block takes as one list (kernels.hip: k_poisson_resolve)
 struct QueueMode {
     int           share = 0;
-    int           group = 0;        // segments per resolver block: 0 = RESOLVE_GROUP_DEFAULT, else 1 / 2 / 4 / 8 (option poisson_resolve_group)
     unsigned int* hint  = nullptr;  // page-locked word k_poisson_refused raises to the sixteenths the fullest refused block would have needed
 };
 const Options& env_options();

@@ -937,11 +937,9 @@ __global__ __launch_bounds__(256) void k_extract_noise2_any(const float* __restr
     }
 }
 
-// One block per GROUP of S queue segments (the segments are the blocks of k_extract4_noise2, whose grid-stride walk spreads the
-// bright voxels over them; a group takes segments blockIdx.x + m * gridDim.x, i.e. stretches of the volume far apart, so that bright and
-// empty regions mix inside a group): poisson_dev.h, resolve_group_body.
-template <int S>
-__global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job, int segments, const ExtractView* __restrict__ vt)
+// One block per queue segment (same grid as k_extract4_noise2; the grid-stride walk of that kernel spreads the
+// bright voxels evenly over the segments).
+__global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job, const ExtractView* __restrict__ vt)
 {
     if (vt) {
         const ExtractView e = vt[blockIdx.y];
@@ -949,21 +947,8 @@ __global__ __launch_bounds__(256) void k_poisson_resolve(ResolveJob job, int seg
         job.k0 = e.k0; job.k1 = e.k1; job.stream = e.stream;
     }
     __shared__ unsigned int ticket;
-    resolve_group_body<S>(job, (long long)blockIdx.x, (long long)gridDim.x, (long long)segments, (int)threadIdx.x, &ticket);
-}
-
-// segments per resolver block: `group` (1, 2, 4, 8; option poisson_resolve_group) or, 0, the library's choice
-static void launch_resolve(hipStream_t s, const ResolveJob& job, int segments, unsigned gy, int group, const ExtractView* vt)
-{
-    int g = group > 0 ? group : RESOLVE_GROUP_DEFAULT;
-    while (g > 1 && segments < g * 1024) g >>= 1;          // small volumes: keep the chip's 256 CUs in blocks
-    const int blocks = (segments + g - 1) / g;
-    switch (g) {
-    case 8:  hipLaunchKernelGGL(k_poisson_resolve<8>, dim3(blocks, gy), dim3(256), 0, s, job, segments, vt); break;
-    case 4:  hipLaunchKernelGGL(k_poisson_resolve<4>, dim3(blocks, gy), dim3(256), 0, s, job, segments, vt); break;
-    case 2:  hipLaunchKernelGGL(k_poisson_resolve<2>, dim3(blocks, gy), dim3(256), 0, s, job, segments, vt); break;
-    default: hipLaunchKernelGGL(k_poisson_resolve<1>, dim3(blocks, gy), dim3(256), 0, s, job, segments, vt); break;
-    }
+    __shared__ double tab[RESOLVE_TAB];
+    resolve_segment_body(job, (long long)blockIdx.x, (int)threadIdx.x, &ticket, tab);
 }
 
 // Queues whose segments hold a SHARE of their blocks' voxels (poisson_queue_share < 16): the voxels a full segment refused, sampled
@@ -1021,7 +1006,7 @@ int launch_poisson_resolve(hipStream_t s, float* out, void* queue_items, const u
 {
     const ResolveJob job{out, reinterpret_cast<const PItem*>(queue_items), qcount, segcap, mul, (uint32_t)seed, (uint32_t)(seed >> 32), stream,
                          (unsigned int)plane, (unsigned int)idx_inc, (unsigned long long)index_offset, 0, 0, 0};     // full segments: no refusals
-    launch_resolve(s, job, segments, 1u, 0, nullptr);
+    hipLaunchKernelGGL(k_poisson_resolve, dim3(segments), dim3(256), 0, s, job, (const ExtractView*)nullptr);
     MVSIM_HIP(hipGetLastError());
     return MVSIM_OK;
 }
@@ -1166,7 +1151,7 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
 #undef MVSIM_LAUNCH_N2
             const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream, (unsigned int)plane, (unsigned int)index_inc,
                                   (unsigned long long)index_offset, qshare >= 16 ? 0 : 1, total / 4, 0};
-            launch_resolve(s, rjob, qblocks, gy, queue_mode.group, vt);
+            hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks, gy), dim3(256), 0, s, rjob, vt);
             if (rjob.walk != 0)
                 hipLaunchKernelGGL(k_poisson_refused, dim3(qblocks < REFUSED_BLOCKS ? qblocks : REFUSED_BLOCKS, gy), dim3(256), 0, s, rjob, qblocks,
                                    full_items, queue_mode.hint, vt);
@@ -1200,7 +1185,7 @@ static int launch_extract_impl(hipStream_t s, const float* in, float* out, const
 #undef MVSIM_LAUNCH_ANY
         const ResolveJob rjob{out, queue, qcount, segcap, mul, k0, k1, stream, (unsigned int)plane, (unsigned int)index_inc,
                               (unsigned long long)index_offset, qshare >= 16 ? 0 : 2, spp * nzo, spp};
-        launch_resolve(s, rjob, qblocks, gy, queue_mode.group, vt);
+        hipLaunchKernelGGL(k_poisson_resolve, dim3(qblocks, gy), dim3(256), 0, s, rjob, vt);
         if (rjob.walk != 0)
             hipLaunchKernelGGL(k_poisson_refused, dim3(qblocks < REFUSED_BLOCKS ? qblocks : REFUSED_BLOCKS, gy), dim3(256), 0, s, rjob, qblocks,
                                full_items, queue_mode.hint, vt);

@@ -100,9 +100,11 @@ __device__ const double kLogFact[17] = {
     8.525161361065415, 10.60460290274525, 12.801827480081469, 15.104412573075516, 17.502307845873887,
     19.987214495661885, 22.552163853123425, 25.19122118273868, 27.89927138384089, 30.671860106080672};
 
-__device__ __forceinline__ double det_lgamma_int(long long k)
+// (`lf`: where the table is read from -- the resolver keeps a copy in LDS: a dependent GLOBAL load inside its divergent attempt costs every
+// lane of the wave a trip to the cache)
+__device__ __forceinline__ double det_lgamma_int(long long k, const double* lf = kLogFact)
 {
-    if (k <= 16) return kLogFact[k < 0 ? 0 : k];
+    if (k <= 16) return lf[k < 0 ? 0 : k];
     const double x = (double)k + 1.0;
     const double ix = 1.0 / x;
     const double ix2 = ix * ix;
@@ -120,7 +122,7 @@ __device__ const double kInvK[64] = {
     1.0 / 55,  1.0 / 56, 1.0 / 57, 1.0 / 58, 1.0 / 59, 1.0 / 60, 1.0 / 61, 1.0 / 62, 1.0 / 63};
 
 // Inversion by sequential search for 0 < lambda < 10 on the 32-bit word `w` of the group block.
-__device__ __forceinline__ float poisson_small(double lambda, uint32_t w)
+__device__ __forceinline__ float poisson_small(double lambda, uint32_t w, const double* invk = kInvK)
 {
     const double u = ((double)w + 0.5) * 0x1.0p-32;
     double p = det_exp_neg(lambda);
@@ -128,7 +130,7 @@ __device__ __forceinline__ float poisson_small(double lambda, uint32_t w)
     int k = 0;
     while (u >= F && k < 63) {
         k += 1;
-        p = (p * lambda) * kInvK[k];
+        p = (p * lambda) * invk[k];
         F = F + p;
     }
     return (float)k;
@@ -172,12 +174,12 @@ __device__ __forceinline__ int ptrs_fast(const PtrsSetup& s, double lambda, uint
 
 // The exact acceptance test of one attempt.
 __device__ __forceinline__ bool ptrs_exact(const PtrsSetup& s, double lambda, double us, double V, double kd,
-                                           double& loglam, bool& have_loglam)
+                                           double& loglam, bool& have_loglam, const double* lf = kLogFact)
 {
     const double us2 = us * us;
     const double lhs = det_log((V * us2 * s.ianum) / (s.bm34 * (s.a + s.b * us2)));
     if (!have_loglam) { loglam = det_log(lambda); have_loglam = true; }
-    const double rhs = (-lambda + kd * loglam) - det_lgamma_int((long long)kd);
+    const double rhs = (-lambda + kd * loglam) - det_lgamma_int((long long)kd, lf);
     return lhs <= rhs;
 }
 
@@ -209,7 +211,7 @@ __device__ __forceinline__ double ptrs_retry(const PtrsSetup& s, double lambda, 
 // so every term is O(1..50) and single precision is accurate to ~1e-5 absolute.  Returns +1 (surely accept),
 // -1 (surely reject) or 0 (too close to call: run the bit-defined fp64 test).  Pure optimisation: whenever it
 // answers, the answer equals the fp64 decision (margin >= 100x the error bound), so counts are unchanged.
-__device__ __forceinline__ int ptrs_screen(const PtrsSetup& s, double lambda, double us, double V, double kd)
+__device__ __forceinline__ int ptrs_screen(const PtrsSetup& s, double lambda, double us, double V, double kd, const double* lf = kLogFact)
 {
     const float lam = (float)lambda;
     if (kd <= 16.0) {
@@ -220,7 +222,7 @@ __device__ __forceinline__ int ptrs_screen(const PtrsSetup& s, double lambda, do
         const float q0 = ((float)V * usq * (float)s.ianum) / ((float)s.bm34 * ((float)s.a + (float)s.b * usq));
         const float kf = (float)kd;
         const float ll = __logf(lam);
-        const float d0 = __logf(q0) - ((kf * ll - lam) - (float)kLogFact[(int)kd]);
+        const float d0 = __logf(q0) - ((kf * ll - lam) - (float)lf[(int)kd]);
         const float e0 = 1.0e-4f + 4.0e-6f * (kf * ll + lam);
         return d0 < -e0 ? 1 : (d0 > e0 ? -1 : 0);
     }
@@ -267,7 +269,7 @@ __device__ __forceinline__ int ptrs_screen(const PtrsSetup& s, double lambda, do
 
 // One attempt of one voxel from its two random words (used by the block-level work queue of
 // k_extract4_noise): returns true when the voxel is resolved.
-__device__ __forceinline__ bool ptrs_step_words(double lambda, uint32_t w0, uint32_t w1, float& res)
+__device__ __forceinline__ bool ptrs_step_words(double lambda, uint32_t w0, uint32_t w1, float& res, const double* lf = kLogFact)
 {
     const PtrsSetup s = ptrs_setup(lambda);
     double us, V, kd;
@@ -275,12 +277,12 @@ __device__ __forceinline__ bool ptrs_step_words(double lambda, uint32_t w0, uint
     if (st == 1) return false;
 #ifndef MVSIM_EXP_NOEXACT
     if (st == 2) {
-        const int sc = ptrs_screen(s, lambda, us, V, kd);
+        const int sc = ptrs_screen(s, lambda, us, V, kd, lf);
         if (sc < 0) return false;
         if (sc == 0) {
             double loglam = 0.0;
             bool have = false;
-            if (!ptrs_exact(s, lambda, us, V, kd, loglam, have)) return false;
+            if (!ptrs_exact(s, lambda, us, V, kd, loglam, have, lf)) return false;
         }
     }
 #endif
@@ -734,63 +736,44 @@ __device__ __forceinline__ bool refused_collect(const ResolveJob& j, long long s
     return true;
 }
 
-// S queue segments resolved by the 256 lanes of a block (k_poisson_resolve: kernels.hip).  The group's segments are first,
-// first + stride, ... (those below `segments`), and their items form ONE list: a lane that has resolved its item takes the next item
-// of the GROUP.  Round 6: with one segment per block (S = 1, rounds 2-5) a block's ~400 bright items were 1.6 items per lane -- a wave
-// ran two trips with every lane busy and then three more for the retries of its last items (each attempt is accepted with
-// probability 0.6-0.9, so the tail is 3-4 trips whatever the list's length): 40 % of its lane slots did work.  The tail is paid per
-// block, not per segment: S segments cost 2 S + 3 trips instead of 5 S.  Same arithmetic per (voxel, attempt): counts unchanged.
-template <int S>
-__device__ __forceinline__ void resolve_group_body(const ResolveJob& j, long long first, long long stride, long long segments, int t,
-                                                   unsigned int* ticket)
+constexpr int RESOLVE_TAB = 17 + 64;                         // doubles of LDS: log(k!) for k <= 16, then 1 / k for k < 64
+
+// One queue segment resolved by the 256 lanes of a block (k_poisson_resolve: kernels.hip).
+__device__ __forceinline__ void resolve_segment_body(const ResolveJob& j, long long segment, int t, unsigned int* ticket, double* tab)
 {
-    unsigned int cn[S], cs[S];                               // inclusive prefix counts over the group: bright items, inversion items
-    unsigned int n = 0u, ns = 0u;
-    bool refused = false;
-#pragma unroll
-    for (int m = 0; m < S; ++m) {
-        const long long sg = first + (long long)m * stride;
-        if (sg < segments) {                                 // block-uniform
-            n += j.qcount[QCOUNT_WORDS * sg];
-            ns += j.qcount[QCOUNT_WORDS * sg + 1];
-            refused |= j.qcount[QCOUNT_WORDS * sg + 2] != 0u;
-        }
-        cn[m] = n; cs[m] = ns;
-    }
+    const unsigned int n = j.qcount[QCOUNT_WORDS * segment], ns = j.qcount[QCOUNT_WORDS * segment + 1];
     // a block that was refused queue slots says so in the header: k_poisson_refused, the next kernel, reads that one word
-    if (t == 0 && j.walk != 0 && refused) const_cast<unsigned int*>(j.qcount)[QCOUNT_HEADER + 2] = 1u;
-    // item i of the group's list: which segment, and where in it
-    auto locate = [&](const unsigned int* cum, unsigned int i, unsigned int& local) -> const PItem* {
-        unsigned int m = 0u, base = 0u;
-#pragma unroll
-        for (int q = 0; q + 1 < S; ++q)
-            if (i >= cum[q]) { m = (unsigned int)(q + 1); base = cum[q]; }
-        local = i - base;
-        return j.queue + (unsigned long long)(first + (long long)m * stride) * j.segcap;
-    };
-    // inversion items (0 < lambda < 10 that the shortcut of phase 1 could not settle), from the back of their segments
-    for (unsigned int i = (unsigned int)t; i < ns; i += 256u) {
-        unsigned int local;
-        const PItem* __restrict__ seg = locate(cs, i, local);
-        const PItem it = seg[j.segcap - 1u - local];
-        j.out[it.out] = poisson_small((double)it.v * j.mul, it.w0);     // w0: the voxel's word of its group block
-    }
-    // PTRS items.  A lane works on ONE ATTEMPT per trip and, the moment its item is resolved, takes the next item of the
-    // group (LDS ticket): every trip has every lane on a live attempt, instead of the wave idling until its unluckiest
-    // item -- retries come in geometrically distributed numbers -- has been accepted.  The loop ends when the tickets run
-    // out: each attempt succeeds with probability > 0.6 and the attempt count is capped, so every lane gets there.
+    if (t == 0 && j.walk != 0 && j.qcount[QCOUNT_WORDS * segment + 2] != 0u) const_cast<unsigned int*>(j.qcount)[QCOUNT_HEADER + 2] = 1u;
+    // the two small tables the recipe indexes, from LDS: a dependent GLOBAL load inside the divergent attempt costs every lane of the
+    // wave a trip to the cache
+    if (t < 17) tab[t] = kLogFact[t];
+    else if (t < RESOLVE_TAB) tab[t] = kInvK[t - 17];
     if (t == 0) *ticket = 256u;
     __syncthreads();
+    const double* lf = tab;
+    const double* invk = tab + 17;
+    const PItem* __restrict__ seg = j.queue + (unsigned long long)segment * j.segcap;
+    // inversion items (0 < lambda < 10 that the shortcut of phase 1 could not settle), from the back
+    for (unsigned int i = (unsigned int)t; i < ns; i += 256u) {
+        const PItem it = seg[j.segcap - 1u - i];
+        j.out[it.out] = poisson_small((double)it.v * j.mul, it.w0, invk);     // w0: the voxel's word of its group block
+    }
+    // PTRS items.  A lane works on ONE ATTEMPT per trip and, the moment its item is resolved, takes the next item of the
+    // segment (LDS ticket): every trip has every lane on a live attempt, instead of the wave idling until its unluckiest
+    // item -- retries come in geometrically distributed numbers -- has been accepted.  The loop ends when the tickets run
+    // out: each attempt succeeds with probability > 0.6 and the attempt count is capped, so every lane gets there.
     unsigned int i = (unsigned int)t;
     PItem it;
     it.out = 0u; it.v = 0.f; it.w0 = 0u; it.w1 = 0u;
     bool have = i < n;
-    if (have) { unsigned int local; const PItem* __restrict__ seg = locate(cn, i, local); it = seg[local]; }
+    if (have) it = seg[i];
     // The words of the attempt a lane is about to evaluate always sit in it.w0 / it.w1: phase 1's words for attempt 0, and for a retry the
     // words drawn at the END of the failed attempt.  (Rounds 2-5 chose between the two at the top of the loop, by `a == 0`; the compiler
     // threaded that test through the back edges, and what came out was an outer loop over items with an INNER loop over the retries of
     // one item -- lanes whose item was accepted waited for the wave's unluckiest item before any of them took a new one, the very thing
-    // the ticket is there to avoid.  Found in the ISA in round 6.)
+    // the ticket is there to avoid.  Found in the ISA in round 6: 1 706 -> 1 366 vector instructions per wave, the stage 0.510 -> 0.487 ms,
+    // profiles/r06_resolver_ab.txt.  Measured on top of it and not kept: several segments per block as one list (fewer, longer-lived
+    // blocks: fewer instructions, more waiting), the next item requested one attempt ahead (held items are items no other lane can take).)
     uint32_t a = 0u;
     if (have) do {
         const double lam = (double)it.v * j.mul;
@@ -800,13 +783,14 @@ __device__ __forceinline__ void resolve_group_body(const ResolveJob& j, long lon
             val = (float)(long long)lam;
             done = true;
         } else {
-            done = ptrs_step_words(lam, it.w0, it.w1, val);
+            done = ptrs_step_words(lam, it.w0, it.w1, val, lf);
         }
         if (done) {
             j.out[it.out] = val;
+            a = 0u;
             i = atomicAdd(ticket, 1u);
             have = i < n;
-            if (have) { unsigned int local; const PItem* __restrict__ seg = locate(cn, i, local); it = seg[local]; a = 0u; }
+            if (have) it = seg[i];
         } else {
             a += 1u;
             const unsigned int kpl = j.idx_inc == 1u ? 0u : it.out / j.plane;
