@@ -30,6 +30,7 @@
 #undef MVSIM_EXP_NOBRIGHT
 #undef MVSIM_P1_F64
 #undef MVSIM_EXP_NLZ
+#undef MVSIM_EXP_LINES_STAMPS
 #endif
 
 namespace mvsim {

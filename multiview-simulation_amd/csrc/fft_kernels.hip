@@ -64,7 +64,7 @@ struct LinesArgs {
     const double2* wx;
     const double2* wy;
     double*       sum_partial;
-    int           pair_tiles;       // 8-column tiles: the two tiles of a 128-byte line on one XCD (see k_fft_lines; option `pair_tiles`, default 1)
+    int           pair_tiles;       // 8-column tiles: the two tiles of a 128-byte line on one XCD (see k_fft_lines; exp bit 4 clears it)
 };
 
 #ifndef MVSIM_ZBS
@@ -75,6 +75,23 @@ struct LinesArgs {
 #endif
 constexpr int ZBS = MVSIM_ZBS, ZB = 1 << ZBS;        // rows per block of the z-blocked layout
 constexpr int NZ_EXT = 96;                          // mirrored planes the flag bit string holds in front of plane 0 (>= Kz - 1 + tap padding)
+
+#if defined(MVSIM_DEV_ATTRIBUTION) && defined(MVSIM_EXP_LINES_STAMPS)
+// Attribution build only (tools/lines_timeline.py): shader-clock stamps of the phases of every block of the image's y passes --
+// [mode FWD / INV][block][8]: start, loads requested, loads arrived, tile staged (barrier), this wave's transform done, barrier, stores
+// requested.  The last launch of each mode stays in the buffer.
+constexpr int STAMP_BLOCKS = 1 << 20;
+__device__ unsigned long long g_line_stamps[2][STAMP_BLOCKS][8];
+#define MVSIM_STAMP(k)                                                                                                       \
+    do {                                                                                                                     \
+        if (!SPARSE && (MODE == FWD || MODE == INV) && threadIdx.x == 0) {                                                   \
+            const unsigned long long sb_ = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;                          \
+            if (sb_ < (unsigned long long)STAMP_BLOCKS) g_line_stamps[MODE == INV][sb_][k] = __builtin_amdgcn_s_memtime();   \
+        }                                                                                                                    \
+    } while (0)
+#else
+#define MVSIM_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ int mirror_index(int i, int n)
 {
@@ -126,6 +143,7 @@ void k_fft_lines(LinesArgs p)
             tile_x = (int)(lin % nt); tile_o = (int)(lin / nt);
         }
     }
+    MVSIM_STAMP(0);
     const int by = tile_o >= p.outer_skip_lo ? tile_o + p.outer_skip_len : tile_o;
     if (p.nzflags) {
         // block-uniform (one scalar load): nothing of an empty plane is read, transformed or stored -- its readers skip it on the
@@ -167,7 +185,9 @@ void k_fft_lines(LinesArgs p)
             }
         }
     }
+    MVSIM_STAMP(1);
     for (int i = tid; i < L; i += T) tw[i] = p.tw[i];
+    MVSIM_STAMP(2);                                             // (behind the wait for the twiddles, i.e. for every load before them)
     constexpr int R1 = PLAN::R1, IT1 = (LW * (L / R1) + 63) / 64;
     float2 ps[MODE == CONVZ ? IT1 : 1][MODE == CONVZ ? R1 : 1];
     if constexpr (MODE == CONVZ) {
@@ -196,7 +216,9 @@ void k_fft_lines(LinesArgs p)
         }
     }
     __syncthreads();
+    MVSIM_STAMP(3);
     PLAN::template run<LW>(wbuf, tw, lane);
+    MVSIM_STAMP(4);
     if (MODE == CONV) {
         // x PSF spectrum, conjugate, transform again (inverse = conj FFT conj).  The spectrum is stored tile-major
         // (each line contiguous), so the wave that owns a line streams its spectrum line straight into the first
@@ -217,6 +239,7 @@ void k_fft_lines(LinesArgs p)
         return;
     }
     __syncthreads();
+    MVSIM_STAMP(5);
     float2* dbase = p.dst + outer_off(p.dst_outer, p.dst_oblk) + (long long)tile_x * NL + c2;
     const int nstore = p.store_limit > 0 ? p.store_limit : L;
     float2 sa = make_float2(0.f, 0.f), sb = make_float2(0.f, 0.f);       // CONVZ: this thread's share of its two lines' sums over z
@@ -230,6 +253,7 @@ void k_fft_lines(LinesArgs p)
             if (MODE == CONVZ) { sa = cadd(sa, a); sb = cadd(sb, b); }
         }
     }
+    MVSIM_STAMP(6);
     if constexpr (MODE == CONVZ) {
         if (p.sum_partial) {
             // adjustImage's sum from the spectrum side, as k_zconv's epilogue: SUM_z of every line (fp32 over a thread's <= NIT rows,
@@ -2105,3 +2129,13 @@ int custom_fft_convolve_slab(mvsim_ctx* ctx, const float* img, const int64_t dim
 }
 
 }  // namespace mvsim
+
+#if defined(MVSIM_DEV_ATTRIBUTION) && defined(MVSIM_EXP_LINES_STAMPS)
+// attribution build only: the stamps of blocks [0, nblocks) of mode `inv` (see g_line_stamps), 8 words per block
+extern "C" int mvsim_dev_read_line_stamps(int inv, unsigned long long* out, size_t nblocks)
+{
+    if (nblocks > (size_t)mvsim::fft::STAMP_BLOCKS) nblocks = (size_t)mvsim::fft::STAMP_BLOCKS;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mvsim::fft::g_line_stamps), nblocks * 8 * sizeof(unsigned long long),
+                                    (size_t)(inv ? 1 : 0) * mvsim::fft::STAMP_BLOCKS * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#endif

@@ -2049,6 +2049,37 @@ def test_fused_rotate_attenuate_x_transform_is_bit_identical(mvs, synth, shape, 
     assert float(res[1][0]["acq"].max()) > 0
 
 
+@pytest.mark.parametrize("shape,kshape,degrees,inc,fused", [((8, 600, 600), (5, 9, 7), 20, 1, 0),      # y lines of 640 points, separate kernels
+                                                           ((8, 700, 700), (7, 9, 31), 25, 1, 1),     # 720 points, fused kernel: mirrored halo rows from their mirror images
+                                                           ((6, 1030, 1030), (5, 15, 9), -35, 2, 0),  # 1080 points, compact planes in pass D
+                                                           ((3, 2060, 2060), (3, 63, 5), 60, 1, 0)])  # 2160 points: one block per CU
+def test_paired_y_tiles_of_long_lines_are_bit_identical(mvs, synth, orc, shape, kshape, degrees, inc, fused):
+    """Round 6: on lines of more than 576 points the y passes move 8-column tiles (64-byte rows), and the two tiles of a 128-byte line
+    now go to ONE XCD, one behind the other in its dispatch order (k_fft_lines; in grid order both XCDs' L2s fetched the whole line:
+    profiles/r06_fetch_calibration.txt).  Only which block takes which tile changes: the adjusted convolved volume and the counts are
+    identical to the grid order (option exp=4), and meet the convolution's contract against the oracle."""
+    rng = np.random.default_rng(91)
+    gt = synth.sphere_phantom(shape[2], shape[1], shape[0]) + (rng.random(shape, dtype=np.float32) < 0.03).astype(np.float32)
+    psf = rng.random(kshape, dtype=np.float32) + 0.05
+    res = {}
+    for exp in (0, 4):
+        with mvs.Context(0) as c:
+            c.set_option("exp", exp)
+            c.set_option("fused_fftx", fused)
+            p = c.view_params(degrees=degrees, inc=inc, snr=25.0, seed=SEED, stream=2, conv_method=1)
+            res[exp] = (c.simulate_view(gt, psf.copy(), p, want=("att", "con", "acq")), c.simulate_view(gt, psf.copy(), p, want=("acq",)))
+    assert float(res[0][0]["att"].max()) > 0 and not np.isnan(res[0][0]["con"]).any()
+    for k in ("att", "con", "acq"):
+        assert np.array_equal(res[0][0][k], res[4][0][k]), k
+    assert np.array_equal(res[0][1]["acq"], res[4][1]["acq"])
+    want = orc.convolve_fft(res[0][0]["att"], psf.copy())
+    got = res[0][0]["con"]
+    # con is the ADJUSTED volume: undo Tools.adjustImage's scale and offset (approximately) before comparing
+    scale = float((got.astype(np.float64) - 1e-4).sum() / want.astype(np.float64).sum())
+    assert rel_to_max((got - np.float32(1e-4)) / np.float32(scale), want) <= 5 * CONV_TOL
+    assert float(res[0][0]["acq"].max()) > 0
+
+
 def test_bench_line_carries_the_contract_keys():
     """bench.py's one JSON line (small volume, so that the test stays short): the contract keys, `value` on the library
     defaults with a serial leg beside it, a roofline whose fused-byte fractions never exceed 1 and that says where the x
