@@ -28,7 +28,7 @@ with a rocprofv3 --kernel-trace of `bench.py --serial`).
 Rank 0 prints ONE JSON line (schema in the task contract) including
   roofline     -- dominant stage: algorithmic bytes / HIP-event time against the 8 TB/s HBM peak, `fused_bytes` /
                   `frac_fused` on the bytes the fused path must move, plus the PMC-measured traffic of the same stage
-                  (profiles/r05_traffic.json, valid only for the kernel sources it was measured on); with
+                  (profiles/r06_traffic.json, valid only for the kernel sources it was measured on); with
                   --conv-method 2 the direct stencil against the 157.3 Tflop/s fp32 vector peak (bound "fp32")
   cpu_baseline -- the CPU oracle (C restatement of the reference's ImgLib2 path, not the JVM) on a bounded sample, two modes:
                   as_reference (the reference's threading) and all_cores
@@ -67,8 +67,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (same guide); the direct stencil's bound
 # PMC traffic record of the running build (tools/profile_all.sh writes it first and points the bench at it through the environment)
-TRAFFIC_JSON = os.environ.get("MVSIM_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r05_traffic.json")
-TRAFFIC_JSON_1024 = os.environ.get("MVSIM_TRAFFIC_JSON_1024") or os.path.join(ROOT, "profiles", "r05_traffic_1024.json")
+TRAFFIC_JSON = os.environ.get("MVSIM_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r06_traffic.json")
+TRAFFIC_JSON_1024 = os.environ.get("MVSIM_TRAFFIC_JSON_1024") or os.path.join(ROOT, "profiles", "r06_traffic_1024.json")
 
 
 def parse_args():
@@ -423,7 +423,7 @@ def roofline_record(mvs, stage: dict, nvox: int, nprime: int, n: int, psf_edge: 
                 "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stages[dom]["frac"],
                 "fused_bytes": fused[dom], "frac_fused": stages[dom]["frac_fused"],
                 # HBM bytes of the dominant stage per view from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE,
-                # separate passes of `bench.py --serial` (profiles/r05_traffic.json); null when that record does not describe
+                # separate passes of `bench.py --serial` (profiles/r06_traffic.json); null when that record does not describe
                 # this build / workload
                 "traffic": stages[dom].get("traffic"),
                 "hbm_measured": stages[dom].get("hbm_measured"),

@@ -226,7 +226,10 @@ int mvsim_simulate_view_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3
  * views share dim and kdim.  The library runs as many of them side by side as pays for their size (option "view_lanes" =
  * auto|1..32: child contexts of `ctx` on the same device, forked from and joined to ctx's stream, so the call is asynchronous on
  * that stream like mvsim_simulate_view_dev).  Every output is bit-identical to what n_views sequential mvsim_simulate_view_dev
- * calls write.  Output buffers must not overlap each other or the ground truth (MVSIM_EINVAL). */
+ * calls write -- also when several views name the SAME (or overlapping) PSF memory, e.g. one buffer for all views: such PSFs are
+ * normalised one after the other in view order, exactly as sequential calls would (a buffer named n times is normalised n times;
+ * distinct buffers are normalised by one host thread each).  Output buffers must not overlap each other or the ground truth
+ * (MVSIM_EINVAL). */
 int mvsim_simulate_views_dev(mvsim_ctx* ctx, const float* gt, const int64_t dim[3], float* const* psf_host,
                              const int64_t kdim[3], const mvsim_view_params* params, const mvsim_view_outputs* outs,
                              int n_views);
@@ -363,7 +366,10 @@ int mvsim_comm_broadcast_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count, i
  * been REGISTERED: a collective -- every rank calls it, in the same order as the other collectives of the communicator, each for
  * its own buffer of >= count floats; it synchronises the context's stream.  A registration is never reused for another buffer:
  * registering again replaces it, mvsim_comm_unregister_volume (local), mvsim_dev_free of the buffer and mvsim_comm_destroy drop
- * it.  One process per rank (ranks that share a process use the RCCL forms). */
+ * it -- LOCALLY: the other ranks keep their mappings of this rank's buffer until THEY unregister, register again or destroy their
+ * communicator.  So a registered volume is unregistered (or freed) on EVERY rank before any rank runs another peer_copy broadcast;
+ * a broadcast into a registration one rank has already dropped writes through a mapping of freed memory.
+ * One process per rank (ranks that share a process use the RCCL forms). */
 int mvsim_comm_register_volume(mvsim_ctx* ctx, float* vol_dev, int64_t count);
 /* Option "broadcast" = pipelined: scatter + all-gather loads the root's outbound links twice (its scatter chunks, then its own chunk of
  * the all-gather: 2 S / (N b) for a volume of S bytes over links of b bytes/s).  The pipelined form scatters the WHOLE volume as N - 1

@@ -2225,6 +2225,38 @@ def test_simulate_views_dev_equals_sequential_views(mvs, synth):
                     c.dev_free(d)
 
 
+def test_stacked_views_that_share_one_psf_buffer(mvs, synth):
+    """`mvsim_simulate_views_dev(..., [psf] * V, ...)` -- every view names the SAME PSF memory.  Sequential calls normalise that
+    buffer V times, one after the other (Tools.normImage in place, SMVD:255; after the first pass the sum is 1 up to rounding, so the
+    later passes move single ulps), and the stacked path does the same, in view order, instead of normalising it from V host threads at
+    once: acquisitions and the buffer itself are bit-identical to the sequential calls, run after run."""
+    n, k, nv = 64, 9, 8
+    gt = synth.sphere_phantom(n)
+    raw = synth.gaussian_psf(k, sigma=(1.2, 1.4, 2.2))
+    with mvs.Context(0) as c:
+        d_gt = _dev_volume(c, gt)
+        acq = [c.dev_alloc(gt.nbytes) for _ in range(nv)]
+        params = [c.view_params(degrees=15 + 45 * v, inc=1, snr=25.0, seed=SEED, stream=v, conv_method=1) for v in range(nv)]
+        try:
+            shared = raw.copy()
+            for v in range(nv):
+                c.simulate_view_dev(d_gt, (n, n, n), shared, params[v], acq[v])
+            want = [c.download(a, gt.shape) for a in acq]
+            want_psf = shared.copy()
+            for rep in range(3):
+                for a in acq:
+                    c.upload(a, np.full(gt.shape, -1.0, np.float32))
+                c.set_option("view_batch", 1)
+                mine = raw.copy()
+                c.simulate_views_dev(d_gt, (n, n, n), [mine] * nv, params, acq)
+                assert np.array_equal(mine, want_psf), rep
+                for v in range(nv):
+                    assert np.array_equal(c.download(acq[v], gt.shape), want[v]), (rep, v)
+        finally:
+            for d in [d_gt] + acq:
+                c.dev_free(d)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_geometries_against_oracle(mvs, orc, seed):
     """Random volume shapes (Nx <= Ny, odd and even, not multiples of the 16-row / 16-column tiles), PSF shapes, angles,
