@@ -1314,7 +1314,7 @@ def main():
         for form in BROADCAST_FORMS:
             if form == args.broadcast or legs_error:
                 continue
-            wd = start_watchdog(out, 240.0, f"the broadcast form '{form}' (multi_gpu.broadcast_ab)") if (world > 1 and rank == 0) else None
+            wd = start_watchdog(out, 90.0, f"the broadcast form '{form}' (multi_gpu.broadcast_ab)") if (world > 1 and rank == 0) else None
             try:
                 run.set_broadcast(form)
                 run.step(); run.step(); run.sync()            # both ground-truth buffers through this form before anything is timed
@@ -1345,8 +1345,8 @@ def main():
     watchdog = None
     if world > 1 and rank == 0:
         # The legs below are collectives over every rank: a rank that dies inside one leaves the others waiting.  The line of record
-        # exists already; if the legs have not come back after ten minutes, rank 0 prints it without them and ends the job.
-        watchdog = start_watchdog(out, 600.0, "the legs behind the line of record")
+        # exists already; if the legs have not come back after five minutes, rank 0 prints it without them and ends the job.
+        watchdog = start_watchdog(out, 300.0, "the legs behind the line of record")
     if multi and args.conv_method == 1 and n <= 512 and not legs_error:
         # the other sizes north_star names, on the N > 1 data path: 1024^3 views sharded v % N (`size_1024`) and BASELINE configs[3] as
         # stated -- every 1024^3 view cut into N z slabs (`tiled_1024`).  Every rank takes part; rank 0 reports.  (The legs run at twice

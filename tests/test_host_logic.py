@@ -448,13 +448,13 @@ def test_committed_pmc_traffic_belongs_to_this_build():
     so it is reported as a skip, with what bench.py will do about it."""
     import importlib, json
     build = importlib.import_module("multiview-simulation_amd.build")
-    for name in ("r05_traffic.json", "r05_traffic_1024.json"):
+    for name in ("r06_traffic.json", "r06_traffic_1024.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             pytest.skip(f"profiles/{name} has not been collected yet (bash tools/profile_all.sh TAG on a GPU box): bench.py prints roofline.traffic = null")
         rec = json.load(open(path))
         assert rec["views_profiled"] >= 1 and rec["per_view_bytes"]["convolve"] > 0
-    path = os.path.join(ROOT, "profiles", "r05_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r06_traffic.json")
     rec = json.load(open(path))
     if rec["kernel_sha"] != build.source_sha():
         pytest.skip(f"{os.path.relpath(path, ROOT)} was collected on kernel sources {rec['kernel_sha']}, this tree is {build.source_sha()}: "

@@ -1,5 +1,5 @@
 """Print the figures DESIGN.md / README.md quote from one profile directory of tools/profile_all.sh:
-    python tools/design_numbers.py gpurun_out/prof_r05_d"""
+    python tools/design_numbers.py gpurun_out/prof_r06_b"""
 import csv, json, sys
 O = sys.argv[1]
 d = json.loads([l for l in open(O + "/bench.json") if l.startswith("{")][-1])

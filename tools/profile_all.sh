@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collect the rocprofv3 artefacts of profiles/ for the current build (run on the GPU box through gpurun):
-#   bash tools/profile_all.sh r05_a
+#   bash tools/profile_all.sh r06_a
 # Order matters: the PMC traffic passes come FIRST and write traffic.json keyed by the SHA of the kernel sources;
 # bench.py runs afterwards with MVSIM_TRAFFIC_JSON pointing at it, so that the bench line of record carries roofline.traffic of
 # the very build it measured.  Counter passes run on their own (no trace domains beside --pmc), FETCH_SIZE and WRITE_SIZE in
 # separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
