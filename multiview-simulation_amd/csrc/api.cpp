@@ -68,9 +68,11 @@ int parse_option(Options& o, const char* name, const char* value)
     }
     if (n == "early_sum") return flag(&o.early_sum);
     if (n == "zconv_strided") return flag(&o.zconv_strided);
-    if (n == "exp") {                                  // A/B bits of tools/ and the tests (common.h): 0 .. 7
-        if (v.size() != 1 || v[0] < '0' || v[0] > '7') return MVSIM_EINVAL;
-        o.exp = v[0] - '0';
+    if (n == "exp") {                                  // A/B bits of tools/ and the tests (common.h): 0 .. 15
+        if (v.empty() || v.size() > 2 || v.find_first_not_of("0123456789") != std::string::npos) return MVSIM_EINVAL;
+        const int k = atoi(v.c_str());
+        if (k > 15) return MVSIM_EINVAL;
+        o.exp = k;
         return MVSIM_OK;
     }
     if (n == "fuse_tail") return flag(&o.fuse_tail);

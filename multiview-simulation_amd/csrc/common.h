@@ -138,7 +138,8 @@ struct Options {
     bool    early_sum = true;          // adjustImage's sum from the spectrum side (pass C epilogue) so that pass E can adjust
     int     exp = 0;                   // experiment bits for A/B runs on one box (tools/): 1 = z pass tiles in plain grid order, 2 = k_zconv_strided wherever its
                                        // geometry allows (without the cost rule of zconv_strided_chunk), 4 = the 8-column tiles of the long y / z lines
-                                       // in plain grid order (the two tiles of a 128-byte line on different XCDs, as before round 6)
+                                       // in plain grid order (the two tiles of a 128-byte line on different XCDs, as before round 6),
+                                       // 8 = the image's y passes on lines of one block per CU (L >= 1280) as ONE transform (k_fft_lines) instead of two half-length phases (k_fft_lines_split)
     bool    zconv_strided = true;      // views that only return the acquisition (compact planes, inc > 1): the direct z pass computes the
                                        // planes k * inc alone (k_zconv_strided: 1 / inc of the taps' work) and takes adjustImage's sum from
                                        // its INPUT rows (the sum over all planes is a linear functional of them); 0: every plane, as round 3

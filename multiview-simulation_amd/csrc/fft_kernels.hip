@@ -24,6 +24,7 @@
 #include <cstring>
 
 namespace mvsim {
+static int ensure_twiddles(mvsim_ctx* ctx, int L, int kind, const float2** out);   // (defined behind the kernels; launch_lines needs the split form's tables)
 namespace fft {
 
 // ---------------------------------------------------------------------------------- y / z pass kernel
@@ -277,6 +278,117 @@ void k_fft_lines(LinesArgs p)
                 if (lane == 0) p.sum_partial[(long long)tile_o * gridDim.x + tile_x] = t;
             }
         }
+    }
+}
+
+// The image's y passes on lines that leave a CU room for ONE tile (L >= 1280: 8 lines x (L + 1) x 8 B > 80 KB; configs[4]'s 2160-point lines),
+// round 6 -- instantiated for L = 2048 and 2160.  With one block per CU nothing overlaps: the block clock stamps (profiles/r06_lines_timeline.txt) show a 2160-point block alive for
+// 60 k ticks of which 32 k are its loads, 20 k its transform and the barrier behind it, 5 k its stores -- HBM idles while it transforms, the
+// SIMDs idle while it loads (2.6 TB/s per pass against 4.4 at 1080 points, where two blocks interleave).  Here the FIRST radix-2 stage of a
+// decimation-in-frequency transform runs in REGISTERS as the rows arrive -- a lane loads rows n and n + L/2 of its two columns,
+//     e[n] = x[n] + x[n + L/2],   o[n] = (x[n] - x[n + L/2]) w_L^n      (X[2k] = FFT_{L/2}(e)[k],  X[2k + 1] = FFT_{L/2}(o)[k])
+// -- and the two half-length transforms pass through an 8-line LDS tile of L/2 points one after the other: e is staged, transformed with the
+// half length's own plan and stored to the even rows; then o (kept in registers meanwhile: 36 VGPRs at 2160 points) to the odd rows.  Half
+// the LDS: TWO blocks per CU, as on the 1080-point lines.  Same result as the L-point plan up to rounding (another factorisation: 2 x the
+// half plan instead of the table's radices for L; measured 2-4e-7 of the range apart, tests/test_gpu_parity.py); option exp bit 8 keeps the
+// one-block form for A/B runs.  tw2 = exp(-2 pi i n / L), n < L/2 (ensure_twiddles kind 1); p.tw = the HALF plan's pass table.
+template <class PLANH, int MODE>
+__global__ __launch_bounds__(Cfg<PLANH::len>::T, (2 * Cfg<PLANH::len>::T + 255) / 256)
+void k_fft_lines_split(LinesArgs p, const float2* __restrict__ tw2)
+{
+    static_assert(MODE == FWD || MODE == INV, "the image's y passes");
+    constexpr int LH = PLANH::len;
+    using C = Cfg<LH>;
+    constexpr int NL = C::NL, LP = C::LP, T = C::T, LW = C::LW;
+    static_assert(NL == 8 && 2 * C::LDS <= 160 * 1024, "8-line tiles of the half length, two per CU");
+    constexpr int LPR = NL / 2;             // lanes per position: one float4 = two adjacent columns
+    constexpr int ROWS = T / LPR;
+    constexpr int NIT = (LH + ROWS - 1) / ROWS;
+    extern __shared__ __align__(16) float2 lds[];
+    float2* buf = lds;
+    float2* tw = lds + NL * LP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c2 = (tid % LPR) * 2;
+    const int r0 = tid / LPR;
+    float2* wbuf = buf + wave * LW * LP;
+    // the two tiles of a 128-byte line on one XCD, one behind the other in its dispatch order (see k_fft_lines)
+    int tile_x = (int)blockIdx.x, tile_o = (int)blockIdx.y;
+    {
+        const unsigned nt = gridDim.x, total = nt * gridDim.y, b = blockIdx.y * nt + blockIdx.x;
+        if ((nt & 1u) == 0 && b < (total & ~15u) && p.pair_tiles) {
+            const unsigned xcd = b & 7u, slot = b >> 3;
+            const unsigned lin = ((((slot >> 1) << 3) + xcd) << 1) | (slot & 1u);
+            tile_x = (int)(lin % nt); tile_o = (int)(lin / nt);
+        }
+    }
+    const int by = tile_o >= p.outer_skip_lo ? tile_o + p.outer_skip_len : tile_o;
+    if (p.nzflags) {
+        if (p.nzflags[by * p.nz_stride] == 0) return;              // an empty plane (block-uniform): see k_fft_lines
+    }
+    auto outer_off = [&](long long outer, long long oblk) {
+        return oblk ? (long long)(by >> ZBS) * oblk + (long long)(by & (ZB - 1)) * outer : (long long)by * outer;
+    };
+    const float2* sbase = p.src + outer_off(p.src_outer, p.src_oblk) + (long long)tile_x * NL + c2;
+    auto row = [&](int pos) -> float4 {                            // position `pos` of the padded line, this lane's two columns
+        if (pos >= p.gap_lo && pos < p.gap_hi) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int sn = p.src_mirror ? map_src(p.lmap, pos) : pos;
+        return *reinterpret_cast<const float4*>(sbase + line_off(sn, p.src_es, p.src_blk));
+    };
+    float4 lo[NIT], hi[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int n = r0 + it * ROWS;
+        lo[it] = hi[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((LH % ROWS == 0) || n < LH) {
+            lo[it] = row(n);
+            hi[it] = row(n + LH);
+        }
+    }
+    // the first stage's twiddles w_L^n pass through the LDS region of the half plan's table, which takes their place before the first
+    // transform (registers: the 72 of the tile's rows leave no room for 18 more across the loads)
+    for (int i = tid; i < LH; i += T) tw[i] = tw2[i];
+    __syncthreads();
+    // first stage in registers: lo <- e, hi <- o (inverse transform: conj FFT conj, as everywhere)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int n = r0 + it * ROWS;
+        const float2 w = tw[((LH % ROWS == 0) || n < LH) ? n : 0];
+        float2 a0 = make_float2(lo[it].x, lo[it].y), a1 = make_float2(lo[it].z, lo[it].w);
+        float2 b0 = make_float2(hi[it].x, hi[it].y), b1 = make_float2(hi[it].z, hi[it].w);
+        if (MODE == INV) { a0 = cconj(a0); a1 = cconj(a1); b0 = cconj(b0); b1 = cconj(b1); }
+        const float2 e0 = cadd(a0, b0), e1 = cadd(a1, b1);
+        const float2 o0 = cmul(csub(a0, b0), w), o1 = cmul(csub(a1, b1), w);
+        lo[it] = make_float4(e0.x, e0.y, e1.x, e1.y);
+        hi[it] = make_float4(o0.x, o0.y, o1.x, o1.y);
+    }
+    __syncthreads();                                                // every lane has read its twiddles: the plan's table takes the region
+    for (int i = tid; i < LH; i += T) tw[i] = p.tw[i];
+    float2* dbase = p.dst + outer_off(p.dst_outer, p.dst_oblk) + (long long)tile_x * NL + c2;
+    const int nstore = p.store_limit > 0 ? p.store_limit : 2 * LH;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int n = r0 + it * ROWS;
+            if ((LH % ROWS == 0) || n < LH) {
+                const float4 v = h == 0 ? lo[it] : hi[it];
+                buf[c2 * LP + n] = make_float2(v.x, v.y);
+                buf[(c2 + 1) * LP + n] = make_float2(v.z, v.w);
+            }
+        }
+        __syncthreads();
+        PLANH::template run<LW>(wbuf, tw, lane);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k = r0 + it * ROWS, n = 2 * k + h;            // output k of this half is row 2 k + h of the line
+            if (((LH % ROWS == 0) || k < LH) && n < nstore) {
+                float2 a = buf[c2 * LP + k], b = buf[(c2 + 1) * LP + k];
+                if (MODE != FWD) { a = cconj(a); b = cconj(b); }
+                *reinterpret_cast<float4*>(dbase + line_off(n, p.dst_es, p.dst_blk)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        if (h == 0) __syncthreads();                                // the odd half overwrites the tile
     }
 }
 
@@ -1482,10 +1594,74 @@ static int c2r_rows_per_block(int M)
     return 0;
 }
 
+// the half-length plans k_fft_lines_split is instantiated for: 2 LH is a table length whose own tile leaves a CU room for one block only,
+// and the 8-line tile of LH points fits twice
+// (... and whose blocks are eight waves, one line each: measured, profiles/r06_split_ab.txt -- 2160 = 2 x 1080 and 2048 = 2 x 1024 gain
+// 15-25 % per pass; 1792 = 2 x 896, four waves of two lines with 112 registers of rows per lane, loses in pass B what it gains in pass D)
+template <int LH> constexpr bool split_half_ok()
+{
+    return Cfg<LH>::NL == 8 && Cfg<LH>::T == 512 && 2 * Cfg<LH>::LDS <= 160 * 1024 && 2 * Cfg<2 * LH>::LDS > 160 * 1024;
+}
+
+template <int LH, int... Rs>
+static int launch_lines_split_t(mvsim_ctx* ctx, int mode, const LinesArgs& a, const float2* tw2, int tiles, int nouter)
+{
+    if constexpr (LH >= 1024 && LH <= 1120 && split_half_ok<LH>()) {
+        using PLANH = Plan<LH, Rs...>;
+        using C = Cfg<LH>;
+        dim3 grid(tiles, nouter), block(C::T);
+        if (mode == FWD) {
+            MVSIM_TRY(set_lds(ctx, k_fft_lines_split<PLANH, FWD>, C::LDS));
+            hipLaunchKernelGGL((k_fft_lines_split<PLANH, FWD>), grid, block, C::LDS, ctx->stream, a, tw2);
+        } else {
+            MVSIM_TRY(set_lds(ctx, k_fft_lines_split<PLANH, INV>, C::LDS));
+            hipLaunchKernelGGL((k_fft_lines_split<PLANH, INV>), grid, block, C::LDS, ctx->stream, a, tw2);
+        }
+        MVSIM_HIP(hipGetLastError());
+        return MVSIM_OK;
+    }
+    set_error("custom FFT: no split form for half length %d", LH);
+    return MVSIM_EINVAL;
+}
+
+static bool lines_split_available(int L)
+{
+    if (L % 2) return false;
+    switch (L / 2) {
+#define X(LL, ...) case LL: if constexpr (LL >= 1024 && LL <= 1120) return split_half_ok<LL>(); else return false;
+        MVSIM_FFT_SIZES(X)
+#undef X
+    }
+    return false;
+}
+
+static bool lines_has_plan(int L)
+{
+    switch (L) {
+#define X(LL, ...) case LL: return true;
+        MVSIM_FFT_SIZES(X)
+#undef X
+    }
+    return false;
+}
+
 static int launch_lines(mvsim_ctx* s, int L, int mode, bool sparse, const LinesArgs& a0, int tiles, int nouter)
 {
     LinesArgs a = a0;
     a.pair_tiles = (s->opt.exp & 4) ? 0 : 1;              // exp bit 4: 8-column tiles in plain grid order (A/B, tools/ab_env.sh)
+    // lines of one block per CU: the image's y passes as two half-length transforms (k_fft_lines_split) unless exp bit 8 asks for the
+    // one-block form; the PSF's sparse passes and the z-pass forms keep k_fft_lines
+    if ((mode == FWD || mode == INV) && !sparse && !a.dst_tile_major && !(s->opt.exp & 8) && lines_has_plan(L) && lines_split_available(L)) {
+        const float2 *twh = nullptr, *tw2 = nullptr;
+        MVSIM_TRY(ensure_twiddles(s, L / 2, 0, &twh));
+        MVSIM_TRY(ensure_twiddles(s, L, 1, &tw2));
+        a.tw = twh;
+        switch (L / 2) {
+#define X(LL, ...) case LL: return launch_lines_split_t<LL, __VA_ARGS__>(s, mode, a, tw2, tiles, nouter);
+            MVSIM_FFT_SIZES(X)
+#undef X
+        }
+    }
     switch (L) {
 #define X(LL, ...) \
     case LL: return launch_lines_t<Plan<LL, __VA_ARGS__>>(s, mode, sparse, a, tiles, nouter);

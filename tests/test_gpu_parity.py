@@ -2080,6 +2080,36 @@ def test_paired_y_tiles_of_long_lines_are_bit_identical(mvs, synth, orc, shape, 
     assert float(res[0][0]["acq"].max()) > 0
 
 
+@pytest.mark.parametrize("shape,kshape,degrees,inc,fused", [((4, 2010, 2010), (3, 31, 5), 20, 1, 0),     # y lines of 2048 points = 2 x 1024, separate kernels
+                                                           ((3, 2000, 2000), (3, 31, 7), -25, 1, 1),    # 2048 = 2 x 1024, fused kernel (16 waves): mirrored halo rows
+                                                           ((6, 2060, 2060), (5, 63, 5), 60, 3, 0)])    # 2160 = 2 x 1080 (configs[4]'s lines), compact planes in pass D
+def test_split_y_lines_agree_with_the_single_transform(mvs, synth, orc, shape, kshape, degrees, inc, fused):
+    """Round 6: y lines whose 8-line tile leaves a CU room for one block only (L >= 1280) are transformed as TWO half-length transforms
+    (k_fft_lines_split: the first radix-2 stage in registers as the rows arrive, then e and o through a half-length tile one after the
+    other -- two blocks per CU).  Another factorisation of the same transform: the adjusted convolved volume agrees with the one-block
+    form (option exp=8) to rounding, far inside the convolution's contract, which both meet against the oracle; the counts follow
+    their lambdas (a count moves where a rounding moves a lambda across a decision of the sampler: ~1e-4 of the voxels)."""
+    rng = np.random.default_rng(92)
+    gt = synth.sphere_phantom(shape[2], shape[1], shape[0]) + (rng.random(shape, dtype=np.float32) < 0.03).astype(np.float32)
+    psf = rng.random(kshape, dtype=np.float32) + 0.05
+    res = {}
+    for exp in (0, 8):
+        with mvs.Context(0) as c:
+            c.set_option("exp", exp)
+            c.set_option("fused_fftx", fused)
+            p = c.view_params(degrees=degrees, inc=inc, snr=25.0, seed=SEED, stream=2, conv_method=1)
+            res[exp] = c.simulate_view(gt, psf.copy(), p, want=("att", "con", "acq"))
+    assert float(res[0]["att"].max()) > 0 and not np.isnan(res[0]["con"]).any()
+    assert np.array_equal(res[0]["att"], res[8]["att"])
+    assert rel_to_max(res[0]["con"], res[8]["con"]) <= 2e-6
+    assert np.mean(res[0]["acq"] != res[8]["acq"]) < 1e-3            # (where a rejection flips, the count is another draw altogether)
+    want = orc.convolve_fft(res[0]["att"], psf.copy())
+    for exp in (0, 8):
+        got = res[exp]["con"]
+        scale = float((got.astype(np.float64) - 1e-4).sum() / want.astype(np.float64).sum())
+        assert rel_to_max((got - np.float32(1e-4)) / np.float32(scale), want) <= 5 * CONV_TOL, exp
+
+
 def test_bench_line_carries_the_contract_keys():
     """bench.py's one JSON line (small volume, so that the test stays short): the contract keys, `value` on the library
     defaults with a serial leg beside it, a roofline whose fused-byte fractions never exceed 1 and that says where the x
