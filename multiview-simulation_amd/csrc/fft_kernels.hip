@@ -282,7 +282,7 @@ void k_fft_lines(LinesArgs p)
 }
 
 // The image's y passes on lines that leave a CU room for ONE tile (L >= 1280: 8 lines x (L + 1) x 8 B > 80 KB; configs[4]'s 2160-point lines),
-// round 6 -- instantiated for L = 2048 and 2160.  With one block per CU nothing overlaps: the block clock stamps (profiles/r06_lines_timeline.txt) show a 2160-point block alive for
+// round 6 -- instantiated for L = 2048, 2160 and 2240 (split_half_ok).  With one block per CU nothing overlaps: the block clock stamps (profiles/r06_lines_timeline.txt) show a 2160-point block alive for
 // 60 k ticks of which 32 k are its loads, 20 k its transform and the barrier behind it, 5 k its stores -- HBM idles while it transforms, the
 // SIMDs idle while it loads (2.6 TB/s per pass against 4.4 at 1080 points, where two blocks interleave).  Here the FIRST radix-2 stage of a
 // decimation-in-frequency transform runs in REGISTERS as the rows arrive -- a lane loads rows n and n + L/2 of its two columns,
@@ -300,7 +300,7 @@ void k_fft_lines_split(LinesArgs p, const float2* __restrict__ tw2)
     constexpr int LH = PLANH::len;
     using C = Cfg<LH>;
     constexpr int NL = C::NL, LP = C::LP, T = C::T, LW = C::LW;
-    static_assert(NL == 8 && 2 * C::LDS <= 160 * 1024, "8-line tiles of the half length, two per CU");
+    static_assert(2 * C::LDS <= 160 * 1024, "tiles of the half length, two per CU");
     constexpr int LPR = NL / 2;             // lanes per position: one float4 = two adjacent columns
     constexpr int ROWS = T / LPR;
     constexpr int NIT = (LH + ROWS - 1) / ROWS;
@@ -311,9 +311,9 @@ void k_fft_lines_split(LinesArgs p, const float2* __restrict__ tw2)
     const int c2 = (tid % LPR) * 2;
     const int r0 = tid / LPR;
     float2* wbuf = buf + wave * LW * LP;
-    // the two tiles of a 128-byte line on one XCD, one behind the other in its dispatch order (see k_fft_lines)
+    // 8-column tiles: the two tiles of a 128-byte line on one XCD, one behind the other in its dispatch order (see k_fft_lines)
     int tile_x = (int)blockIdx.x, tile_o = (int)blockIdx.y;
-    {
+    if constexpr (NL * sizeof(float2) < 128) {
         const unsigned nt = gridDim.x, total = nt * gridDim.y, b = blockIdx.y * nt + blockIdx.x;
         if ((nt & 1u) == 0 && b < (total & ~15u) && p.pair_tiles) {
             const unsigned xcd = b & 7u, slot = b >> 3;
@@ -329,9 +329,19 @@ void k_fft_lines_split(LinesArgs p, const float2* __restrict__ tw2)
         return oblk ? (long long)(by >> ZBS) * oblk + (long long)(by & (ZB - 1)) * outer : (long long)by * outer;
     };
     const float2* sbase = p.src + outer_off(p.src_outer, p.src_oblk) + (long long)tile_x * NL + c2;
-    auto row = [&](int pos) -> float4 {                            // position `pos` of the padded line, this lane's two columns
+    // position `pos` of the padded line, this lane's two columns.  The mirrored halo rows (pass B behind the fused rotate kernel) by ONE
+    // reflection -- the launcher takes this kernel only where the halo is shorter than the image --: map_src's general path (a modulo)
+    // costs the 18 address computations of a lane registers they do not have
+    const int mir_n = p.src_mirror ? p.lmap.n : (1 << 30), mir_a = p.src_mirror ? p.lmap.a : (1 << 30), mir_P = p.lmap.P, mir_b = p.lmap.b;
+    auto row = [&](int pos) -> float4 {
         if (pos >= p.gap_lo && pos < p.gap_hi) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const int sn = p.src_mirror ? map_src(p.lmap, pos) : pos;
+        int sn = pos;
+        if (pos >= mir_a) {                                        // (never without src_mirror)
+            if (pos < mir_P - mir_b) return make_float4(0.f, 0.f, 0.f, 0.f);
+            sn = pos - mir_P;
+        }
+        sn = sn < 0 ? -sn : sn;
+        sn = sn >= mir_n ? 2 * mir_n - 2 - sn : sn;
         return *reinterpret_cast<const float4*>(sbase + line_off(sn, p.src_es, p.src_blk));
     };
     float4 lo[NIT], hi[NIT];
@@ -377,7 +387,11 @@ void k_fft_lines_split(LinesArgs p, const float2* __restrict__ tw2)
             }
         }
         __syncthreads();
-        PLANH::template run<LW>(wbuf, tw, lane);
+        // a wave's lines one at a time: with the odd half pinned in registers a two-line transform (its butterflies' operands side by
+        // side) does not fit the 128 VGPRs of two blocks per CU; one line after the other costs the same pass iterations (60 .. 180
+        // butterflies of a 540-point line fill the 64 lanes as well as 120 .. 360 of two)
+#pragma unroll 1
+        for (int j = 0; j < LW; ++j) PLANH::template run<1>(wbuf + j * LP, tw, lane);
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -1596,8 +1610,15 @@ static int c2r_rows_per_block(int M)
 
 // the half-length plans k_fft_lines_split is instantiated for: 2 LH is a table length whose own tile leaves a CU room for one block only,
 // and the 8-line tile of LH points fits twice
-// (... and whose blocks are eight waves, one line each: measured, profiles/r06_split_ab.txt -- 2160 = 2 x 1080 and 2048 = 2 x 1024 gain
-// 15-25 % per pass; 1792 = 2 x 896, four waves of two lines with 112 registers of rows per lane, loses in pass B what it gains in pass D)
+// (... and whose blocks are eight waves: measured, profiles/r06_split_ab.txt -- 2160 = 2 x 1080 and 2048 = 2 x 1024 gain
+// 15-25 % per pass; 1792 = 2 x 896, four waves of two lines with 112 registers of rows per lane, loses in pass B what it gains in pass D).
+// The same form would serve the lines of 1024 .. 1152 points for another reason -- their halves (512 .. 576 points) take SIXTEEN-column
+// tiles: 128-byte rows in every load and store, two blocks per CU either way -- and was built and run for them (the kernel below takes
+// 16-column half tiles as it stands: WIDE in the launcher; same tests, green).  It is NOT instantiated there: with two lines
+// per wave the compiler does not fit the 72 registers of a lane's rows, their addresses and the pinned odd half into the 128 of two blocks
+// per CU (104-228 bytes of scratch in every variant tried: all rows at once, groups of three with the even half written to LDS at once,
+// one-reflection addressing), spills rows as they arrive -- i.e. waits for them one by one -- and pass B at 1024^3 takes 2.66 instead
+// of 1.66 ms (profiles/r06_split_ab.txt).
 template <int LH> constexpr bool split_half_ok()
 {
     return Cfg<LH>::NL == 8 && Cfg<LH>::T == 512 && 2 * Cfg<LH>::LDS <= 160 * 1024 && 2 * Cfg<2 * LH>::LDS > 160 * 1024;
@@ -1609,7 +1630,10 @@ static int launch_lines_split_t(mvsim_ctx* ctx, int mode, const LinesArgs& a, co
     if constexpr (LH >= 1024 && LH <= 1120 && split_half_ok<LH>()) {
         using PLANH = Plan<LH, Rs...>;
         using C = Cfg<LH>;
-        dim3 grid(tiles, nouter), block(C::T);
+        // `tiles` counts tiles of the whole length's width (8 columns); the half length's tiles may be 16 wide
+        constexpr int WIDE = C::NL / Cfg<2 * LH>::NL;
+        if (tiles % WIDE) { set_error("custom FFT: %d tiles of 8 columns do not pair up", tiles); return MVSIM_EINVAL; }
+        dim3 grid(tiles / WIDE, nouter), block(C::T);
         if (mode == FWD) {
             MVSIM_TRY(set_lds(ctx, k_fft_lines_split<PLANH, FWD>, C::LDS));
             hipLaunchKernelGGL((k_fft_lines_split<PLANH, FWD>), grid, block, C::LDS, ctx->stream, a, tw2);
@@ -1651,7 +1675,8 @@ static int launch_lines(mvsim_ctx* s, int L, int mode, bool sparse, const LinesA
     a.pair_tiles = (s->opt.exp & 4) ? 0 : 1;              // exp bit 4: 8-column tiles in plain grid order (A/B, tools/ab_env.sh)
     // lines of one block per CU: the image's y passes as two half-length transforms (k_fft_lines_split) unless exp bit 8 asks for the
     // one-block form; the PSF's sparse passes and the z-pass forms keep k_fft_lines
-    if ((mode == FWD || mode == INV) && !sparse && !a.dst_tile_major && !(s->opt.exp & 8) && lines_has_plan(L) && lines_split_available(L)) {
+    if ((mode == FWD || mode == INV) && !sparse && !a.dst_tile_major && !(s->opt.exp & 8) && lines_has_plan(L) && lines_split_available(L) &&
+        tiles % 2 == 0 && (!a.src_mirror || (a.lmap.mode == 0 && a.lmap.b < a.lmap.n && a.lmap.a - a.lmap.n < a.lmap.n))) {
         const float2 *twh = nullptr, *tw2 = nullptr;
         MVSIM_TRY(ensure_twiddles(s, L / 2, 0, &twh));
         MVSIM_TRY(ensure_twiddles(s, L, 1, &tw2));

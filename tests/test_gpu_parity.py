@@ -2057,21 +2057,24 @@ def test_paired_y_tiles_of_long_lines_are_bit_identical(mvs, synth, orc, shape, 
     """Round 6: on lines of more than 576 points the y passes move 8-column tiles (64-byte rows), and the two tiles of a 128-byte line
     now go to ONE XCD, one behind the other in its dispatch order (k_fft_lines; in grid order both XCDs' L2s fetched the whole line:
     profiles/r06_fetch_calibration.txt).  Only which block takes which tile changes: the adjusted convolved volume and the counts are
-    identical to the grid order (option exp=4), and meet the convolution's contract against the oracle."""
+    identical to the grid order (option exp bit 4), and meet the convolution's contract against the oracle."""
     rng = np.random.default_rng(91)
     gt = synth.sphere_phantom(shape[2], shape[1], shape[0]) + (rng.random(shape, dtype=np.float32) < 0.03).astype(np.float32)
     psf = rng.random(kshape, dtype=np.float32) + 0.05
     res = {}
-    for exp in (0, 4):
+    # (exp bit 8: the whole-length 8-column tiles also where the library would split the line into two half-length transforms -- the
+    # 1080- and 2160-point cases, test_split_y_lines_agree_with_the_single_transform; bit 4: those tiles in plain grid order)
+    for exp in (8, 12):
         with mvs.Context(0) as c:
             c.set_option("exp", exp)
             c.set_option("fused_fftx", fused)
             p = c.view_params(degrees=degrees, inc=inc, snr=25.0, seed=SEED, stream=2, conv_method=1)
             res[exp] = (c.simulate_view(gt, psf.copy(), p, want=("att", "con", "acq")), c.simulate_view(gt, psf.copy(), p, want=("acq",)))
-    assert float(res[0][0]["att"].max()) > 0 and not np.isnan(res[0][0]["con"]).any()
+    assert float(res[8][0]["att"].max()) > 0 and not np.isnan(res[8][0]["con"]).any()
     for k in ("att", "con", "acq"):
-        assert np.array_equal(res[0][0][k], res[4][0][k]), k
-    assert np.array_equal(res[0][1]["acq"], res[4][1]["acq"])
+        assert np.array_equal(res[8][0][k], res[12][0][k]), k
+    assert np.array_equal(res[8][1]["acq"], res[12][1]["acq"])
+    res[0] = res[8]
     want = orc.convolve_fft(res[0][0]["att"], psf.copy())
     got = res[0][0]["con"]
     # con is the ADJUSTED volume: undo Tools.adjustImage's scale and offset (approximately) before comparing
@@ -2084,9 +2087,9 @@ def test_paired_y_tiles_of_long_lines_are_bit_identical(mvs, synth, orc, shape, 
                                                            ((3, 2000, 2000), (3, 31, 7), -25, 1, 1),    # 2048 = 2 x 1024, fused kernel (16 waves): mirrored halo rows
                                                            ((6, 2060, 2060), (5, 63, 5), 60, 3, 0)])    # 2160 = 2 x 1080 (configs[4]'s lines), compact planes in pass D
 def test_split_y_lines_agree_with_the_single_transform(mvs, synth, orc, shape, kshape, degrees, inc, fused):
-    """Round 6: y lines whose 8-line tile leaves a CU room for one block only (L >= 1280) are transformed as TWO half-length transforms
-    (k_fft_lines_split: the first radix-2 stage in registers as the rows arrive, then e and o through a half-length tile one after the
-    other -- two blocks per CU).  Another factorisation of the same transform: the adjusted convolved volume agrees with the one-block
+    """Round 6: y lines of 2048 / 2160 / 2240 points (whose 8-line tile leaves a CU room for one block only) are transformed as TWO
+    half-length transforms (k_fft_lines_split: the first radix-2 stage in registers as the rows arrive, then e and o through a
+    half-length tile one after the other -- two blocks per CU).  Another factorisation of the same transform: the adjusted convolved volume agrees with the one-block
     form (option exp=8) to rounding, far inside the convolution's contract, which both meet against the oracle; the counts follow
     their lambdas (a count moves where a rounding moves a lambda across a decision of the sampler: ~1e-4 of the voxels)."""
     rng = np.random.default_rng(92)
