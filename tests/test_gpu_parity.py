@@ -2085,7 +2085,8 @@ def test_paired_y_tiles_of_long_lines_are_bit_identical(mvs, synth, orc, shape, 
 
 @pytest.mark.parametrize("shape,kshape,degrees,inc,fused", [((4, 2010, 2010), (3, 31, 5), 20, 1, 0),     # y lines of 2048 points = 2 x 1024, separate kernels
                                                            ((3, 2000, 2000), (3, 31, 7), -25, 1, 1),    # 2048 = 2 x 1024, fused kernel (16 waves): mirrored halo rows
-                                                           ((6, 2060, 2060), (5, 63, 5), 60, 3, 0)])    # 2160 = 2 x 1080 (configs[4]'s lines), compact planes in pass D
+                                                           ((6, 2060, 2060), (5, 63, 5), 60, 3, 0),     # 2160 = 2 x 1080 (configs[4]'s lines), compact planes in pass D
+                                                           ((3, 2200, 2200), (3, 31, 5), 10, 1, 0)])    # 2240 = 2 x 1120: two tiles of 81 KB per CU
 def test_split_y_lines_agree_with_the_single_transform(mvs, synth, orc, shape, kshape, degrees, inc, fused):
     """Round 6: y lines of 2048 / 2160 / 2240 points (whose 8-line tile leaves a CU room for one block only) are transformed as TWO
     half-length transforms (k_fft_lines_split: the first radix-2 stage in registers as the rows arrive, then e and o through a
