@@ -2114,6 +2114,26 @@ def test_split_y_lines_agree_with_the_single_transform(mvs, synth, orc, shape, k
         assert rel_to_max((got - np.float32(1e-4)) / np.float32(scale), want) <= 5 * CONV_TOL, exp
 
 
+def test_split_y_lines_in_place_behind_the_padded_z_transform(mvs, synth, orc):
+    """k_fft_lines_split where the y passes run IN PLACE on a z-padded spectrum (option fft_zpass=fft: the formulation for PSFs deeper
+    than 64 taps): a block reads every row of its tile before it stores the first, so rows 2k / 2k + 1 may overwrite rows n / n + L/2;
+    the planes of the z gap are skipped by the outer index map.  Against the one-block form (exp=8) and the oracle."""
+    shape, kshape = (5, 2010, 2010), (5, 31, 7)
+    rng = np.random.default_rng(93)
+    v = (synth.sphere_phantom(shape[2], shape[1], shape[0]) + (rng.random(shape, dtype=np.float32) < 0.03)).astype(np.float32)
+    psf = rng.random(kshape, dtype=np.float32) + 0.05
+    res = {}
+    for exp in (0, 8):
+        with mvs.Context(0) as c:
+            c.set_option("exp", exp)
+            c.set_option("fft_zpass", "fft")
+            res[exp] = c.convolve(v, psf.copy(), method=1)
+    want = orc.convolve_fft(v, psf.copy())
+    assert rel_to_max(res[0], res[8]) <= 2e-6
+    for exp in (0, 8):
+        assert rel_to_max(res[exp], want) <= CONV_TOL, exp
+
+
 def test_bench_line_carries_the_contract_keys():
     """bench.py's one JSON line (small volume, so that the test stays short): the contract keys, `value` on the library
     defaults with a serial leg beside it, a roofline whose fused-byte fractions never exceed 1 and that says where the x
