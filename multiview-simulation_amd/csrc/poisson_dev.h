@@ -138,6 +138,11 @@ __device__ __forceinline__ float poisson_small(double lambda, uint32_t w, const 
 
 __device__ __forceinline__ double u32_open(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
 
+// An integer-valued double (a floor: the count PTRS proposes) as float.  The recipe's (float)(long long)d rounds that integer to the nearest
+// float, and so does (float)d -- the same value for every |d| < 2^63 -- in ONE conversion; f64 -> i64 -> f32 has no instruction of its own
+// and costs ~16 per value (two per pair in every PTRS trip of phase 1: 4 % of its vector instructions).
+__device__ __forceinline__ float count_as_float(double d) { return (float)d; }
+
 constexpr uint32_t kPtrsMaxAttempts = 60000u;   // cap (never reached in practice: p ~ 0.1^k); then floor(lambda)
 
 // ---- Hoermann PTRS for lambda >= 10 on 32-bit uniforms, split into pieces so that the one-voxel and the
@@ -286,7 +291,7 @@ __device__ __forceinline__ bool ptrs_step_words(double lambda, uint32_t w0, uint
         }
     }
 #endif
-    res = (float)(long long)kd;
+    res = count_as_float(kd);
     return true;
 }
 
@@ -532,7 +537,7 @@ __device__ __forceinline__ bool ptrs_squeeze_f32(double lambda, uint32_t w0, uin
     const double fl = floor(y);
     const float frac = (float)(y - fl);
     const float g = 4.0e-6f * t + 1.0e-5f;
-    res = (float)(long long)fl;
+    res = count_as_float(fl);
     return us >= 0.070001f && V * bm2 <= (0.9277f * bm2 - 3.6224f) - (4.0e-6f * b + 1.0e-5f) && frac >= g && frac <= 1.0f - g &&
            lambda < 1.0e9;
 }
